@@ -1,0 +1,425 @@
+/* TEST INFRASTRUCTURE — CPU oracle, NOT part of the product path.
+ *
+ * Clean-room plain-C restatement of the reference's hot path (jing2li/MGPreconditionedGCR @
+ * 2024_10_08), function by function, in the reference's own operation order so that results
+ * agree with the real reference to rounding (most of them bit for bit).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library — as the
+ * checker, never as the thing shipped or measured.  The HIP library never links or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against the
+ * golden vectors in tests/golden/ that were produced by the real reference compiled here
+ * (oracle/ref_harness.cpp, tests/golden/make_golden.py).  The one part with no reference
+ * output is the multigrid *application* (src/MG.h:124-129,405-430 returns uninitialised
+ * memory): orc_mg_* restates its well-defined pieces (pinned) and a
+ * corrected cycle (documented in DESIGN.md; "parity unpinned" for the cycle as a whole).
+ *
+ * Every function cites the reference lines it follows (paths relative to the reference root).
+ * All complex data is C99 `double _Complex`, layout-compatible with std::complex<double> and
+ * with interleaved (re,im) doubles.  gcc's complex multiply (__muldc3) is the same routine
+ * libstdc++'s std::complex<double>::operator* lowers to, so element-wise results match g++.
+ */
+#include <complex.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef double _Complex cplx;
+
+/* ------------------------------------------------------------------ Field algebra -------- */
+
+/* src/Fields.h:216-226  dot(a,b) = sum_i conj(a_i) * b_i, sequential, index order */
+void orc_dot(int64_t n, const cplx *a, const cplx *b, cplx *out) {
+    cplx s = 0.0;
+    for (int64_t i = 0; i < n; i++) s += conj(a[i]) * b[i];
+    *out = s;
+}
+
+/* src/Fields.h:228-235  squarednorm = Re sum_i conj(a_i) * a_i (complex accumulator) */
+double orc_sqnorm(int64_t n, const cplx *a) {
+    cplx s = 0.0;
+    for (int64_t i = 0; i < n; i++) s += conj(a[i]) * a[i];
+    return creal(s);
+}
+
+/* src/Fields.h:192-214,245-253  out = a + b*alpha  (operator* computes `alpha * b_i`) */
+void orc_add_scaled(int64_t n, const cplx *a, const cplx *b, const cplx *alpha, cplx *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = a[i] + (*alpha) * b[i];
+}
+/* out = a - b*alpha */
+void orc_sub_scaled(int64_t n, const cplx *a, const cplx *b, const cplx *alpha, cplx *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = a[i] - (*alpha) * b[i];
+}
+/* src/Fields.h:237-243  normalise: field[i] *= 1./norm */
+void orc_normalise(int64_t n, cplx *a) {
+    double nrm = sqrt(orc_sqnorm(n, a));
+    for (int64_t i = 0; i < n; i++) a[i] *= 1. / nrm;
+}
+
+/* ------------------------------------------------------------------ operators ------------ */
+
+typedef enum { OP_CSR = 1, OP_DIRAC = 2, OP_BCSR = 3, OP_GCR = 4, OP_MG = 5 } op_kind;
+
+struct orc_op;
+typedef struct orc_gcr_param {
+    /* mirror of GCR_Param (src/SolverParam.h:21-35) */
+    int truncation, restart, max_iter;
+    double tol;
+    int verbose;
+    struct orc_op *left_precond, *right_precond;
+    /* extensions the reference does not have (both default 0 = reference behaviour):
+     *  use_x0      r0 = b - A x0 instead of the reference's r0 = b (src/GCR.h:189)
+     *  flexible    proper flexible right preconditioning: p = M r, Ap = A p, r stays the true
+     *              residual — instead of the reference's literal r = M(r) (src/GCR.h:236-238) */
+    int use_x0, flexible;
+} orc_gcr_param;
+
+typedef struct orc_mg orc_mg;
+
+typedef struct orc_op {
+    op_kind kind;
+    int64_t dim;
+    /* CSR (src/Operator.h:56-101): int64 indices as in the reference (num_type = long) */
+    int64_t nrow;
+    const int64_t *rowptr, *col;
+    const cplx *val;
+    /* Dirac = 1 - k D (src/Operator.h:104-122) */
+    struct orc_op *D;
+    cplx k;
+    /* block-CSR of dense bs x bs blocks (src/HierarchicalSparse.h:22-48) */
+    int32_t nbrow, bs;
+    int32_t *browptr, *bcol;
+    cplx *blocks;
+    /* GCR used as an operator (src/GCR.h:62-68) */
+    struct orc_op *A;
+    orc_gcr_param gp;
+    int x0_mode; /* 0: reference (x0 = caller-supplied random field, r0 = b) ; 1: x0 = 0 */
+    /* MG */
+    orc_mg *mg;
+    int owns;
+} orc_op;
+
+void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
+
+/* src/Operator.h:330-346  y_row = sum_l VAL[l] * x[COL[l]], sequential per row */
+static void csr_apply(const orc_op *op, const cplx *x, cplx *y) {
+    for (int64_t row = 0; row < op->nrow; row++) {
+        cplx sum = 0.0;
+        for (int64_t l = op->rowptr[row]; l < op->rowptr[row + 1]; l++) sum += op->val[l] * x[op->col[l]];
+        y[row] = sum;
+    }
+}
+
+/* src/Operator.h:569-575  f - (D f) * k */
+static void dirac_apply(const orc_op *op, const cplx *x, cplx *y) {
+    cplx *t = (cplx *)malloc(sizeof(cplx) * (size_t)op->dim);
+    orc_op_apply(op->D, x, t);
+    for (int64_t i = 0; i < op->dim; i++) y[i] = x[i] - op->k * t[i];
+    free(t);
+}
+
+/* src/HierarchicalSparse.h:101-161 with Dense::operator() (src/Operator.h:159-173) as the block
+ * kernel: value = 0; for l in row: value += Dense_l(x_block[col]);  Dense: out[r] = 0, then
+ * out[r] = out[r] + mat[r*bs+c] * f[c] for c ascending. */
+static void bcsr_apply(const orc_op *op, const cplx *x, cplx *y) {
+    int bs = op->bs;
+    cplx *tmp = (cplx *)malloc(sizeof(cplx) * (size_t)bs);
+    for (int32_t brow = 0; brow < op->nbrow; brow++) {
+        cplx *value = y + (size_t)brow * bs;
+        for (int i = 0; i < bs; i++) value[i] = 0.0;
+        for (int32_t l = op->browptr[brow]; l < op->browptr[brow + 1]; l++) {
+            const cplx *m = op->blocks + (size_t)l * bs * bs;
+            const cplx *f = x + (size_t)op->bcol[l] * bs;
+            for (int r = 0; r < bs; r++) {
+                cplx o = 0.0;
+                for (int c = 0; c < bs; c++) o = o + m[r * bs + c] * f[c];
+                tmp[r] = o;
+            }
+            for (int r = 0; r < bs; r++) value[r] += tmp[r]; /* Field::operator+= src/Fields.h:288-297 */
+        }
+    }
+    free(tmp);
+}
+
+orc_op *orc_op_csr(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const cplx *val) {
+    orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+    op->kind = OP_CSR; op->dim = ncol; op->nrow = nrow;
+    op->rowptr = rowptr; op->col = col; op->val = val; /* borrowed: caller keeps them alive */
+    return op;
+}
+orc_op *orc_op_dirac(orc_op *D, double k_re, double k_im) {
+    orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+    op->kind = OP_DIRAC; op->dim = D->dim; op->D = D; op->k = k_re + k_im * I;
+    return op;
+}
+
+/* src/HierarchicalSparse.h:58-98  unsorted (row,col,block) triplets -> block-CSR; duplicates of a
+ * (row,col) pair are KEPT (summed at apply time).  Sorted by key row*nbcol+col.  The reference
+ * uses std::sort, whose order among equal keys is unspecified; we use a stable sort (equal keys
+ * keep input order) — sums over duplicates may differ from the reference in the last bit. */
+typedef struct { int64_t key; int32_t idx; } trip_key;
+static int trip_cmp(const void *a, const void *b) {
+    const trip_key *x = (const trip_key *)a, *y = (const trip_key *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+orc_op *orc_op_bcsr_from_triplets(int32_t nbrow, int32_t nbcol, int32_t bs, int32_t nt, const int32_t *rows,
+                                  const int32_t *cols, const cplx *blocks) {
+    orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+    op->kind = OP_BCSR; op->dim = (int64_t)nbcol * bs; op->nbrow = nbrow; op->bs = bs; op->owns = 1;
+    op->browptr = (int32_t *)calloc((size_t)nbrow + 1, sizeof(int32_t));
+    op->bcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)nt);
+    op->blocks = (cplx *)malloc(sizeof(cplx) * (size_t)nt * bs * bs);
+    trip_key *keys = (trip_key *)malloc(sizeof(trip_key) * (size_t)nt);
+    for (int32_t t = 0; t < nt; t++) { keys[t].key = (int64_t)rows[t] * nbcol + cols[t]; keys[t].idx = t; }
+    qsort(keys, (size_t)nt, sizeof(trip_key), trip_cmp);
+    for (int32_t t = 0; t < nt; t++) {
+        int32_t s = keys[t].idx;
+        op->bcol[t] = cols[s];
+        memcpy(op->blocks + (size_t)t * bs * bs, blocks + (size_t)s * bs * bs, sizeof(cplx) * (size_t)bs * bs);
+        op->browptr[rows[s] + 1]++;
+    }
+    for (int32_t r = 0; r < nbrow; r++) op->browptr[r + 1] += op->browptr[r];
+    free(keys);
+    return op;
+}
+int32_t orc_bcsr_nblocks(const orc_op *op) { return op->browptr[op->nbrow]; }
+void orc_bcsr_export(const orc_op *op, int32_t *browptr, int32_t *bcol, cplx *blocks) {
+    memcpy(browptr, op->browptr, sizeof(int32_t) * ((size_t)op->nbrow + 1));
+    int32_t nb = op->browptr[op->nbrow];
+    memcpy(bcol, op->bcol, sizeof(int32_t) * (size_t)nb);
+    memcpy(blocks, op->blocks, sizeof(cplx) * (size_t)nb * op->bs * op->bs);
+}
+
+/* src/HierarchicalSparse.h:164-178  val_at(row,col): sum over duplicate blocks */
+void orc_bcsr_val_at(const orc_op *op, int64_t row, int64_t col, cplx *out) {
+    int32_t bs = op->bs;
+    int32_t br = (int32_t)(row / bs), bc = (int32_t)(col / bs);
+    int32_t ro = (int32_t)(row - (int64_t)br * bs), co = (int32_t)(col - (int64_t)bc * bs);
+    cplx o = 0.0;
+    for (int32_t i = op->browptr[br]; i < op->browptr[br + 1]; i++)
+        if (op->bcol[i] == bc) o += op->blocks[(size_t)i * bs * bs + (size_t)ro * bs + co];
+    *out = o;
+}
+
+int64_t orc_op_dim(const orc_op *op) { return op->dim; }
+
+/* ------------------------------------------------------------------ GCR ------------------ */
+
+static cplx *vnew(int64_t n) { return (cplx *)malloc(sizeof(cplx) * (size_t)n); }
+
+/* src/GCR.h:158-302.  Returns the number of iterations performed (global_count).
+ * hist[0] = step-0 entry, hist[k] = sqrt(|r|^2)/|b| printed at step k (src/GCR.h:214,271-272);
+ * at most hist_cap entries are stored.  *converged = 1 unless global_count == max_iter
+ * (src/GCR.h:294-298). */
+int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, double *hist, int hist_cap,
+                  int *converged) {
+    int64_t n = A->dim;
+    /* mode selection, src/GCR.h:171-185 */
+    int truncation, restart, storage = gp->max_iter;
+    if (gp->truncation != 0) { truncation = gp->truncation; storage = truncation; } else truncation = gp->max_iter;
+    if (gp->restart != 0) { restart = gp->restart; storage = restart; } else restart = gp->max_iter;
+    (void)truncation;
+    if (storage < 1) storage = 1; /* max_iter = 0 with neither mode: the reference would new[0]; unused in practice */
+    if (restart < 1) restart = 1;
+
+    cplx *r = vnew(n), *p = vnew(n), *Ap = vnew(n), *Ar = vnew(n), *t = vnew(n);
+    cplx *z = NULL;
+    /* r = rhs (src/GCR.h:189) — the reference ignores x0 here */
+    if (gp->use_x0) {
+        orc_op_apply(A, x, t);
+        for (int64_t i = 0; i < n; i++) r[i] = rhs[i] - t[i];
+    } else {
+        memcpy(r, rhs, sizeof(cplx) * (size_t)n);
+    }
+    if (gp->flexible && gp->right_precond) {
+        z = vnew(n);
+        orc_op_apply(gp->right_precond, r, z);
+        memcpy(p, z, sizeof(cplx) * (size_t)n);
+    } else {
+        memcpy(p, r, sizeof(cplx) * (size_t)n); /* p = r */
+    }
+    orc_op_apply(A, p, Ap);                  /* Ap = A p  (src/GCR.h:191) */
+    memcpy(Ar, Ap, sizeof(cplx) * (size_t)n); /* Ar = Ap */
+    if (!gp->flexible) {
+        /* src/GCR.h:197-204: r = Mr(r); r = Ml(r)  — AFTER p and Ap were formed */
+        if (gp->right_precond) { orc_op_apply(gp->right_precond, r, t); memcpy(r, t, sizeof(cplx) * (size_t)n); }
+        if (gp->left_precond) { orc_op_apply(gp->left_precond, r, t); memcpy(r, t, sizeof(cplx) * (size_t)n); }
+    }
+    cplx **Aps = (cplx **)calloc((size_t)storage, sizeof(cplx *));
+    cplx **ps = (cplx **)calloc((size_t)storage, sizeof(cplx *));
+    Aps[0] = vnew(n); ps[0] = vnew(n);
+    memcpy(Aps[0], Ap, sizeof(cplx) * (size_t)n);
+    memcpy(ps[0], p, sizeof(cplx) * (size_t)n);
+
+    double bnorm2 = orc_sqnorm(n, rhs);
+    double bnorm = sqrt(bnorm2);
+    if (hist && hist_cap > 0) hist[0] = sqrt(orc_sqnorm(n, r)) / bnorm;
+    if (gp->verbose) printf("Step %d residual norm = %.10e\n", 0, sqrt(orc_sqnorm(n, r)) / bnorm);
+
+    int iter_count = 0, global_count = 0;
+    cplx *Ap_corr = vnew(n), *p_corr = vnew(n);
+    double rn2;
+    do {
+        global_count++;
+        iter_count++;
+        /* alpha = r.dot(Ap) / Ap.dot(Ap)   (src/GCR.h:230) */
+        cplx num, den;
+        orc_dot(n, r, Ap, &num);
+        orc_dot(n, Ap, Ap, &den);
+        cplx alpha = num / den;
+        /* x = x + p*alpha ; r = r - Ap*alpha  (src/GCR.h:232-233) */
+        for (int64_t i = 0; i < n; i++) x[i] = x[i] + alpha * p[i];
+        for (int64_t i = 0; i < n; i++) r[i] = r[i] - alpha * Ap[i];
+        const cplx *dir = r; /* the vector the new direction is built from */
+        if (gp->flexible && gp->right_precond) {
+            orc_op_apply(gp->right_precond, r, z);
+            dir = z;
+        } else if (gp->right_precond) { /* src/GCR.h:236-238 */
+            orc_op_apply(gp->right_precond, r, t);
+            memcpy(r, t, sizeof(cplx) * (size_t)n);
+        }
+        orc_op_apply(A, dir, Ar); /* src/GCR.h:242 */
+        if (gp->left_precond) {   /* src/GCR.h:245-247 */
+            orc_op_apply(gp->left_precond, Ar, t);
+            memcpy(Ar, t, sizeof(cplx) * (size_t)n);
+        }
+        int lim = storage < iter_count ? storage : iter_count; /* src/GCR.h:251 */
+        for (int64_t i = 0; i < n; i++) { Ap_corr[i] = 0.0; p_corr[i] = 0.0; }
+        for (int i = 0; i < lim; i++) { /* src/GCR.h:257-262 */
+            cplx bn, bd;
+            orc_dot(n, Ar, Aps[i], &bn);
+            orc_dot(n, Aps[i], Aps[i], &bd);
+            cplx beta = bn / bd;
+            for (int64_t j = 0; j < n; j++) p_corr[j] = p_corr[j] - beta * ps[i][j];
+            for (int64_t j = 0; j < n; j++) Ap_corr[j] = Ap_corr[j] - beta * Aps[i][j];
+        }
+        for (int64_t i = 0; i < n; i++) p[i] = dir[i] + p_corr[i];   /* src/GCR.h:265 */
+        for (int64_t i = 0; i < n; i++) Ap[i] = Ar[i] + Ap_corr[i];  /* src/GCR.h:266 */
+        rn2 = orc_sqnorm(n, r);
+        if (hist && global_count < hist_cap) hist[global_count] = sqrt(rn2) / bnorm;
+        if (gp->verbose) printf("Step %d residual norm = %.10e\n", global_count, sqrt(rn2) / bnorm);
+        if (iter_count % restart == 0) { /* src/GCR.h:277-283: wipe (slots are never read again before being rewritten) */
+            iter_count = 0;
+        }
+        int slot = iter_count % storage; /* src/GCR.h:286-287 */
+        if (!Aps[slot]) { Aps[slot] = vnew(n); ps[slot] = vnew(n); }
+        memcpy(Aps[slot], Ap, sizeof(cplx) * (size_t)n);
+        memcpy(ps[slot], p, sizeof(cplx) * (size_t)n);
+    } while ((rn2 / bnorm2) > gp->tol * gp->tol && global_count < gp->max_iter); /* src/GCR.h:288 */
+
+    if (converged) *converged = (global_count == gp->max_iter) ? 0 : 1;
+    if (gp->verbose) {
+        if (global_count == gp->max_iter)
+            printf("GCR did not converge after %d steps! Residual norm = %.10e\n", gp->max_iter, sqrt(rn2) / bnorm);
+        else
+            printf("GCR converged after %d steps. Residual norm=%.10e\n", global_count, sqrt(rn2) / bnorm);
+    }
+    for (int i = 0; i < storage; i++) { free(Aps[i]); free(ps[i]); }
+    free(Aps); free(ps); free(Ap_corr); free(p_corr);
+    free(r); free(p); free(Ap); free(Ar); free(t); free(z);
+    return global_count;
+}
+
+/* GCR as an Operator (src/GCR.h:62-68): x = init_rand(2); solve(f, x); return x.
+ * x0_mode 0 reproduces the reference when the caller supplies the same random x0 through
+ * orc_op_gcr_set_x0 (libc rand() is compiler/evaluation-order dependent, SURVEY.md §0 fact 9, so
+ * the oracle never calls it); x0_mode 1 starts from x0 = 0. */
+orc_op *orc_op_gcr(orc_op *A, const orc_gcr_param *gp, int x0_mode) {
+    orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+    op->kind = OP_GCR; op->dim = A ? A->dim : 0; op->A = A; op->gp = *gp; op->x0_mode = x0_mode;
+    return op;
+}
+void orc_op_gcr_set_operator(orc_op *g, orc_op *A) { g->A = A; g->dim = A->dim; } /* GCR::initialise src/GCR.h:31 */
+static const cplx *g_gcr_x0 = NULL;
+void orc_op_gcr_set_x0(const cplx *x0) { g_gcr_x0 = x0; }
+
+static void gcr_apply(orc_op *op, const cplx *f, cplx *y) {
+    int64_t n = op->dim;
+    if (op->x0_mode == 0 && g_gcr_x0) memcpy(y, g_gcr_x0, sizeof(cplx) * (size_t)n);
+    else memset(y, 0, sizeof(cplx) * (size_t)n);
+    orc_gcr_solve(op->A, &op->gp, f, y, NULL, 0, NULL);
+}
+
+void orc_mg_apply(orc_mg *mg, const cplx *f, cplx *y);
+
+void orc_op_apply(orc_op *op, const cplx *x, cplx *y) {
+    switch (op->kind) {
+        case OP_CSR: csr_apply(op, x, y); break;
+        case OP_DIRAC: dirac_apply(op, x, y); break;
+        case OP_BCSR: bcsr_apply(op, x, y); break;
+        case OP_GCR: gcr_apply(op, x, y); break;
+        case OP_MG: orc_mg_apply(op->mg, x, y); break;
+    }
+}
+
+void orc_op_free(orc_op *op) {
+    if (!op) return;
+    if (op->owns) { free(op->browptr); free(op->bcol); free(op->blocks); }
+    free(op);
+}
+
+/* ------------------------------------------------------------------ data loader ---------- */
+
+/* src/Parse.cpp:64-90  text-CSR reader: "nrow ncol nnz", then nrow row offsets (ROW[nrow] = nnz
+ * implied, src/Operator.h:61), then nnz lines "col (re,im)".  Two-call protocol: first call with
+ * NULL arrays returns the sizes. */
+int orc_read_text_csr(const char *path, int64_t *nrow, int64_t *ncol, int64_t *nnz, int64_t *rowptr, int64_t *col,
+                      cplx *val) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    long long a, b, c;
+    if (fscanf(f, "%lld %lld %lld", &a, &b, &c) != 3) { fclose(f); return -2; }
+    *nrow = a; *ncol = b; *nnz = c;
+    if (!rowptr) { fclose(f); return 0; }
+    for (int64_t i = 0; i < a; i++) {
+        long long v;
+        if (fscanf(f, "%lld", &v) != 1) { fclose(f); return -3; }
+        rowptr[i] = v;
+    }
+    rowptr[a] = c;
+    for (int64_t i = 0; i < c; i++) {
+        long long cc; double re, im;
+        if (fscanf(f, "%lld (%lf,%lf)", &cc, &re, &im) != 3) { fclose(f); return -4; }
+        col[i] = cc; val[i] = re + im * I;
+    }
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ generators ----------- */
+
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+/* repo-owned deterministic RHS on the reference's 0.001 grid (src/Fields.h:133); same recipe as
+ * oracle/ref_harness.cpp:fill_rhs and the product's mgcr_fill_rhs */
+void orc_fill_rhs(int64_t n, uint64_t seed, cplx *out) {
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t a = splitmix64(seed * 0x100000001B3ull + 2 * (uint64_t)i);
+        uint64_t b = splitmix64(seed * 0x100000001B3ull + 2 * (uint64_t)i + 1);
+        out[i] = ((double)(a % 2000) / 1000. - 1.) + ((double)(b % 2000) / 1000. - 1.) * I;
+    }
+}
+
+/* 3-D 7-point Poisson: lexicographic, diag 6, off-diag -1, Dirichlet
+ * truncation; columns ascending within a row.  nnz = 7 n^3 - 6 n^2. */
+void orc_poisson3d(int64_t n, int64_t *rowptr, int64_t *col, cplx *val) {
+    int64_t p = 0;
+    for (int64_t i = 0; i < n; i++) for (int64_t j = 0; j < n; j++) for (int64_t k = 0; k < n; k++) {
+        int64_t r = (i * n + j) * n + k;
+        rowptr[r] = p;
+        if (i > 0)     { col[p] = r - n * n; val[p++] = -1.; }
+        if (j > 0)     { col[p] = r - n;     val[p++] = -1.; }
+        if (k > 0)     { col[p] = r - 1;     val[p++] = -1.; }
+        col[p] = r; val[p++] = 6.;
+        if (k < n - 1) { col[p] = r + 1;     val[p++] = -1.; }
+        if (j < n - 1) { col[p] = r + n;     val[p++] = -1.; }
+        if (i < n - 1) { col[p] = r + n * n; val[p++] = -1.; }
+    }
+    rowptr[n * n * n] = p;
+}

@@ -1,0 +1,230 @@
+"""TEST INFRASTRUCTURE — ctypes/numpy front-end of the CPU oracle (oracle/libmgcr_oracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (mgpreconditionedgcr_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmgcr_oracle.so")
+_lib = None
+
+c128 = np.complex128
+_cp = np.ctypeslib.ndpointer(dtype=c128, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+class GcrParamC(C.Structure):
+    _fields_ = [("truncation", C.c_int), ("restart", C.c_int), ("max_iter", C.c_int),
+                ("tol", C.c_double), ("verbose", C.c_int),
+                ("left_precond", C.c_void_p), ("right_precond", C.c_void_p),
+                ("use_x0", C.c_int), ("flexible", C.c_int)]
+
+
+def build():
+    """Compile the oracle (gcc) if the .so is missing or older than its sources."""
+    srcs = [os.path.join(_HERE, f) for f in ("mgcr_oracle.c", "mgcr_oracle_mg.c")]
+    if (not os.path.exists(_LIB_PATH)
+            or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)):
+        subprocess.run(["make", "-C", _HERE, "oracle"], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_dot.argtypes = [C.c_int64, _cp, _cp, _cp]
+        L.orc_sqnorm.argtypes = [C.c_int64, _cp]
+        L.orc_sqnorm.restype = C.c_double
+        L.orc_add_scaled.argtypes = [C.c_int64, _cp, _cp, _cp, _cp]
+        L.orc_sub_scaled.argtypes = [C.c_int64, _cp, _cp, _cp, _cp]
+        L.orc_normalise.argtypes = [C.c_int64, _cp]
+        L.orc_op_csr.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _cp]
+        L.orc_op_csr.restype = C.c_void_p
+        L.orc_op_dirac.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_op_dirac.restype = C.c_void_p
+        L.orc_op_bcsr_from_triplets.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _cp]
+        L.orc_op_bcsr_from_triplets.restype = C.c_void_p
+        L.orc_bcsr_nblocks.argtypes = [C.c_void_p]
+        L.orc_bcsr_nblocks.restype = C.c_int32
+        L.orc_bcsr_export.argtypes = [C.c_void_p, _i32p, _i32p, _cp]
+        L.orc_bcsr_val_at.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _cp]
+        L.orc_op_dim.argtypes = [C.c_void_p]
+        L.orc_op_dim.restype = C.c_int64
+        L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
+        L.orc_op_free.argtypes = [C.c_void_p]
+        L.orc_op_gcr.argtypes = [C.c_void_p, C.POINTER(GcrParamC), C.c_int]
+        L.orc_op_gcr.restype = C.c_void_p
+        L.orc_op_gcr_set_operator.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_op_gcr_set_x0.argtypes = [C.c_void_p]
+        L.orc_gcr_solve.argtypes = [C.c_void_p, C.POINTER(GcrParamC), _cp, _cp, _f64p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_gcr_solve.restype = C.c_int
+        L.orc_read_text_csr.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_read_text_csr.restype = C.c_int
+        L.orc_fill_rhs.argtypes = [C.c_int64, C.c_uint64, _cp]
+        L.orc_poisson3d.argtypes = [C.c_int64, _i64p, _i64p, _cp]
+        _lib = L
+    return _lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=c128)
+
+
+# ---------------------------------------------------------------- Field algebra
+def dot(a, b):
+    out = np.zeros(1, c128)
+    lib().orc_dot(a.size, _c(a), _c(b), out)
+    return out[0]
+
+
+def sqnorm(a):
+    return lib().orc_sqnorm(a.size, _c(a))
+
+
+def add_scaled(a, b, alpha):
+    out = np.empty(a.size, c128)
+    lib().orc_add_scaled(a.size, _c(a), _c(b), np.array([alpha], c128), out)
+    return out
+
+
+def sub_scaled(a, b, alpha):
+    out = np.empty(a.size, c128)
+    lib().orc_sub_scaled(a.size, _c(a), _c(b), np.array([alpha], c128), out)
+    return out
+
+
+# ---------------------------------------------------------------- operators
+class Op:
+    """Opaque oracle operator handle; keeps the numpy buffers it borrows alive."""
+
+    def __init__(self, handle, keep=()):
+        self.h = handle
+        self._keep = list(keep)
+
+    @property
+    def dim(self):
+        return lib().orc_op_dim(self.h)
+
+    def __call__(self, x):
+        y = np.empty(self.dim, c128)
+        lib().orc_op_apply(self.h, _c(x), y)
+        return y
+
+
+def csr(nrow, ncol, rowptr, col, val):
+    rowptr = np.ascontiguousarray(rowptr, np.int64)
+    col = np.ascontiguousarray(col, np.int64)
+    val = _c(val)
+    return Op(lib().orc_op_csr(nrow, ncol, rowptr, col, val), keep=(rowptr, col, val))
+
+
+def dirac(D, k):
+    k = complex(k)
+    return Op(lib().orc_op_dirac(D.h, k.real, k.imag), keep=(D,))
+
+
+def bcsr_from_triplets(nbrow, nbcol, bs, rows, cols, blocks):
+    rows = np.ascontiguousarray(rows, np.int32)
+    cols = np.ascontiguousarray(cols, np.int32)
+    blocks = _c(blocks)
+    return Op(lib().orc_op_bcsr_from_triplets(nbrow, nbcol, bs, rows.size, rows, cols, blocks))
+
+
+def bcsr_export(op, nbrow, bs):
+    nb = lib().orc_bcsr_nblocks(op.h)
+    browptr = np.empty(nbrow + 1, np.int32)
+    bcol = np.empty(nb, np.int32)
+    blocks = np.empty(nb * bs * bs, c128)
+    lib().orc_bcsr_export(op.h, browptr, bcol, blocks)
+    return browptr, bcol, blocks.reshape(nb, bs, bs)
+
+
+def bcsr_val_at(op, row, col):
+    out = np.zeros(1, c128)
+    lib().orc_bcsr_val_at(op.h, row, col, out)
+    return out[0]
+
+
+def gcr_param(truncation=0, restart=0, max_iter=100, tol=1e-16, verbose=False, left=None, right=None,
+              use_x0=False, flexible=False):
+    """Mirror of GCR_Param(trunc, re, max_it, tol, verb, l, r) (src/SolverParam.h:33)."""
+    p = GcrParamC(truncation, restart, max_iter, tol, int(verbose),
+                  left.h if left is not None else None, right.h if right is not None else None,
+                  int(use_x0), int(flexible))
+    p._keep = (left, right)
+    return p
+
+
+def gcr_solve(A, param, rhs, x0=None):
+    """GCR::solve(rhs, x) (src/GCR.h:158-302).  Returns (x, history, n_iter, converged)."""
+    n = A.dim
+    x = np.zeros(n, c128) if x0 is None else _c(x0).copy()
+    cap = param.max_iter + 2
+    hist = np.zeros(cap, np.float64)
+    conv = C.c_int(0)
+    it = lib().orc_gcr_solve(A.h, C.byref(param), _c(rhs), x, hist, cap, C.byref(conv))
+    return x, hist[: it + 1].copy(), it, bool(conv.value)
+
+
+def gcr_op(A, param, x0_mode=1):
+    """GCR used as an Operator (preconditioner / smoother), src/GCR.h:62-68."""
+    return Op(lib().orc_op_gcr(A.h if A is not None else None, C.byref(param), x0_mode), keep=(A, param))
+
+
+# ---------------------------------------------------------------- data
+def read_text_csr(path):
+    """read_data (src/Parse.cpp:64-90): returns (nrow, ncol, rowptr[int64], col[int64], val)."""
+    nrow, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib().orc_read_text_csr(path.encode(), C.byref(nrow), C.byref(ncol), C.byref(nnz), None, None, None)
+    if rc != 0:
+        raise IOError("File read is unsuccessful! (%s, rc=%d)" % (path, rc))
+    rowptr = np.empty(nrow.value + 1, np.int64)
+    col = np.empty(nnz.value, np.int64)
+    val = np.empty(nnz.value, c128)
+    rc = lib().orc_read_text_csr(path.encode(), C.byref(nrow), C.byref(ncol), C.byref(nnz),
+                                 rowptr.ctypes.data, col.ctypes.data, val.ctypes.data)
+    if rc != 0:
+        raise IOError("parse error in %s (rc=%d)" % (path, rc))
+    return nrow.value, ncol.value, rowptr, col, val
+
+
+def fill_rhs(n, seed=0):
+    out = np.empty(n, c128)
+    lib().orc_fill_rhs(n, seed, out)
+    return out
+
+
+def rhs_grid(n, seed=0):
+    """Pure-numpy twin of orc_fill_rhs / ref_harness fill_rhs (splitmix64 on the 0.001 grid)."""
+    def sm(x):
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        base = np.uint64(seed) * np.uint64(0x100000001B3)
+        i = np.arange(n, dtype=np.uint64)
+        a = sm(base + np.uint64(2) * i)
+        b = sm(base + np.uint64(2) * i + np.uint64(1))
+    re = (a % np.uint64(2000)).astype(np.float64) / 1000. - 1.
+    im = (b % np.uint64(2000)).astype(np.float64) / 1000. - 1.
+    return (re + 1j * im).astype(c128)
+
+
+def poisson3d(n):
+    N = n * n * n
+    nnz = 7 * N - 6 * n * n
+    rowptr = np.empty(N + 1, np.int64)
+    col = np.empty(nnz, np.int64)
+    val = np.empty(nnz, c128)
+    lib().orc_poisson3d(n, rowptr, col, val)
+    return N, rowptr, col, val

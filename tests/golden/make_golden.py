@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs `oracle/_ref/ref_harness` (the reference's own headers compiled where they lie under
+/root/reference/src by `make -C oracle _ref`; g++ on purpose) and packs
+what it dumps into compressed .npz files.  Only DATA is committed: inputs and the reference's
+outputs.  The data file `data/sample_matrix/4x4parsed.txt` (the reference's only shipped
+input) is committed gzip-compressed next to them, because the GPU box
+has no /root/reference.
+
+Usage (in the build container, where /root/reference exists):
+    make -C oracle _ref && python tests/golden/make_golden.py
+"""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+REF = os.environ.get("MGCR_REFERENCE_ROOT", "/root/reference")
+
+
+def run(out, *args):
+    log = subprocess.run([HARNESS, out, *args], check=True, capture_output=True, text=True)
+    return log.stdout, log.stderr
+
+
+def c(out, name):
+    return np.fromfile(os.path.join(out, name + ".bin"), dtype=np.complex128)
+
+
+def d(out, name, dtype=np.float64):
+    return np.fromfile(os.path.join(out, name + ".bin"), dtype=dtype)
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("build the harness first: make -C oracle _ref")
+    out = tempfile.mkdtemp(prefix="mgcr_gold_")
+    try:
+        stdout, _ = run(out, "sample")
+        # the printed history of the first (restart-5) solve, as a cross-check of the spy
+        printed = []
+        for line in stdout.splitlines():
+            if line.startswith("Step "):
+                printed.append(float(line.split("=")[1]))
+            if line.startswith("GCR converged"):
+                break
+        sample = dict(
+            g1_x=c(out, "g1_x"), g1_Dx=c(out, "g1_Dx"), g1_dirac_x=c(out, "g1_dirac_x"),
+            g2_a=c(out, "g2_a"), g2_b=c(out, "g2_b"), g2_scalars=c(out, "g2_scalars"),
+            g2_a_plus_alpha_b=c(out, "g2_a_plus_alpha_b"),
+            g2_a_minus_alpha_b=c(out, "g2_a_minus_alpha_b"),
+            gcr_rhs=c(out, "gcr_rhs"),
+            g3_printed=np.array(printed),
+        )
+        for tag in ["g3_restart5", "g4_restart2", "g5_trunc8", "g6_full", "g10_maxiter0",
+                    "g10_x0rand", "g11_right_neumann", "g11_left_neumann", "g3b_complexk"]:
+            sample[tag + "_hist"] = d(out, tag + "_hist")
+            sample[tag + "_x"] = c(out, tag + "_x")
+        np.savez_compressed(os.path.join(HERE, "sample_4x4.npz"), **sample)
+
+        run(out, "hsparse")
+        meta = d(out, "g8_meta", np.int32)
+        np.savez_compressed(
+            os.path.join(HERE, "hsparse.npz"), nb=meta[0], bs=meta[1], nt=meta[2],
+            blocks=c(out, "g8_blocks"), rows=d(out, "g8_rows", np.int32),
+            cols=d(out, "g8_cols", np.int32), x=c(out, "g8_x"), y=c(out, "g8_y"),
+            dense=c(out, "g8_dense"))
+
+        run(out, "mg")
+        meta = d(out, "g9_meta", np.int64)
+        nblocks, bsz, ne, sub = (int(v) for v in meta[:4])
+        N = 3072
+        P = c(out, "g9_P").reshape(nblocks, ne, N)
+        np.savez_compressed(
+            os.path.join(HERE, "mg_4x4.npz"), nblocks=nblocks, block_size=bsz, ne=ne, sub=sub,
+            k=0.1, block_map=d(out, "g9_block_map", np.int64).reshape(nblocks, bsz), P=P,
+            eigvec0=c(out, "g9_eigvec0"), eigvec1=c(out, "g9_eigvec1"),
+            gamma5_eigvec0=c(out, "g9_gamma5_eigvec0"),
+            v=c(out, "g9_v"), Rv=c(out, "g9_Rv"), PRv=c(out, "g9_PRv"), AcRv=c(out, "g9_AcRv"),
+            Ac_dense=c(out, "g9_Ac_dense").reshape(nblocks * ne, nblocks * ne),
+            identities=d(out, "g9_identities"))
+
+        pois = {}
+        run(out, "poisson", "32", "10", "p32")
+        pois["p32_hist"] = d(out, "p32_hist")
+        pois["p32_x"] = c(out, "p32_x")
+        run(out, "poisson", "8", "300", "p8t4", "4", "0", "1e-10")
+        pois["p8_trunc4_hist"] = d(out, "p8t4_hist")
+        pois["p8_trunc4_x"] = c(out, "p8t4_x")
+        pois["p8_rhs"] = c(out, "p8t4_rhs")
+        # full GCR looses orthogonality and blows up after ~35 steps (no breakdown guard,
+        # SURVEY.md §5): pin the well-conditioned prefix only
+        run(out, "poisson", "8", "25", "p8full", "0", "0", "1e-10")
+        pois["p8_full_hist"] = d(out, "p8full_hist")
+        run(out, "poisson", "16", "300", "p16r3", "0", "3", "1e-12")
+        pois["p16_restart3_hist"] = d(out, "p16r3_hist")
+        pois["p16_restart3_x"] = c(out, "p16r3_x")
+        if os.environ.get("MGCR_GOLD_128", "1") == "1":
+            run(out, "poisson", "128", "10", "p128")
+            pois["p128_hist"] = d(out, "p128_hist")
+        np.savez_compressed(os.path.join(HERE, "poisson.npz"), **pois)
+
+        src = os.path.join(REF, "data", "sample_matrix", "4x4parsed.txt")
+        with open(src, "rb") as fi, gzip.GzipFile(
+                os.path.join(HERE, "4x4parsed.txt.gz"), "wb", mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

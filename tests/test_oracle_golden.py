@@ -1,0 +1,135 @@
+"""Pins the CPU oracle (oracle/mgcr_oracle.c) to the golden vectors produced by the REAL
+reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+@pytest.fixture(scope="module")
+def sample_ops(sample_matrix_path):
+    nrow, ncol, rowptr, col, val = orc.read_text_csr(sample_matrix_path)
+    assert (nrow, ncol, col.size) == (3072, 3072, 119808)
+    assert rowptr[1] == 39 and rowptr[-1] == 119808
+    D = orc.csr(nrow, ncol, rowptr, col, val)
+    return D, orc.dirac(D, 0.15)
+
+
+def test_g1_spmv_bit_exact(sample_ops, sample_gold):
+    D, dirac = sample_ops
+    g = sample_gold
+    assert np.array_equal(D(g["g1_x"]), g["g1_Dx"])
+    assert np.array_equal(dirac(g["g1_x"]), g["g1_dirac_x"])
+
+
+def test_g2_blas1_bit_exact(sample_gold):
+    g = sample_gold
+    a, b = g["g2_a"], g["g2_b"]
+    dot_ab, norms, alpha = g["g2_scalars"]
+    assert orc.dot(a, b) == dot_ab
+    assert orc.sqnorm(a) == norms.real and orc.sqnorm(b) == norms.imag
+    assert np.array_equal(orc.add_scaled(a, b, alpha), g["g2_a_plus_alpha_b"])
+    assert np.array_equal(orc.sub_scaled(a, b, alpha), g["g2_a_minus_alpha_b"])
+
+
+CASES = [
+    # tag, GCR_Param(trunc, restart, max_iter, tol), known iteration count
+    ("g3_restart5", dict(restart=5, max_iter=4000, tol=1e-13), 118),
+    ("g4_restart2", dict(restart=2, max_iter=4000, tol=1e-13), 116),
+    ("g5_trunc8", dict(truncation=8, max_iter=300, tol=1e-3), 46),
+    ("g6_full", dict(max_iter=300, tol=1e-13), 300),
+    ("g10_maxiter0", dict(restart=10, max_iter=0, tol=1e-8), 1),
+]
+
+
+@pytest.mark.parametrize("tag,kw,iters", CASES)
+def test_gcr_history_bit_exact(sample_ops, sample_gold, tag, kw, iters):
+    _, dirac = sample_ops
+    g = sample_gold
+    x, hist, it, conv = orc.gcr_solve(dirac, orc.gcr_param(**kw), g["gcr_rhs"])
+    assert it == iters
+    ref = g[tag + "_hist"]
+    assert hist.size == ref.size
+    # identical operation order => identical bits
+    assert np.array_equal(hist[1:], ref[1:])
+    assert np.array_equal(x, g[tag + "_x"])
+
+
+def test_g3_known_answers(sample_gold):
+    """The step values SURVEY.md §8(c) lists for G3, and the reference's own printf output."""
+    h = sample_gold["g3_restart5_hist"]
+    for step, val in [(1, 5.1119407829e-01), (2, 3.1216006878e-01), (3, 2.0665781387e-01),
+                      (10, 2.8824580865e-02), (50, 1.1675757077e-06), (118, 8.9330941014e-14)]:
+        assert abs(h[step] - val) <= 5e-11 * val
+    printed = sample_gold["g3_printed"]
+    assert printed.size == 119 and np.allclose(printed[1:], h[1:], rtol=1e-10, atol=0)
+
+
+def test_complex_k(sample_ops, sample_gold):
+    D, _ = sample_ops
+    op = orc.dirac(D, 0.12 + 0.05j)
+    x, hist, it, _ = orc.gcr_solve(op, orc.gcr_param(restart=5, max_iter=40, tol=1e-13), sample_gold["gcr_rhs"])
+    assert np.array_equal(hist[1:], sample_gold["g3b_complexk_hist"][1:])
+    assert np.array_equal(x, sample_gold["g3b_complexk_x"])
+
+
+def test_x0_is_ignored_for_r0(sample_ops, sample_gold):
+    """src/GCR.h:189: r0 = b regardless of x0; x_final = x0 + corrections."""
+    _, dirac = sample_ops
+    g = sample_gold
+    p = orc.gcr_param(restart=5, max_iter=20, tol=1e-13)
+    x_zero, h0, _, _ = orc.gcr_solve(dirac, p, g["gcr_rhs"])
+    # the reference run started from init_rand(2) (g++ order): x_ref - x0 must equal our zero-start x
+    # up to the rounding of (x0 + a) - x0; we do not have x0, so compare histories instead
+    assert np.array_equal(h0[1:], g["g10_x0rand_hist"][1:])
+
+
+def test_precond_hooks_literal(sample_ops, sample_gold):
+    """r = M(r) after the update, Ar = Ml(Ar) after the SpMV (src/GCR.h:197-204,236-247)."""
+    D, dirac = sample_ops
+    g = sample_gold
+    M = orc.dirac(D, -0.15)
+    x, hist, it, _ = orc.gcr_solve(dirac, orc.gcr_param(restart=5, max_iter=20, tol=1e-13, right=M), g["gcr_rhs"])
+    assert np.array_equal(hist[1:], g["g11_right_neumann_hist"][1:])
+    assert np.array_equal(x, g["g11_right_neumann_x"])
+    x, hist, it, _ = orc.gcr_solve(dirac, orc.gcr_param(restart=5, max_iter=60, tol=1e-13, left=M), g["gcr_rhs"])
+    assert np.array_equal(hist[1:], g["g11_left_neumann_hist"][1:])
+    assert np.array_equal(x, g["g11_left_neumann_x"])
+
+
+def test_poisson_histories(poisson_gold):
+    g = poisson_gold
+    N, rowptr, col, val = orc.poisson3d(32)
+    assert col.size == 7 * 32 ** 3 - 6 * 32 ** 2
+    A = orc.csr(N, N, rowptr, col, val)
+    rhs = orc.fill_rhs(N, 0)
+    assert np.array_equal(rhs, orc.rhs_grid(N, 0))
+    x, hist, it, _ = orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=10, tol=1e-13), rhs)
+    assert np.array_equal(hist[1:], g["p32_hist"][1:]) and np.array_equal(x, g["p32_x"])
+    # SURVEY §8(c) G7 known answers were for an init_rand RHS; ours is the splitmix RHS, so only
+    # the self-consistency with the reference run on the same RHS is checked.
+    N, rowptr, col, val = orc.poisson3d(8)
+    A = orc.csr(N, N, rowptr, col, val)
+    rhs = orc.fill_rhs(N, 0)
+    assert np.array_equal(rhs, g["p8_rhs"])
+    x, hist, it, conv = orc.gcr_solve(A, orc.gcr_param(truncation=4, max_iter=300, tol=1e-10), rhs)
+    assert conv and np.array_equal(hist[1:], g["p8_trunc4_hist"][1:]) and np.array_equal(x, g["p8_trunc4_x"])
+    x, hist, it, conv = orc.gcr_solve(A, orc.gcr_param(max_iter=25, tol=1e-10), rhs)
+    assert np.array_equal(hist[1:], g["p8_full_hist"][1:])
+    N, rowptr, col, val = orc.poisson3d(16)
+    A = orc.csr(N, N, rowptr, col, val)
+    x, hist, it, conv = orc.gcr_solve(A, orc.gcr_param(restart=3, max_iter=300, tol=1e-12), orc.fill_rhs(N, 0))
+    assert conv and np.array_equal(hist[1:], g["p16_restart3_hist"][1:]) and np.array_equal(x, g["p16_restart3_x"])
+
+
+def test_g8_hsparse(hsparse_gold):
+    g = hsparse_gold
+    nb, bs = int(g["nb"]), int(g["bs"])
+    H = orc.bcsr_from_triplets(nb, nb, bs, g["rows"], g["cols"], g["blocks"])
+    y = H(g["x"])
+    # duplicates: std::sort order among equal keys is unspecified in the reference => last-bit slack
+    assert np.allclose(y, g["y"], rtol=1e-14, atol=1e-15)
+    dense = g["dense"].reshape(nb * bs, nb * bs)
+    for (r, c) in [(0, 0), (17, 18), (16, 17), (23, 1), (9, 22)]:
+        assert np.isclose(orc.bcsr_val_at(H, r, c), dense[r, c], rtol=1e-15, atol=0)
+    assert np.allclose(dense @ g["x"], g["y"], rtol=1e-13)
