@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: restarted GCR iterations/sec and SpMV HBM GB/s
+on the 3-D 7-point Poisson system of BASELINE.json configs[1] (128^3, unpreconditioned GCR
+restart 5, complex fp64, x0 = 0, deterministic RHS), one process per GPU.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one GCR iteration (1 SpMV + the fused orthogonalisation kernels).  The timed region
+is one mgcr_gcr_solve call limited to exactly K iterations (tol = 0 so it cannot stop early),
+inputs resident in HBM, bracketed by barrier + device synchronisation; the max over ranks is
+reported.  N > 1: the grid grows along i to (128 N) x 128 x 128 and is slab-partitioned, 128
+planes (= the N=1 problem) per GPU — weak scaling; value = N * iterations/s (shard-iterations/s).
+
+One JSON line on stdout (rank 0), with `roofline` (SpMV kernel, hipEvent-timed on the library's
+own stream) and `cpu_baseline` (the real reference, oracle/_ref/ref_harness, on this box's host
+cores; falls back to the oracle port when that binary is absent).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def spmv_algorithmic_bytes(nnz, nrow, ncol):
+    """complex-fp64 values + int32 columns + int32 row pointers + x read once
+    + y written once."""
+    return nnz * 20 + (nrow + 1) * 4 + ncol * 16 + nrow * 16
+
+
+def cpu_baseline(n, iters=10):
+    """Time the reference CPU path on this box's host cores (bounded sample: `iters` GCR
+    iterations of the same system, 1 thread — the reference's Sparse/Field path is single
+    threaded, src/Operator.h:330-346, src/Fields.h:192-308)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    ncores = os.cpu_count() or 1
+    if os.path.exists(exe):
+        out = subprocess.run([exe, "/tmp", "bench", str(n), str(iters)], capture_output=True, text=True, timeout=900)
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                d = json.loads(line)
+                return {"value": d["it_per_s"], "unit": "it/s", "cores": 1, "kind": "reference",
+                        "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by the real reference "
+                                  "(oracle/_ref/ref_harness, g++ -O3), 1 thread of %d host cores" % (iters, n, ncores),
+                        "spmv_seconds": d["spmv_seconds"], "host_cores": ncores}
+    # fallback: the oracle port (same operation order, fewer temporaries => faster than the reference)
+    import numpy as np  # noqa: F401
+    from oracle import oracle as orc
+    N, rowptr, col, val = orc.poisson3d(n)
+    A = orc.csr(N, N, rowptr, col, val)
+    b = orc.fill_rhs(N, 0)
+    t0 = time.perf_counter()
+    orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=iters, tol=0.0), b)
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "it/s", "cores": 1, "kind": "port",
+            "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by oracle/mgcr_oracle.c, 1 thread"
+                      % (iters, n), "host_cores": ncores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=128, help="Poisson grid edge per GPU shard (128 = BASELINE configs[1])")
+    ap.add_argument("--restart", type=int, default=5)
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, world, args.gpus))
+
+    import numpy as np
+    import torch
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, Sparse, problems
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        raise SystemExit("multi-GPU bench: distributed path not wired yet in this revision")
+    mg.init(local_rank)
+
+    n = args.n
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    nnz = int(rowptr[-1])
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    dims = (n, n, n)
+    rhs = Field(dims).fill_rhs(0)
+    x = Field(dims)
+
+    def run(iters):
+        x.set_zero()
+        gcr = GCR(A, GCR_Param(0, args.restart, iters, 0.0, False, check_every=max(iters, 1)))
+        torch.cuda.synchronize()
+        mg.lib().mgcr_synchronize()
+        t0 = time.perf_counter()
+        gcr.solve(rhs, x)
+        mg.lib().mgcr_synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert gcr.last_iterations == iters, (gcr.last_iterations, iters)
+        return dt, gcr
+
+    if args.warmup > 0:
+        run(args.warmup)
+    dt, gcr = run(args.steps)
+    hist = gcr.last_history
+    ms_per_step = dt * 1e3 / args.steps
+    it_per_s = args.steps / dt
+
+    # dominant kernel: SpMV, timed with hipEvents on the library stream
+    y = Field(dims)
+    spmv_ms = A.bench_apply(rhs, y, reps=args.spmv_reps)
+    b_spmv = spmv_algorithmic_bytes(nnz, N, ncol)
+    stored = A.stored_bytes()
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            d = json.load(open(prof))
+            if d.get("n") == n:
+                traffic = d.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    V = 16 * N
+    mean_lim = (args.restart + 1) / 2.0
+    iter_bytes_model = b_spmv + (13 + 3 * mean_lim) * V       # SURVEY.md §8(d) accounting
+    iter_bytes_ours = b_spmv + (11 + 3 * mean_lim) * V        # what this implementation moves (gcr.hip header)
+
+    out = {
+        "metric": "gcr_iterations_per_sec", "value": it_per_s * world, "unit": "it/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "complex-f64", "data": "synthetic",
+        "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, fp64 complex, x0=0, "
+                               "RHS splitmix64 seed 0" % (n, args.restart),
+                   "rows": N, "nnz": nnz, "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],
+                   "partition": "1 GPU" if world == 1 else "slab x%d" % world},
+        "spmv": {"ms": spmv_ms, "algorithmic_bytes": b_spmv, "stored_matrix_bytes": stored["matrix_bytes"],
+                 "GBps": achieved, "frac_hbm_peak": achieved / HBM_PEAK_GBS},
+        "iteration": {"algorithmic_bytes_survey": iter_bytes_model, "bytes_moved_model": iter_bytes_ours,
+                      "GBps_survey": iter_bytes_model / (ms_per_step * 1e-3) / 1e9,
+                      "frac_hbm_peak_survey": iter_bytes_model / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "roofline": {"kernel": "ell_spmv_rowthread<7> (SpMV)", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
+        "final_rel_residual": float(hist[-1]),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(n)
+        except Exception as e:  # the baseline leg must never take the GPU numbers down with it
+            out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/* mgcr.h — C ABI of libmgcr_hip.so: the MI355X (gfx950) implementation of the multigrid-
+ * preconditioned GCR inner loop (SpMV + MG V-cycle pieces + GCR orthogonalisation).
+ *
+ * The reference (jing2li/MGPreconditionedGCR @ 2024_10_08) has no FFI: its seam is the C++
+ * virtual `Operator<num_type>` plus `Field<num_type>` and the `*_Param` structs.  Every entry
+ * point below names the reference interface it replaces (paths relative to the reference root);
+ * include/mgcr/ *.h re-creates those C++ classes on top of this ABI.
+ *
+ * Conventions
+ *  - plain C types only; complex data is interleaved (re,im) doubles ("ri"), i.e. layout-
+ *    compatible with std::complex<double>[] (src/Fields.h:70, src/Operator.h:97);
+ *  - every function returns an int status (MGCR_OK = 0); mgcr_last_error() gives the message of
+ *    the last failure on the calling thread.  Nothing aborts (the reference asserts/exit(1)s,
+ *    src/Fields.h:14,279-283 — the C++ shim turns a non-zero status back into that behaviour);
+ *  - host arrays passed in are copied, never adopted; handles are opaque and destroyed explicitly;
+ *  - one process drives one GPU (mgcr_init(device)); the library is thread-compatible: entry
+ *    points serialise on an internal mutex, so an operator may be applied from several host
+ *    threads (the reference does that inside its OpenMP set-up loops, src/MG.h:206-278);
+ *  - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *    MGCR_ERR_NO_DEVICE.
+ */
+#ifndef MGCR_H
+#define MGCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGCR_OK 0
+#define MGCR_ERR_INVALID 1      /* bad argument (size mismatch, null handle, ...) */
+#define MGCR_ERR_NO_DEVICE 2    /* no HIP device / mgcr_init not called */
+#define MGCR_ERR_HIP 3          /* a HIP runtime call failed */
+#define MGCR_ERR_ALLOC 4
+#define MGCR_ERR_IO 5
+#define MGCR_ERR_COMM 6
+#define MGCR_ERR_UNSUPPORTED 7
+
+typedef struct mgcr_vec_s *mgcr_vec_t; /* device-resident Field   (src/Fields.h:29-71)   */
+typedef struct mgcr_op_s *mgcr_op_t;   /* device-resident Operator (src/Operator.h:16-29) */
+
+/* ---- context ------------------------------------------------------------------------------ */
+int mgcr_init(int device);
+int mgcr_finalize(void);
+const char *mgcr_last_error(void);
+const char *mgcr_version(void);
+/* name, CU count and total memory of the active device */
+int mgcr_device_info(char *name, int name_cap, int *n_cu, int64_t *mem_bytes);
+/* blocks until all work queued by this library has finished */
+int mgcr_synchronize(void);
+
+/* ---- Field: src/Fields.h ------------------------------------------------------------------- */
+int mgcr_vec_create(int64_t n, mgcr_vec_t *out);                   /* Field(dims,ndim)   :77-80  */
+int mgcr_vec_destroy(mgcr_vec_t v);                                /* ~Field             :186-190 */
+int64_t mgcr_vec_size(mgcr_vec_t v);                               /* field_size         :120-123 */
+int mgcr_vec_upload(mgcr_vec_t v, const double *host_ri);          /* Field(dims,ndim,init) :83-89 */
+int mgcr_vec_download(mgcr_vec_t v, double *host_ri);              /* val_at             :163-168 */
+int mgcr_vec_copy(mgcr_vec_t dst, mgcr_vec_t src);                 /* operator=          :256-286 */
+int mgcr_vec_zero(mgcr_vec_t v);                                   /* set_zero           :137-145 */
+int mgcr_vec_set_constant(mgcr_vec_t v, const double c_ri[2]);     /* set_constant       :146-151 */
+/* deterministic repo-owned RHS on the grid of init_rand (:125-135) — splitmix64, not libc rand */
+int mgcr_vec_fill_rhs(mgcr_vec_t v, uint64_t seed, int64_t global_offset);
+int mgcr_dot(mgcr_vec_t a, mgcr_vec_t b, double out_ri[2]);        /* dot: sum conj(a)b  :216-226 */
+int mgcr_norm2(mgcr_vec_t a, double *out);                         /* squarednorm        :228-235 */
+/* out = a + alpha*b   (operator+ / operator- / operator* fused)                 :192-214,245-253 */
+int mgcr_add_scaled(mgcr_vec_t out, mgcr_vec_t a, const double alpha_ri[2], mgcr_vec_t b);
+int mgcr_axpy(const double alpha_ri[2], mgcr_vec_t x, mgcr_vec_t y); /* y += alpha*x  (+=  :288-297) */
+int mgcr_scale(mgcr_vec_t v, const double alpha_ri[2]);            /* operator*          :245-253 */
+int mgcr_normalise(mgcr_vec_t v);                                  /* normalise          :237-243 */
+
+/* ---- Operators: src/Operator.h, src/HierarchicalSparse.h ---------------------------------- */
+/* Sparse<long> (CSR, int64 indices as the reference stores them, src/Operator.h:56-101).  The
+ * device copy is an ELL slab (column-major, int32 columns) plus a CSR tail for long rows. */
+int mgcr_csr_create(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col,
+                    const double *val_ri, mgcr_op_t *out);
+/* DiracOp = 1 - k D (src/Operator.h:104-122,569-575): a view on `csr` that applies
+ * y = x - k*(D x) with the shift fused into the SpMV epilogue.  Borrows `csr` (as the reference
+ * borrows its Sparse*). */
+int mgcr_dirac_create(mgcr_op_t csr, const double k_ri[2], mgcr_op_t *out);
+int mgcr_dirac_set_k(mgcr_op_t dirac, const double k_ri[2]);       /* set_k src/Operator.h:116 */
+/* HierarchicalSparse<long,int> (block-CSR of dense bs x bs blocks, row-major inside a block,
+ * src/HierarchicalSparse.h:22-48) from UNSORTED (block-row, block-col, block) triplets with the
+ * constructor's semantics (:58-98): sorted by row*nbcol+col, duplicates of a pair kept and
+ * summed at apply time. */
+int mgcr_bcsr_create_from_triplets(int32_t nbrow, int32_t nbcol, int32_t bs, int32_t ntriplets,
+                                   const int32_t *rows, const int32_t *cols, const double *blocks_ri,
+                                   mgcr_op_t *out);
+int mgcr_bcsr_create(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *browptr,
+                     const int32_t *bcol, const double *blocks_ri, mgcr_op_t *out);
+int mgcr_op_destroy(mgcr_op_t op);
+int64_t mgcr_op_dim(mgcr_op_t op);                                 /* get_dim src/Operator.h:21 */
+int64_t mgcr_op_nrow(mgcr_op_t op);
+int64_t mgcr_op_nnz(mgcr_op_t op);
+/* y = op(x)        Operator::operator() src/Operator.h:19; Sparse :330-346; DiracOp :569-575;
+ *                  HierarchicalSparse.h:101-161; GCR.h:62-68; MG.h:124-129 */
+int mgcr_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y);
+/* bytes the device layout of `op` occupies / streams per apply (for roofline accounting) */
+int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width, int64_t *tail_nnz);
+
+/* ---- GCR: src/GCR.h, src/SolverParam.h ---------------------------------------------------- */
+typedef struct mgcr_gcr_param {
+    /* GCR_Param (src/SolverParam.h:21-35) */
+    int32_t truncation; /* != 0: ring of `truncation` directions, never wiped      */
+    int32_t restart;    /* != 0: `restart` slots, all wiped every `restart` steps  */
+    int32_t max_iter;   /* do..while: at least one iteration even for 0 (src/GCR.h:222,288) */
+    double tol;         /* stop when |r|^2/|b|^2 <= tol^2 (src/GCR.h:288)          */
+    int32_t verbose;    /* print "Step %d residual norm = %.10e" lines (src/GCR.h:214,271) */
+    mgcr_op_t left_precond;  /* SolverParam (src/SolverParam.h:10-18); may be NULL */
+    mgcr_op_t right_precond;
+    /* extensions, 0 = the reference's behaviour */
+    int32_t use_x0;      /* 1: r0 = b - A x0 (the reference uses r0 = b, src/GCR.h:189) */
+    int32_t flexible;    /* 1: flexible right preconditioning (p = M r, true residual kept)
+                            instead of the reference's literal r = M(r) (src/GCR.h:236-238) */
+    int32_t check_every; /* host looks at the device-side convergence flag every this many
+                            iterations (0 = library default); results do not depend on it */
+} mgcr_gcr_param;
+
+/* GCR::solve(rhs, x) (src/GCR.h:158-302).  hist[0] is the step-0 entry, hist[k] the value
+ * printed at step k (sqrt(|r|^2)/|b|); at most hist_cap entries are written (hist may be NULL).
+ * *n_iter = iterations performed (global_count); *converged = 0 iff n_iter == max_iter. */
+int mgcr_gcr_solve(mgcr_op_t A, const mgcr_gcr_param *param, mgcr_vec_t rhs, mgcr_vec_t x,
+                   double *hist, int32_t hist_cap, int32_t *n_iter, int32_t *converged);
+/* GCR as an Operator (src/GCR.h:19-50,62-68): apply(f) solves A x = f.  A may be NULL and be
+ * supplied later with mgcr_gcr_set_operator (GCR(GCR_Param*) + initialise(), src/GCR.h:30-31).
+ * x0_mode 0: x0 = the vector given with mgcr_gcr_set_x0 (the reference seeds x0 with
+ * init_rand(2)); 1: x0 = 0.  Used as smoother / coarse solver / preconditioner, it runs without
+ * host round-trips: the device-side convergence flag turns the remaining iterations into no-ops. */
+int mgcr_gcr_create(mgcr_op_t A, const mgcr_gcr_param *param, int32_t x0_mode, mgcr_op_t *out);
+int mgcr_gcr_set_operator(mgcr_op_t gcr, mgcr_op_t A);
+int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0);
+
+/* ---- measurement helpers (bench.py) ------------------------------------------------------- */
+/* runs `reps` applies back to back on the library stream, bracketed by hipEvents there;
+ * returns the average milliseconds per apply */
+int mgcr_bench_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y, int32_t reps, double *ms_avg);
+/* opaque hipEvent-based stopwatch on the library stream */
+int mgcr_timer_start(void);
+int mgcr_timer_stop(double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGCR_H */

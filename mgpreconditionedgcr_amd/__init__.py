@@ -1,0 +1,13 @@
+"""MI355X-native multigrid-preconditioned GCR hot path (SpMV + MG V-cycle + GCR orthogonalisation).
+
+Drop-in for that one path of jing2li/MGPreconditionedGCR behind its Operator / Field / *_Param
+interface: hand-written HIP (gfx950) kernels in libmgcr_hip.so behind the C ABI of
+include/mgcr.h; this package is the Python mirror of the reference's host interface.
+"""
+from ._lib import MgcrError, finalize, init, lib  # noqa: F401
+from .api import (DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, Operator,  # noqa: F401
+                  Sparse, read_data)
+from . import problems  # noqa: F401
+
+__all__ = ["init", "finalize", "lib", "MgcrError", "Field", "Operator", "Sparse", "DiracOp",
+           "HierarchicalSparse", "GCR_Param", "GCR", "read_data", "problems"]

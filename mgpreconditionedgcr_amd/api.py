@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's Operator / Field / SolverParam interface over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference's C++ classes (paths relative
+to the reference root); the data lives in HBM and every operation is a HIP kernel of
+libmgcr_hip.so.  This Python layer is what tests/ and bench.py drive; the C++ twin of the same
+interface is include/mgcr/*.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import GcrParamC, MgcrError, check
+
+c128 = np.complex128
+
+
+def _ri(z):
+    z = complex(z)
+    return (C.c_double * 2)(z.real, z.imag)
+
+
+class Field:
+    """Field<num_type> (src/Fields.h:29-71): complex-fp64 vector tagged with mesh dimensions."""
+
+    def __init__(self, dims, data=None):
+        _lib.init()
+        if isinstance(dims, (int, np.integer)):
+            dims = (int(dims),)
+        self.dims = tuple(int(d) for d in dims)
+        n = int(np.prod(self.dims, dtype=np.int64))
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_vec_create(n, C.byref(h)))
+        self.h = h
+        self._n = n
+        if data is not None:
+            self.upload(data)
+
+    # -- construction / queries
+    @classmethod
+    def like(cls, other):
+        return cls(other.dims)
+
+    def field_size(self):  # src/Fields.h:120-123
+        return self._n
+
+    def get_ndim(self):
+        return len(self.dims)
+
+    def upload(self, data):
+        a = np.ascontiguousarray(data, dtype=c128).reshape(-1)
+        if a.size != self._n:
+            raise MgcrError(1, "Dimension mismatch.")
+        check(_lib.lib().mgcr_vec_upload(self.h, a.ctypes.data))
+        return self
+
+    def to_numpy(self):
+        out = np.empty(self._n, c128)
+        check(_lib.lib().mgcr_vec_download(self.h, out.ctypes.data))
+        return out
+
+    def val_at(self, location):  # src/Fields.h:163-168 (host convenience, one element)
+        if not 0 <= location < self._n:
+            raise MgcrError(1, "Field memory access out of bound!")
+        return self.to_numpy()[location]
+
+    def set_zero(self):  # src/Fields.h:137-145
+        check(_lib.lib().mgcr_vec_zero(self.h))
+        return self
+
+    def set_constant(self, c):  # src/Fields.h:146-151
+        check(_lib.lib().mgcr_vec_set_constant(self.h, _ri(c)))
+        return self
+
+    def fill_rhs(self, seed=0, global_offset=0):
+        """Deterministic repo-owned stand-in for init_rand (src/Fields.h:125-135)."""
+        check(_lib.lib().mgcr_vec_fill_rhs(self.h, seed, global_offset))
+        return self
+
+    def assign(self, other):  # operator= src/Fields.h:256-286
+        check(_lib.lib().mgcr_vec_copy(self.h, other.h))
+        return self
+
+    def copy(self):
+        return Field(self.dims).assign(self)
+
+    # -- algebra (value semantics like the reference; the fused solver kernels do not use these)
+    def dot(self, other):  # src/Fields.h:216-226
+        out = (C.c_double * 2)()
+        check(_lib.lib().mgcr_dot(self.h, other.h, out))
+        return complex(out[0], out[1])
+
+    def squarednorm(self):  # src/Fields.h:228-235
+        out = C.c_double()
+        check(_lib.lib().mgcr_norm2(self.h, C.byref(out)))
+        return out.value
+
+    def norm(self):
+        return float(np.sqrt(self.squarednorm()))
+
+    def add_scaled(self, alpha, other):
+        """self + other*alpha as a new Field (operator+ with operator*, src/Fields.h:192-253)."""
+        out = Field(self.dims)
+        check(_lib.lib().mgcr_add_scaled(out.h, self.h, _ri(alpha), other.h))
+        return out
+
+    def __add__(self, other):
+        return self.add_scaled(1.0, other)
+
+    def __sub__(self, other):
+        return self.add_scaled(-1.0, other)
+
+    def __mul__(self, a):  # src/Fields.h:245-253
+        out = self.copy()
+        check(_lib.lib().mgcr_scale(out.h, _ri(a)))
+        return out
+
+    def __iadd__(self, other):  # src/Fields.h:288-297
+        check(_lib.lib().mgcr_axpy(_ri(1.0), other.h, self.h))
+        return self
+
+    def __isub__(self, other):
+        check(_lib.lib().mgcr_axpy(_ri(-1.0), other.h, self.h))
+        return self
+
+    def normalise(self):  # src/Fields.h:237-243
+        check(_lib.lib().mgcr_normalise(self.h))
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().mgcr_vec_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Operator:
+    """Operator<num_type> (src/Operator.h:16-29)."""
+
+    def __init__(self):
+        self.h = None
+        self._keep = []
+
+    def get_dim(self):
+        return int(_lib.lib().mgcr_op_dim(self.h))
+
+    def get_nrow(self):
+        return int(_lib.lib().mgcr_op_nrow(self.h))
+
+    def __call__(self, f, out=None):
+        """Field operator()(const Field&): applies the operator, returns a new Field."""
+        if out is None:
+            nrow = self.get_nrow()
+            out = Field(f.dims if nrow == f.field_size() else (nrow,))
+        check(_lib.lib().mgcr_op_apply(self.h, f.h, out.h))
+        return out
+
+    def stored_bytes(self):
+        b, w, t = C.c_int64(), C.c_int32(), C.c_int64()
+        check(_lib.lib().mgcr_op_stored_bytes(self.h, C.byref(b), C.byref(w), C.byref(t)))
+        return dict(matrix_bytes=b.value, ell_width=w.value, tail_nnz=t.value)
+
+    def bench_apply(self, x, y, reps=20):
+        ms = C.c_double()
+        check(_lib.lib().mgcr_bench_op_apply(self.h, x.h, y.h, reps, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().mgcr_op_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Sparse(Operator):
+    """Sparse<long> (src/Operator.h:56-101): CSR with int64 indices on the host side."""
+
+    def __init__(self, rows, cols, rowptr, col, val):
+        super().__init__()
+        _lib.init()
+        rowptr = np.ascontiguousarray(rowptr, np.int64)
+        col = np.ascontiguousarray(col, np.int64)
+        val = np.ascontiguousarray(val, c128)
+        if rowptr.size != rows + 1 or col.size != rowptr[-1] or val.size != col.size:
+            raise MgcrError(1, "CSR arrays have inconsistent sizes")
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_csr_create(rows, cols, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, C.byref(h)))
+        self.h = h
+        self._nnz = int(rowptr[-1])
+
+    def get_nnz(self):  # src/Operator.h:73
+        return self._nnz
+
+
+class DiracOp(Operator):
+    """DiracOp = Id - k*D (src/Operator.h:104-122,555-575); borrows the Sparse."""
+
+    def __init__(self, mat, k_factor):
+        super().__init__()
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_dirac_create(mat.h, _ri(k_factor), C.byref(h)))
+        self.h = h
+        self._keep.append(mat)
+
+    def set_k(self, new_k):  # src/Operator.h:116
+        check(_lib.lib().mgcr_dirac_set_k(self.h, _ri(new_k)))
+
+
+class HierarchicalSparse(Operator):
+    """HierarchicalSparse<long,int> (src/HierarchicalSparse.h:22-48) from unsorted
+    (block_row, block_col, dense block) triplets, duplicates kept (ctor :58-98)."""
+
+    def __init__(self, block_rows, block_cols, rows, cols, blocks):
+        super().__init__()
+        _lib.init()
+        rows = np.ascontiguousarray(rows, np.int32)
+        cols = np.ascontiguousarray(cols, np.int32)
+        blocks = np.ascontiguousarray(blocks, c128)
+        nt = rows.size
+        bs = int(round(np.sqrt(blocks.size // max(nt, 1))))
+        if nt == 0 or bs * bs * nt != blocks.size:
+            raise MgcrError(1, "blocks must hold ntriplets square blocks")
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_bcsr_create_from_triplets(block_rows, block_cols, bs, nt, rows.ctypes.data,
+                                                        cols.ctypes.data, blocks.ctypes.data, C.byref(h)))
+        self.h = h
+        self.bs = bs
+
+
+class GCR_Param:
+    """GCR_Param(trunc, re, max_it, tau, verb, solver_l, solver_r) (src/SolverParam.h:21-35,85-99)."""
+
+    def __init__(self, trunc=0, re=0, max_it=100, tau=1e-16, verb=True, solver_l=None, solver_r=None,
+                 use_x0=False, flexible=False, check_every=0):
+        self.truncation, self.restart, self.max_iter, self.tol = int(trunc), int(re), int(max_it), float(tau)
+        self.verbose = bool(verb)
+        self.left_precond, self.right_precond = solver_l, solver_r
+        self.use_x0, self.flexible, self.check_every = bool(use_x0), bool(flexible), int(check_every)
+
+    def _c(self):
+        return GcrParamC(self.truncation, self.restart, self.max_iter, self.tol, int(self.verbose),
+                         self.left_precond.h if self.left_precond is not None else None,
+                         self.right_precond.h if self.right_precond is not None else None,
+                         int(self.use_x0), int(self.flexible), self.check_every)
+
+
+class GCR(Operator):
+    """GCR<num_type> (src/GCR.h:18-50): `GCR(M, param)` or `GCR(param)` + `initialise(M)`."""
+
+    def __init__(self, M=None, gcr_param=None, x0_mode=1):
+        super().__init__()
+        if isinstance(M, GCR_Param) and gcr_param is None:  # GCR(GCR_Param*) src/GCR.h:30
+            M, gcr_param = None, M
+        _lib.init()
+        self.param = gcr_param
+        self.A = M
+        h = C.c_void_p()
+        pc = gcr_param._c()
+        check(_lib.lib().mgcr_gcr_create(M.h if M is not None else None, C.byref(pc), x0_mode, C.byref(h)))
+        self.h = h
+        self._keep += [M, gcr_param, gcr_param.left_precond, gcr_param.right_precond]
+        self.last_history = None
+        self.last_iterations = None
+        self.last_converged = None
+
+    def initialise(self, M):  # src/GCR.h:31
+        self.A = M
+        self._keep.append(M)
+        check(_lib.lib().mgcr_gcr_set_operator(self.h, M.h))
+
+    def set_x0(self, x0):
+        check(_lib.lib().mgcr_gcr_set_x0(self.h, x0.h if x0 is not None else None))
+
+    def solve(self, rhs, x):
+        """void solve(const Field& rhs, Field& x) (src/GCR.h:158-302). x is updated in place;
+        the residual history / iteration count are kept in last_history / last_iterations."""
+        cap = max(self.param.max_iter, 1) + 1
+        hist = np.zeros(cap, np.float64)
+        it, conv = C.c_int32(), C.c_int32()
+        pc = self.param._c()
+        check(_lib.lib().mgcr_gcr_solve(self.A.h, C.byref(pc), rhs.h, x.h, hist.ctypes.data, cap,
+                                        C.byref(it), C.byref(conv)))
+        self.last_iterations = it.value
+        self.last_converged = bool(conv.value)
+        self.last_history = hist[: it.value + 1].copy()
+        return x
+
+
+def read_data(filename, directory=None):
+    """Sparse<long> read_data(const std::string&) (src/Parse.cpp:64-90).
+
+    The reference opens "../../data/sample_matrix/" + filename relative to the cwd; `directory`
+    (or $MGCR_SAMPLE_DIR) overrides that prefix.  Format: SURVEY.md Appendix B."""
+    prefix = directory if directory is not None else os.environ.get("MGCR_SAMPLE_DIR", "../../data/sample_matrix/")
+    path = os.path.join(prefix, filename)
+    try:
+        f = open(path, "r")
+    except OSError:
+        print("File read is unsuccessful!")  # src/Parse.cpp:67-68 (the reference then reads garbage)
+        raise
+    print("File read is successful.")
+    with f:
+        row, col, nnz = (int(t) for t in f.readline().split())
+        rowptr = np.empty(row + 1, np.int64)
+        rowptr[:row] = np.array(f.readline().split(), dtype=np.int64)
+        rowptr[row] = nnz  # ROW[rows] = nnz, src/Operator.h:61
+        cols = np.empty(nnz, np.int64)
+        vals = np.empty(nnz, c128)
+        for i, line in enumerate(f):
+            if i >= nnz:
+                break
+            a, b = line.split()
+            cols[i] = int(a)
+            re, im = b[1:-1].split(",")
+            vals[i] = complex(float(re), float(im))
+    return Sparse(row, col, rowptr, cols, vals)

@@ -1,0 +1,218 @@
+// Operator / solver part of the C ABI (include/mgcr.h).
+#include <algorithm>
+#include <numeric>
+
+#include "internal.h"
+
+using namespace mgcr;
+
+#define LOCK() std::lock_guard<std::recursive_mutex> lk__(ctx().mtx)
+
+extern "C" {
+
+int mgcr_csr_create(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const double *val_ri,
+                    mgcr_op_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(out && rowptr && (col || rowptr[nrow] == 0) && (val_ri || rowptr[nrow] == 0), MGCR_ERR_INVALID,
+               "mgcr_csr_create: null argument");
+    LOCK();
+    mgcr_op_s *op = new mgcr_op_s();
+    op->kind = OP_CSR;
+    op->dim = ncol;
+    op->nrow = nrow;
+    int rc = csr_build_device(nrow, ncol, rowptr, col, val_ri, &op->csr);
+    if (rc != MGCR_OK) { delete op; return rc; }
+    *out = op;
+    return MGCR_OK;
+}
+
+int mgcr_dirac_create(mgcr_op_t csr, const double k_ri[2], mgcr_op_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(csr && k_ri && out, MGCR_ERR_INVALID, "mgcr_dirac_create: null argument");
+    MGCR_CHECK(csr->kind == OP_CSR, MGCR_ERR_INVALID, "mgcr_dirac_create: DiracOp wraps a Sparse (CSR) operator");
+    MGCR_CHECK(csr->csr.nrow == csr->csr.ncol, MGCR_ERR_INVALID, "mgcr_dirac_create: matrix must be square");
+    LOCK();
+    mgcr_op_s *op = new mgcr_op_s();
+    op->kind = OP_DIRAC;
+    op->dim = csr->dim;
+    op->nrow = csr->nrow;
+    op->base = csr;
+    op->k = make_double2(k_ri[0], k_ri[1]);
+    *out = op;
+    return MGCR_OK;
+}
+
+int mgcr_dirac_set_k(mgcr_op_t dirac, const double k_ri[2]) {
+    MGCR_CHECK(dirac && k_ri && dirac->kind == OP_DIRAC, MGCR_ERR_INVALID, "mgcr_dirac_set_k: not a DiracOp");
+    LOCK();
+    dirac->k = make_double2(k_ri[0], k_ri[1]);
+    return MGCR_OK;
+}
+
+int mgcr_bcsr_create(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *browptr, const int32_t *bcol,
+                     const double *blocks_ri, mgcr_op_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(out && browptr && bcol && blocks_ri, MGCR_ERR_INVALID, "mgcr_bcsr_create: null argument");
+    LOCK();
+    mgcr_op_s *op = new mgcr_op_s();
+    op->kind = OP_BCSR;
+    int rc = bcsr_build_device(nbrow, nbcol, bs, browptr, bcol, blocks_ri, &op->bcsr);
+    if (rc != MGCR_OK) { delete op; return rc; }
+    op->dim = (int64_t)nbcol * bs;  // this->dim = block_cols * sub_dim, src/HierarchicalSparse.h:62
+    op->nrow = (int64_t)nbrow * bs;
+    *out = op;
+    return MGCR_OK;
+}
+
+// HierarchicalSparse constructor (src/HierarchicalSparse.h:58-98): sort the triplets by
+// row*nbcol+col, keep duplicates.  Unlike the reference we accept empty block-rows and a first
+// triplet outside row 0 (its row counter would mis-assign those), and the sort is
+// stable.
+int mgcr_bcsr_create_from_triplets(int32_t nbrow, int32_t nbcol, int32_t bs, int32_t ntriplets, const int32_t *rows,
+                                   const int32_t *cols, const double *blocks_ri, mgcr_op_t *out) {
+    MGCR_CHECK(out && rows && cols && blocks_ri && ntriplets >= 0, MGCR_ERR_INVALID,
+               "mgcr_bcsr_create_from_triplets: bad argument");
+    for (int32_t t = 0; t < ntriplets; t++)
+        MGCR_CHECK(rows[t] >= 0 && rows[t] < nbrow && cols[t] >= 0 && cols[t] < nbcol, MGCR_ERR_INVALID,
+                   "triplet %d: block index (%d,%d) out of range", t, rows[t], cols[t]);
+    std::vector<int32_t> order((size_t)ntriplets);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (int64_t)rows[a] * nbcol + cols[a] < (int64_t)rows[b] * nbcol + cols[b];
+    });
+    std::vector<int32_t> browptr((size_t)nbrow + 1, 0), bcol((size_t)ntriplets);
+    std::vector<double> blocks((size_t)ntriplets * bs * bs * 2);
+    const size_t bsz = (size_t)bs * bs * 2;
+    for (int32_t t = 0; t < ntriplets; t++) {
+        int32_t s = order[(size_t)t];
+        bcol[(size_t)t] = cols[s];
+        std::copy(blocks_ri + (size_t)s * bsz, blocks_ri + (size_t)(s + 1) * bsz, blocks.begin() + (size_t)t * bsz);
+        browptr[(size_t)rows[s] + 1]++;
+    }
+    for (int32_t r = 0; r < nbrow; r++) browptr[(size_t)r + 1] += browptr[(size_t)r];
+    return mgcr_bcsr_create(nbrow, nbcol, bs, browptr.data(), bcol.data(), blocks.data(), out);
+}
+
+int mgcr_op_destroy(mgcr_op_t op) {
+    if (!op) return MGCR_OK;
+    LOCK();
+    if (ctx().ready) hipStreamSynchronize(ctx().stream);
+    switch (op->kind) {
+        case OP_CSR: csr_free(&op->csr); break;
+        case OP_BCSR: bcsr_free(&op->bcsr); break;
+        case OP_GCR: gcr_state_destroy(op->gcr); break;
+        default: break;  // OP_DIRAC borrows its Sparse (src/Operator.h:117,555-560)
+    }
+    delete op;
+    return MGCR_OK;
+}
+
+int64_t mgcr_op_dim(mgcr_op_t op) { return op ? op->dim : -1; }
+int64_t mgcr_op_nrow(mgcr_op_t op) { return op ? op->nrow : -1; }
+int64_t mgcr_op_nnz(mgcr_op_t op) {
+    if (!op) return -1;
+    switch (op->kind) {
+        case OP_CSR: return op->csr.nnz;
+        case OP_DIRAC: return op->base->csr.nnz;
+        case OP_BCSR: return (int64_t)op->bcsr.nblocks * op->bcsr.bs * op->bcsr.bs;  // src/HierarchicalSparse.h:31
+        default: return -1;
+    }
+}
+
+int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width, int64_t *tail_nnz) {
+    MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
+    const Op *o = op->kind == OP_DIRAC ? op->base : op;
+    if (o->kind == OP_CSR) {
+        const CsrDev &A = o->csr;
+        int64_t slab = (int64_t)A.nchunk * A.npad * A.L;
+        if (matrix_bytes) *matrix_bytes = slab * 20 + A.tail_nnz * 20 + A.n_tail_rows * 8 + (A.n_tail_rows ? 4 : 0);
+        if (ell_width) *ell_width = A.nchunk * A.L;
+        if (tail_nnz) *tail_nnz = A.tail_nnz;
+        return MGCR_OK;
+    }
+    if (o->kind == OP_BCSR) {
+        const BcsrDev &B = o->bcsr;
+        if (matrix_bytes) *matrix_bytes = (int64_t)B.nblocks * (16LL * B.bs * B.bs + 4) + ((int64_t)B.nbrow + 1) * 4;
+        if (ell_width) *ell_width = 0;
+        if (tail_nnz) *tail_nnz = 0;
+        return MGCR_OK;
+    }
+    set_error("mgcr_op_stored_bytes: not a matrix operator");
+    return MGCR_ERR_UNSUPPORTED;
+}
+
+int mgcr_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(op && x && y, MGCR_ERR_INVALID, "mgcr_op_apply: null argument");
+    MGCR_CHECK(x->n == op->dim, MGCR_ERR_INVALID, "Sparse matrix dimension does not match Field dimension!");
+    int64_t nrow = op->nrow ? op->nrow : op->dim;
+    MGCR_CHECK(y->n == nrow, MGCR_ERR_INVALID, "output Field has %lld entries, operator has %lld rows", (long long)y->n, (long long)nrow);
+    LOCK();
+    return op_apply_raw(op, x->d, y->d, x->n);
+}
+
+int mgcr_gcr_solve(mgcr_op_t A, const mgcr_gcr_param *param, mgcr_vec_t rhs, mgcr_vec_t x, double *hist, int32_t hist_cap,
+                   int32_t *n_iter, int32_t *converged) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(A && param && rhs && x, MGCR_ERR_INVALID, "mgcr_gcr_solve: null argument");
+    // assertm(rhs.field_size() == this->dim, ...) src/GCR.h:160-161
+    MGCR_CHECK(rhs->n == A->dim, MGCR_ERR_INVALID, "Field dimension does not match with Operator!");
+    MGCR_CHECK(x->n == A->dim, MGCR_ERR_INVALID, "x dimension does not match with Operator!");
+    MGCR_CHECK(rhs->d != x->d, MGCR_ERR_INVALID, "rhs and x must be different Fields");
+    LOCK();
+    GcrState *s = nullptr;
+    MGCR_TRY(gcr_state_create(A, param, 1, &s));
+    int it = 0, conv = 0;
+    int rc = gcr_run(s, rhs->d, x->d, false, hist, hist_cap, &it, &conv);
+    gcr_state_destroy(s);
+    if (n_iter) *n_iter = it;
+    if (converged) *converged = conv;
+    return rc;
+}
+
+int mgcr_gcr_create(mgcr_op_t A, const mgcr_gcr_param *param, int32_t x0_mode, mgcr_op_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(param && out, MGCR_ERR_INVALID, "mgcr_gcr_create: null argument");
+    LOCK();
+    mgcr_op_s *op = new mgcr_op_s();
+    op->kind = OP_GCR;
+    op->dim = A ? A->dim : 0;
+    op->nrow = op->dim;
+    int rc = gcr_state_create(A, param, x0_mode, &op->gcr);
+    if (rc != MGCR_OK) { delete op; return rc; }
+    *out = op;
+    return MGCR_OK;
+}
+
+int mgcr_gcr_set_operator(mgcr_op_t gcr, mgcr_op_t A) {
+    MGCR_CHECK(gcr && A && gcr->kind == OP_GCR, MGCR_ERR_INVALID, "mgcr_gcr_set_operator: not a GCR operator");
+    LOCK();
+    gcr->dim = A->dim;  // GCR::initialise src/GCR.h:31
+    gcr->nrow = A->dim;
+    return gcr_state_set_operator(gcr->gcr, A);
+}
+
+int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(gcr && gcr->kind == OP_GCR, MGCR_ERR_INVALID, "mgcr_gcr_set_x0: not a GCR operator");
+    LOCK();
+    return gcr_state_set_x0(gcr->gcr, x0 ? x0->d : nullptr, x0 ? x0->n : 0);
+}
+
+int mgcr_bench_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y, int32_t reps, double *ms_avg) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(op && x && y && reps > 0 && ms_avg, MGCR_ERR_INVALID, "mgcr_bench_op_apply: bad argument");
+    LOCK();
+    Context &c = ctx();
+    MGCR_TRY(mgcr_op_apply(op, x, y));  // warm-up (and argument checks)
+    MGCR_HIP(hipEventRecord(c.ev0, c.stream));
+    for (int i = 0; i < reps; i++) MGCR_TRY(op_apply_raw(op, x->d, y->d, x->n));
+    MGCR_HIP(hipEventRecord(c.ev1, c.stream));
+    MGCR_HIP(hipEventSynchronize(c.ev1));
+    float ms = 0.f;
+    MGCR_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    *ms_avg = (double)ms / reps;
+    return MGCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Stand-alone Field kernels (src/Fields.h): copy / fill / axpy-like / dot.  HBM-bound streaming
+// kernels: 16 B per lane per access (one complex fp64 = one dwordx4), grid-stride over at most
+// RED_MAX_BLOCKS x RED_THREADS threads so that every CU holds its full 32 waves.
+#include "internal.h"
+#include "reduce.h"
+
+namespace mgcr {
+
+int red_grid(int64_t n) {
+    int64_t g = (n + RED_THREADS - 1) / RED_THREADS;
+    if (g < 1) g = 1;
+    if (g > RED_MAX_BLOCKS) g = RED_MAX_BLOCKS;
+    return (int)g;
+}
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void __launch_bounds__(RED_THREADS) copy_kernel(cplx *__restrict__ dst, const cplx *__restrict__ src, int64_t n) {
+    GRID_STRIDE(i, n) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(RED_THREADS) set_kernel(cplx *__restrict__ dst, cplx c, int64_t n) {
+    GRID_STRIDE(i, n) dst[i] = c;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// values on the 0.001 grid of Field::init_rand (src/Fields.h:133), from a repo-owned generator
+__global__ void __launch_bounds__(RED_THREADS) fill_rhs_kernel(cplx *__restrict__ dst, int64_t n, uint64_t seed, int64_t off) {
+    GRID_STRIDE(i, n) {
+        uint64_t g = (uint64_t)(i + off);
+        uint64_t a = splitmix64(seed * 0x100000001B3ull + 2 * g);
+        uint64_t b = splitmix64(seed * 0x100000001B3ull + 2 * g + 1);
+        dst[i] = make_double2((double)(a % 2000) / 1000. - 1., (double)(b % 2000) / 1000. - 1.);
+    }
+}
+// out = a + alpha*b; out may alias a or b (each element is read before it is written by the same lane)
+__global__ void __launch_bounds__(RED_THREADS) add_scaled_kernel(cplx *out, const cplx *a, cplx alpha, const cplx *b, int64_t n) {
+    GRID_STRIDE(i, n) out[i] = cadd(a[i], cmul(alpha, b[i]));
+}
+__global__ void __launch_bounds__(RED_THREADS) scale_kernel(cplx *v, cplx alpha, int64_t n) {
+    GRID_STRIDE(i, n) v[i] = cmul(alpha, v[i]);
+}
+
+// partial sums of conj(a_i) b_i  ->  parts[0][blk] (re), parts[1][blk] (im)
+__global__ void __launch_bounds__(RED_THREADS) dot_partials_kernel(const cplx *__restrict__ a, const cplx *__restrict__ b,
+                                                                  int64_t n, double *__restrict__ parts) {
+    __shared__ double lds[2 * 17];
+    double v[2] = {0., 0.};
+    GRID_STRIDE(i, n) {
+        cplx t = cconj_mul(a[i], b[i]);
+        v[0] += t.x;
+        v[1] += t.y;
+    }
+    block_sum_bcast<2>(v, lds);
+    if (threadIdx.x == 0) {
+        parts[blockIdx.x] = v[0];
+        parts[RED_MAX_BLOCKS + blockIdx.x] = v[1];
+    }
+}
+
+__global__ void __launch_bounds__(RED_THREADS) fold_kernel(const double *__restrict__ parts, int nblk, int nscal, double *__restrict__ out) {
+    __shared__ double lds[17];
+    for (int k = 0; k < nscal; k++) {
+        double v[1];
+        fold_partials<1>(parts + (size_t)k * RED_MAX_BLOCKS, nblk, v, lds);
+        if (threadIdx.x == 0) out[k] = v[0];
+    }
+}
+
+#define LAUNCH(kernel, grid, ...)                                                     \
+    do {                                                                              \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(RED_THREADS), 0, ctx().stream, __VA_ARGS__); \
+        MGCR_HIP(hipGetLastError());                                                  \
+    } while (0)
+
+int k_copy(cplx *dst, const cplx *src, int64_t n) {
+    if (n == 0 || dst == src) return MGCR_OK;
+    LAUNCH(copy_kernel, red_grid(n), dst, src, n);
+    return MGCR_OK;
+}
+int k_zero(cplx *dst, int64_t n) { return k_set_constant(dst, make_double2(0., 0.), n); }
+int k_set_constant(cplx *dst, cplx c, int64_t n) {
+    if (n == 0) return MGCR_OK;
+    LAUNCH(set_kernel, red_grid(n), dst, c, n);
+    return MGCR_OK;
+}
+int k_fill_rhs(cplx *dst, int64_t n, uint64_t seed, int64_t offset) {
+    if (n == 0) return MGCR_OK;
+    LAUNCH(fill_rhs_kernel, red_grid(n), dst, n, seed, offset);
+    return MGCR_OK;
+}
+int k_add_scaled(cplx *out, const cplx *a, cplx alpha, const cplx *b, int64_t n) {
+    if (n == 0) return MGCR_OK;
+    LAUNCH(add_scaled_kernel, red_grid(n), out, a, alpha, b, n);
+    return MGCR_OK;
+}
+int k_scale(cplx *v, cplx alpha, int64_t n) {
+    if (n == 0) return MGCR_OK;
+    LAUNCH(scale_kernel, red_grid(n), v, alpha, n);
+    return MGCR_OK;
+}
+int k_dot_partials(const cplx *a, const cplx *b, int64_t n, double *parts, int *nblk) {
+    int g = red_grid(n);
+    LAUNCH(dot_partials_kernel, g, a, b, n, parts);
+    *nblk = g;
+    return MGCR_OK;
+}
+int k_fold(const double *parts, int nblk, int nscal, double *out_dev) {
+    LAUNCH(fold_kernel, 1, parts, nblk, nscal, out_dev);
+    return MGCR_OK;
+}
+
+}  // namespace mgcr

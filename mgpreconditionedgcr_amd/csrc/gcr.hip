@@ -1,0 +1,539 @@
+// Device-resident GCR (restarted / truncated / full) — the reference's GCR<T>::solve
+// (src/GCR.h:158-302) re-designed for MI355X:
+//
+//   * x, r and the stored directions live in HBM for the whole solve; p and Ap are not separate
+//     vectors but the ring slot that was written last (the reference copies them, :286-287);
+//   * per iteration three fused BLAS-1 kernels + one SpMV instead of ~90 vector passes
+//     (SURVEY.md §8(a) A3):
+//        xr_update   x += a p, r -= a Ap, |r|^2 partials                         6 V
+//        SpMV        Ar = A r                                                     B_spmv
+//        multidot    <Ar, Aps[i]> partials for all stored i in one pass           (1+lim) V
+//        build       p' = r - sum b_i ps[i], Ap' = Ar - sum b_i Aps[i] written straight into the
+//                    ring slot, plus <r,Ap'> and <Ap',Ap'> partials               (4+2 lim) V
+//     = B_spmv + (11 + 3 lim) V of HBM traffic per iteration;
+//   * all scalars (alpha, beta_i, norms, the iteration counter, the convergence flag and the
+//     residual history) stay on the device.  Reductions are two-stage and deterministic: producers
+//     write per-workgroup partials, consumers fold them in a fixed order (reduce.h), so the
+//     history is reproducible run to run.  The host only looks at the flag every `check_every`
+//     iterations; once the flag is up every later kernel returns immediately, so x, r and the
+//     history are exactly those of the converged step;
+//   * used as an Operator (smoother / coarse solver / preconditioner, src/GCR.h:62-68) a solve
+//     is enqueued without any host round trip.
+//
+// Arithmetic follows the reference's order and conjugation (alpha = <r,Ap>/<Ap,Ap> with conj on
+// r, beta = <Ar,Aps_i>/<Aps_i,Aps_i> with conj on Ar: SURVEY.md §0 fact 2); the library is built
+// with -ffp-contract=off so element-wise results round like the reference's.
+#include <cmath>
+
+#include "internal.h"
+#include "reduce.h"
+
+namespace mgcr {
+
+void set_apply_skip_flag(const int *flag);
+const int *get_apply_skip_flag();
+
+constexpr int ND = 8;  // directions per multidot / build launch
+
+struct DevState {
+    int done;      // set on convergence; every later kernel of this solve is a no-op
+    int iter;      // global_count
+    int pad0, pad1;
+    double bnorm2; // |b|^2
+    double rr;     // |r|^2 of the last finished step
+    double tol2;
+};
+
+struct DirPtrs {
+    const cplx *ps[ND];
+    const cplx *aps[ND];
+    int slot[ND];
+};
+
+struct GcrState {
+    Op *A = nullptr;
+    mgcr_gcr_param p{};
+    int x0_mode = 1;
+    int64_t n = 0;
+    int storage = 0, restart = 0;
+    int alloc_slots = 0;
+    std::vector<cplx *> ps, aps;
+    cplx *r = nullptr, *ar = nullptr, *z = nullptr, *tmp = nullptr, *accp = nullptr, *accap = nullptr;
+    cplx *x0 = nullptr;
+    DevState *st = nullptr;
+    double *partsA = nullptr, *partsR = nullptr, *partsN = nullptr, *partsB = nullptr;
+    cplx *den = nullptr;  // cached <Aps[i],Aps[i]> per slot
+    double *hist = nullptr;
+    int hist_cap = 0;
+    int partsB_dirs = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void reset_kernel(DevState *st, const int *inherit, double tol2) {
+    st->done = inherit ? *inherit : 0;
+    st->iter = 0;
+    st->bnorm2 = 0.;
+    st->rr = 0.;
+    st->tol2 = tol2;
+}
+
+// r = b - t  (use_x0 extension)
+__global__ void __launch_bounds__(RED_THREADS) sub_kernel(cplx *__restrict__ out, const cplx *__restrict__ a,
+                                                          const cplx *__restrict__ b, int64_t n, const DevState *st) {
+    if (st->done) return;
+    GRID_STRIDE(i, n) out[i] = csub(a[i], b[i]);
+}
+
+// partials of |a|^2 -> parts[blk]
+__global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *__restrict__ a, int64_t n,
+                                                                   double *__restrict__ parts, const DevState *st) {
+    __shared__ double lds[17];
+    if (st && st->done) return;
+    double v[1] = {0.};
+    GRID_STRIDE(i, n) {
+        cplx t = a[i];
+        v[0] += t.x * t.x + t.y * t.y;  // Re(conj(a) a), src/Fields.h:228-235
+    }
+    block_sum_bcast<1>(v, lds);
+    if (threadIdx.x == 0) parts[blockIdx.x] = v[0];
+}
+
+// partials of <r,Ap> (conj on r) and <Ap,Ap>  ->  partsA[0..3][blk]
+__global__ void __launch_bounds__(RED_THREADS) dot2_partials_kernel(const cplx *__restrict__ r, const cplx *__restrict__ ap,
+                                                                   int64_t n, double *__restrict__ parts, const DevState *st) {
+    __shared__ double lds[4 * 17];
+    if (st->done) return;
+    double v[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n) {
+        cplx a = ap[i];
+        cplx t = cconj_mul(r[i], a);
+        v[0] += t.x; v[1] += t.y;
+        cplx u = cconj_mul(a, a);
+        v[2] += u.x; v[3] += u.y;
+    }
+    block_sum_bcast<4>(v, lds);
+    if (threadIdx.x < 4) parts[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+}
+
+// step 0 bookkeeping (src/GCR.h:213-216)
+__global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const double *__restrict__ partsN, int nblkN,
+                                                           const double *__restrict__ partsR, int nblkR,
+                                                           double *__restrict__ hist) {
+    __shared__ double lds[17];
+    if (st->done) return;
+    double b[1], r[1];
+    fold_partials<1>(partsN, nblkN, b, lds);
+    fold_partials<1>(partsR, nblkR, r, lds);
+    if (threadIdx.x == 0) {
+        st->bnorm2 = b[0];
+        st->rr = r[0];
+        hist[0] = sqrt(r[0]) / sqrt(b[0]);
+    }
+}
+
+// alpha = <r,Ap>/<Ap,Ap>;  x = x + p*alpha;  r = r - Ap*alpha  (src/GCR.h:230-233) + |r|^2 partials
+__global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *__restrict__ st, const double *__restrict__ partsA,
+                                                                int nblkA, const cplx *__restrict__ p,
+                                                                const cplx *__restrict__ ap, cplx *__restrict__ x,
+                                                                cplx *__restrict__ r, int64_t n, double *__restrict__ partsR,
+                                                                cplx *__restrict__ den_slot) {
+    __shared__ double lds[4 * 17];
+    if (st->done) return;
+    double s[4];
+    fold_partials<4>(partsA, nblkA, s, lds);
+    const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
+    const cplx alpha = cdiv(num, den);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *den_slot = den;
+    double v[1] = {0.};
+    GRID_STRIDE(i, n) {
+        x[i] = cadd(x[i], cmul(alpha, p[i]));
+        cplx rn = csub(r[i], cmul(alpha, ap[i]));
+        r[i] = rn;
+        v[0] += rn.x * rn.x + rn.y * rn.y;
+    }
+    block_sum_bcast<1>(v, lds);
+    if (threadIdx.x == 0) partsR[blockIdx.x] = v[0];
+}
+
+// <Ar, Aps[j]> for j < nd (conj on Ar, src/GCR.h:258) -> partsB[(base+j)*2 + {0,1}][blk].
+// When `book` is set, workgroup 0 also closes the step: folds |r|^2, bumps the iteration
+// counter, records the history entry and raises the convergence flag (src/GCR.h:270-274,288).
+__global__ void __launch_bounds__(RED_THREADS) multidot_kernel(DevState *__restrict__ st, const cplx *__restrict__ ar,
+                                                               DirPtrs d, int nd, int base, int64_t n,
+                                                               double *__restrict__ partsB, int book,
+                                                               const double *__restrict__ partsR, int nblkR,
+                                                               double *__restrict__ hist, int hist_cap) {
+    __shared__ double lds[2 * ND * 17];
+    if (st->done) return;
+    double v[2 * ND];
+#pragma unroll
+    for (int j = 0; j < 2 * ND; j++) v[j] = 0.;
+    GRID_STRIDE(i, n) {
+        cplx a = ar[i];
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+            if (j < nd) {
+                cplx t = cconj_mul(a, d.aps[j][i]);
+                v[2 * j] += t.x;
+                v[2 * j + 1] += t.y;
+            }
+        }
+    }
+    block_sum_bcast<2 * ND>(v, lds);
+    if (threadIdx.x < 2 * nd) partsB[(size_t)(2 * base + threadIdx.x) * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+    if (book && blockIdx.x == 0) {
+        double rr[1];
+        fold_partials<1>(partsR, nblkR, rr, lds);
+        if (threadIdx.x == 0) {
+            int it = st->iter + 1;
+            st->iter = it;
+            st->rr = rr[0];
+            if (it < hist_cap) hist[it] = sqrt(rr[0]) / sqrt(st->bnorm2);
+            // continue while |r|^2/|b|^2 > tol^2 (src/GCR.h:288); NaN compares false -> stop, like the reference
+            if (!((rr[0] / st->bnorm2) > st->tol2)) st->done = 1;
+        }
+    }
+}
+
+// beta_j = <Ar,Aps_j>/<Aps_j,Aps_j>;  p_corr -= ps_j*beta_j;  Ap_corr -= Aps_j*beta_j  (src/GCR.h:257-262)
+// first: accumulators start at 0 (else read from accp/accap); last: p' = dir + p_corr, Ap' = Ar + Ap_corr
+// are written to the ring slot (src/GCR.h:265-266,286-287) and <r,Ap'>, <Ap',Ap'> partials emitted.
+__global__ void __launch_bounds__(RED_THREADS) build_kernel(const DevState *__restrict__ st, const double *__restrict__ partsB,
+                                                            int nblkB, const cplx *__restrict__ den, DirPtrs d, int nd, int base,
+                                                            int first, int last, const cplx *__restrict__ dir,
+                                                            const cplx *__restrict__ r, const cplx *__restrict__ ar,
+                                                            cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n,
+                                                            double *__restrict__ partsA) {
+    __shared__ double lds[2 * ND * 17];
+    __shared__ cplx sbeta[ND];
+    if (st->done) return;
+    double s[2 * ND];
+    fold_partials<2 * ND>(partsB + (size_t)(2 * base) * RED_MAX_BLOCKS, nblkB, s, lds);
+    if (threadIdx.x < nd) {
+        // s[] is identical in every thread; pick this thread's pair without dynamic register indexing
+        cplx num = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < ND; j++)
+            if (j == (int)threadIdx.x) num = make_double2(s[2 * j], s[2 * j + 1]);
+        sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
+    }
+    __syncthreads();
+    cplx beta[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) beta[j] = (j < nd) ? sbeta[j] : make_double2(0., 0.);
+    double v[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n) {
+        cplx pc = first ? make_double2(0., 0.) : accp[i];
+        cplx ac = first ? make_double2(0., 0.) : accap[i];
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+            if (j < nd) {
+                pc = csub(pc, cmul(beta[j], d.ps[j][i]));
+                ac = csub(ac, cmul(beta[j], d.aps[j][i]));
+            }
+        }
+        if (last) {
+            cplx pn = cadd(dir[i], pc);
+            cplx an = cadd(ar[i], ac);
+            p_out[i] = pn;
+            ap_out[i] = an;
+            cplx t = cconj_mul(r[i], an);
+            v[0] += t.x; v[1] += t.y;
+            cplx u = cconj_mul(an, an);
+            v[2] += u.x; v[3] += u.y;
+        } else {
+            accp[i] = pc;
+            accap[i] = ac;
+        }
+    }
+    if (last) {
+        block_sum_bcast<4>(v, lds);
+        if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int dalloc(T **p, size_t count) {
+    hipError_t e = hipMalloc((void **)p, sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", sizeof(T) * count, hipGetErrorString(e));
+        return MGCR_ERR_ALLOC;
+    }
+    return MGCR_OK;
+}
+
+int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n) {
+    MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
+    switch (op->kind) {
+        case OP_CSR:
+            MGCR_CHECK(op->csr.ncol == n, MGCR_ERR_INVALID, "Sparse matrix dimension does not match Field dimension!");
+            return csr_apply(op->csr, x, y, false, make_double2(0., 0.));
+        case OP_DIRAC:
+            MGCR_CHECK(op->base->csr.ncol == n && op->base->csr.nrow == n, MGCR_ERR_INVALID,
+                       "DiracOp needs a square matrix matching the Field dimension");
+            // assertm(k != 0., ...) src/Operator.h:571
+            MGCR_CHECK(op->k.x != 0. || op->k.y != 0., MGCR_ERR_INVALID, "No k value supplied for Dirac Operator!");
+            return csr_apply(op->base->csr, x, y, true, op->k);
+        case OP_BCSR:
+            MGCR_CHECK((int64_t)op->bcsr.nbcol * op->bcsr.bs == n, MGCR_ERR_INVALID,
+                       "Sparse matrix dimension does not match Field dimension!");
+            return bcsr_apply(op->bcsr, x, y);
+        case OP_GCR:
+            return gcr_apply_as_operator(op->gcr, x, y);
+        default:
+            set_error("operator kind %d cannot be applied", (int)op->kind);
+            return MGCR_ERR_UNSUPPORTED;
+    }
+}
+
+static void gcr_free_vectors(GcrState *s) {
+    for (cplx *p : s->ps) hipFree(p);
+    for (cplx *p : s->aps) hipFree(p);
+    s->ps.clear(); s->aps.clear();
+    hipFree(s->r); hipFree(s->ar); hipFree(s->z); hipFree(s->tmp); hipFree(s->accp); hipFree(s->accap);
+    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB);
+    s->r = s->ar = s->z = s->tmp = s->accp = s->accap = nullptr;
+    s->den = nullptr; s->hist = nullptr; s->partsB = nullptr;
+    s->alloc_slots = 0; s->n = 0; s->partsB_dirs = 0; s->hist_cap = 0;
+}
+
+void gcr_state_destroy(GcrState *s) {
+    if (!s) return;
+    if (ctx().ready) hipStreamSynchronize(ctx().stream);
+    gcr_free_vectors(s);
+    hipFree(s->x0); hipFree(s->st); hipFree(s->partsA); hipFree(s->partsR); hipFree(s->partsN);
+    delete s;
+}
+
+int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out) {
+    MGCR_CHECK(p, MGCR_ERR_INVALID, "null GCR parameters");
+    // assertm(param->truncation==0 || param->restart==0, ...) src/GCR.h:165
+    MGCR_CHECK(p->truncation == 0 || p->restart == 0, MGCR_ERR_INVALID, "Do not support concurrent restarting and truncation.");
+    MGCR_CHECK(p->truncation >= 0 && p->restart >= 0 && p->max_iter >= 0, MGCR_ERR_INVALID, "negative GCR parameter");
+    GcrState *s = new GcrState();
+    s->A = A;
+    s->p = *p;
+    s->x0_mode = x0_mode;
+    int rc = dalloc(&s->st, 1);
+    if (rc == MGCR_OK) rc = dalloc(&s->partsA, 4 * RED_MAX_BLOCKS);
+    if (rc == MGCR_OK) rc = dalloc(&s->partsR, RED_MAX_BLOCKS);
+    if (rc == MGCR_OK) rc = dalloc(&s->partsN, RED_MAX_BLOCKS);
+    if (rc != MGCR_OK) { gcr_state_destroy(s); return rc; }
+    *out = s;
+    return MGCR_OK;
+}
+
+int gcr_state_set_operator(GcrState *s, Op *A) {
+    s->A = A;
+    return MGCR_OK;
+}
+
+int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n) {
+    if (s->x0) { hipStreamSynchronize(ctx().stream); hipFree(s->x0); s->x0 = nullptr; }
+    if (!x0) return MGCR_OK;
+    MGCR_TRY(dalloc(&s->x0, (size_t)n));
+    MGCR_TRY(k_copy(s->x0, x0, n));
+    return MGCR_OK;
+}
+
+static int ensure_slot(GcrState *s, int slot) {
+    while ((int)s->ps.size() <= slot) {
+        cplx *a = nullptr, *b = nullptr;
+        MGCR_TRY(dalloc(&a, (size_t)s->n));
+        s->ps.push_back(a);
+        MGCR_TRY(dalloc(&b, (size_t)s->n));
+        s->aps.push_back(b);
+    }
+    return MGCR_OK;
+}
+
+static int gcr_prepare(GcrState *s, int64_t n) {
+    const mgcr_gcr_param &p = s->p;
+    // mode selection, src/GCR.h:171-185
+    int storage = p.max_iter, restart;
+    if (p.truncation != 0) storage = p.truncation;
+    if (p.restart != 0) { restart = p.restart; storage = restart; } else restart = p.max_iter;
+    if (storage < 1) storage = 1;
+    if (restart < 1) restart = 1;
+    bool precond = p.left_precond || p.right_precond;
+    if (s->n != n || s->storage != storage) {
+        if (ctx().ready) hipStreamSynchronize(ctx().stream);
+        gcr_free_vectors(s);
+        s->n = n;
+        s->storage = storage;
+        MGCR_TRY(dalloc(&s->r, (size_t)n));
+        MGCR_TRY(dalloc(&s->ar, (size_t)n));
+        MGCR_TRY(dalloc(&s->den, (size_t)storage));
+        int cap = (p.max_iter > 0 ? p.max_iter : 1) + 1;
+        MGCR_TRY(dalloc(&s->hist, (size_t)cap));
+        s->hist_cap = cap;
+        int bd = storage < ND ? ND : (storage + ND - 1) / ND * ND;
+        MGCR_TRY(dalloc(&s->partsB, (size_t)2 * bd * RED_MAX_BLOCKS));
+        MGCR_HIP(hipMemsetAsync(s->partsB, 0, sizeof(double) * (size_t)2 * bd * RED_MAX_BLOCKS, ctx().stream));
+        s->partsB_dirs = bd;
+    }
+    s->restart = restart;
+    if (precond && !s->tmp) MGCR_TRY(dalloc(&s->tmp, (size_t)n));
+    if (p.flexible && p.right_precond && !s->z) MGCR_TRY(dalloc(&s->z, (size_t)n));
+    if (storage > ND && !s->accp) {
+        MGCR_TRY(dalloc(&s->accp, (size_t)n));
+        MGCR_TRY(dalloc(&s->accap, (size_t)n));
+    }
+    // restart / truncated modes: all slots up front; full mode grows on demand
+    int want = (p.truncation != 0 || p.restart != 0) ? storage : 1;
+    MGCR_TRY(ensure_slot(s, want - 1));
+    return MGCR_OK;
+}
+
+#define KLAUNCH(kernel, grid, ...)                                                                 \
+    do {                                                                                           \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(RED_THREADS), 0, ctx().stream, __VA_ARGS__);   \
+        MGCR_HIP(hipGetLastError());                                                               \
+    } while (0)
+
+struct SkipGuard {
+    const int *prev;
+    explicit SkipGuard(const int *f) : prev(get_apply_skip_flag()) { set_apply_skip_flag(f); }
+    ~SkipGuard() { set_apply_skip_flag(prev); }
+};
+
+int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged) {
+    Context &c = ctx();
+    MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
+    const int64_t n = s->A->dim;
+    MGCR_TRY(gcr_prepare(s, n));
+    const mgcr_gcr_param &p = s->p;
+    const int g = red_grid(n);
+    const bool flex = p.flexible && p.right_precond;
+    const int *inherit = get_apply_skip_flag();  // outer solver's flag: if it is up, this solve is a no-op too
+
+    hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, c.stream, s->st, inherit, p.tol * p.tol);
+    MGCR_HIP(hipGetLastError());
+    SkipGuard guard(&s->st->done);
+
+    // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
+    if (p.use_x0) {
+        MGCR_TRY(op_apply_raw(s->A, x, s->ar, n));
+        KLAUNCH(sub_kernel, g, s->r, rhs, s->ar, n, s->st);
+    } else {
+        MGCR_TRY(k_copy(s->r, rhs, n));
+    }
+    // p = r (or M r); Ap = A p; both go straight into slot 0 (src/GCR.h:190-191,208-211)
+    if (flex) {
+        MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
+        MGCR_TRY(k_copy(s->ps[0], s->z, n));
+    } else {
+        MGCR_TRY(k_copy(s->ps[0], s->r, n));
+    }
+    MGCR_TRY(op_apply_raw(s->A, s->ps[0], s->aps[0], n));
+    if (!flex) {  // literal hooks, src/GCR.h:197-204 (after p and Ap were formed)
+        if (p.right_precond) { MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
+        if (p.left_precond) { MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
+    }
+    KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, s->st);
+    KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, s->st);
+    KLAUNCH(dot2_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, s->partsA, s->st);
+    KLAUNCH(init_kernel, 1, s->st, s->partsN, g, s->partsR, g, s->hist);
+
+    const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
+    int check_every = p.check_every > 0 ? p.check_every : 10;
+    int iter_count = 0, cur = 0, global = 0;
+    bool done = false;
+    while (global < max_it && !done) {
+        global++;
+        iter_count++;
+        // alpha, x, r
+        KLAUNCH(xr_update_kernel, g, (const DevState *)s->st, (const double *)s->partsA, g, (const cplx *)s->ps[cur],
+                (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur);
+        const cplx *dir = s->r;
+        if (flex) {
+            MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
+            dir = s->z;
+        } else if (p.right_precond) {  // src/GCR.h:236-238
+            MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n));
+            std::swap(s->r, s->tmp);
+            dir = s->r;
+            KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, s->st);
+        }
+        MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
+        if (p.left_precond) {                         // src/GCR.h:245-247
+            MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->ar, s->tmp, n));
+            std::swap(s->ar, s->tmp);
+        }
+        const int lim = s->storage < iter_count ? s->storage : iter_count;  // src/GCR.h:251
+        // slot the new direction goes to (src/GCR.h:277-287)
+        int ic_next = iter_count;
+        if (iter_count % s->restart == 0) ic_next = 0;
+        const int nxt = ic_next % s->storage;
+        MGCR_TRY(ensure_slot(s, nxt));
+        const int nchunk = (lim + ND - 1) / ND;
+        for (int ch = 0; ch < nchunk; ch++) {
+            DirPtrs d;
+            int nd = lim - ch * ND < ND ? lim - ch * ND : ND;
+            for (int j = 0; j < ND; j++) {
+                int sl = ch * ND + (j < nd ? j : 0);
+                d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
+            }
+            KLAUNCH(multidot_kernel, g, s->st, (const cplx *)s->ar, d, nd, ch * ND, n, s->partsB, ch == nchunk - 1 ? 1 : 0,
+                    (const double *)s->partsR, g, s->hist, s->hist_cap);
+        }
+        for (int ch = 0; ch < nchunk; ch++) {
+            DirPtrs d;
+            int nd = lim - ch * ND < ND ? lim - ch * ND : ND;
+            for (int j = 0; j < ND; j++) {
+                int sl = ch * ND + (j < nd ? j : 0);
+                d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
+            }
+            KLAUNCH(build_kernel, g, (const DevState *)s->st, (const double *)s->partsB, g, (const cplx *)s->den, d, nd,
+                    ch * ND, ch == 0 ? 1 : 0, ch == nchunk - 1 ? 1 : 0, dir, (const cplx *)s->r, (const cplx *)s->ar,
+                    s->accp, s->accap, s->ps[nxt], s->aps[nxt], n, s->partsA);
+        }
+        iter_count = ic_next;
+        cur = nxt;
+        if (!nested && (global % check_every == 0 || global == max_it)) {
+            MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
+            MGCR_HIP(hipStreamSynchronize(c.stream));
+            const DevState *hs = (const DevState *)c.h_mail;
+            if (hs->done) done = true;
+        }
+    }
+    if (nested) return MGCR_OK;
+
+    MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
+    MGCR_HIP(hipStreamSynchronize(c.stream));
+    DevState hs = *(const DevState *)c.h_mail;
+    int it = hs.iter;
+    if (n_iter) *n_iter = it;
+    if (converged) *converged = (it == p.max_iter) ? 0 : 1;  // src/GCR.h:294-298
+    std::vector<double> hh((size_t)it + 1);
+    MGCR_HIP(hipMemcpy(hh.data(), s->hist, sizeof(double) * ((size_t)it + 1), hipMemcpyDeviceToHost));
+    if (hist)
+        for (int i = 0; i <= it && i < hist_cap; i++) hist[i] = hh[i];
+    if (p.verbose) {  // src/GCR.h:213-216,270-274,293-300
+        for (int i = 0; i <= it; i++) printf("Step %d residual norm = %.10e\n", i, hh[i]);
+        if (it == p.max_iter)
+            printf("GCR did not converge after %d steps! Residual norm = %.10e\n", p.max_iter, hh[it]);
+        else
+            printf("GCR converged after %d steps. Residual norm=%.10e\n", it, hh[it]);
+    }
+    return MGCR_OK;
+}
+
+// x = init_rand(2) in the reference (src/GCR.h:63-68); here the caller-provided x0 or zero
+int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y) {
+    MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
+    const int64_t n = s->A->dim;
+    if (s->x0_mode == 0 && s->x0) MGCR_TRY(k_copy(y, s->x0, n));
+    else MGCR_TRY(k_zero(y, n));
+    return gcr_run(s, f, y, true, nullptr, 0, nullptr, nullptr);
+}
+
+}  // namespace mgcr

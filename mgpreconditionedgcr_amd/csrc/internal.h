@@ -1,0 +1,148 @@
+// Internal declarations of libmgcr_hip.so (gfx950 only; no compatibility layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mgcr.h"
+
+namespace mgcr {
+
+typedef double2 cplx;  // interleaved (re, im), 16 B: one dwordx4 per element per lane
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define MGCR_HIP(call)                                                     \
+    do {                                                                   \
+        hipError_t e__ = (call);                                           \
+        if (e__ != hipSuccess) return mgcr::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+#define MGCR_CHECK(cond, code, ...)        \
+    do {                                   \
+        if (!(cond)) {                     \
+            mgcr::set_error(__VA_ARGS__);  \
+            return (code);                 \
+        }                                  \
+    } while (0)
+#define MGCR_TRY(call)                 \
+    do {                               \
+        int rc__ = (call);             \
+        if (rc__ != MGCR_OK) return rc__; \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// Reductions.  Every reducing kernel runs a grid of at most RED_MAX_BLOCKS blocks of RED_THREADS
+// threads (= 512 x 16 waves: two blocks per CU fill all 32 wave slots of the 256 CUs) and writes
+// one partial per block and scalar into a [nscal][RED_MAX_BLOCKS] slab.  Whoever consumes the
+// scalars (the next kernel of the iteration) folds the slab in a fixed order inside each of its
+// own blocks, so that every block sees bit-identical values, nothing goes through atomics, no
+// extra "finalise" launch is needed and results are reproducible run to run.
+constexpr int RED_THREADS = 1024;
+constexpr int RED_MAX_BLOCKS = 512;
+constexpr int MAX_DIRS = 32;  // max stored directions handled by one multi-dot / build launch
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // pinned host mailbox for small device->host reads (scalars, flags)
+    double *h_mail = nullptr;  // 64 doubles
+    std::recursive_mutex mtx;
+};
+Context &ctx();
+int require_ctx();
+
+struct Vec {
+    int64_t n = 0;
+    cplx *d = nullptr;
+    bool owns = true;
+};
+
+enum OpKind { OP_CSR = 1, OP_DIRAC = 2, OP_BCSR = 3, OP_GCR = 4, OP_MG = 5 };
+
+// ELL slab + CSR tail (int32 indices).
+//   ELL: W = nchunk*L entries per row, L lanes co-operate on a row.
+//        element (row, w) lives at ((w / L) * npad + row) * L + (w % L)  -> for a fixed chunk,
+//        consecutive (row, lane) pairs are consecutive in memory: coalesced 16-B val loads.
+//        L = 1 is the classic column-major ELL, one thread per row, entries in CSR order (so
+//        the per-row sum runs in the reference's order, src/Operator.h:338-341).
+//   tail: rows longer than W keep their remaining entries in CSR (tail_rows lists them).
+struct CsrDev {
+    int64_t nrow = 0, ncol = 0, nnz = 0;
+    int32_t W = 0, L = 1, nchunk = 0;
+    int64_t npad = 0;
+    cplx *ell_val = nullptr;
+    int32_t *ell_col = nullptr;
+    int64_t n_tail_rows = 0, tail_nnz = 0;
+    int32_t *tail_rows = nullptr;   // [n_tail_rows]
+    int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]
+    int32_t *tail_col = nullptr;    // [tail_nnz]
+    cplx *tail_val = nullptr;
+};
+
+struct BcsrDev {
+    int32_t nbrow = 0, nbcol = 0, bs = 0, nblocks = 0;
+    int32_t *browptr = nullptr, *bcol = nullptr;
+    cplx *blocks = nullptr;  // [nblocks][bs][bs] row-major
+};
+
+struct GcrState;
+struct MgState;
+
+struct Op {
+    OpKind kind;
+    int64_t dim = 0, nrow = 0;
+    CsrDev csr;          // OP_CSR
+    Op *base = nullptr;  // OP_DIRAC: borrowed CSR
+    cplx k = {0., 0.};   // OP_DIRAC
+    BcsrDev bcsr;        // OP_BCSR
+    GcrState *gcr = nullptr;  // OP_GCR
+    MgState *mg = nullptr;    // OP_MG
+};
+
+// ---- blas1.hip -------------------------------------------------------------------------------
+int red_grid(int64_t n);
+int k_copy(cplx *dst, const cplx *src, int64_t n);
+int k_zero(cplx *dst, int64_t n);
+int k_set_constant(cplx *dst, cplx c, int64_t n);
+int k_fill_rhs(cplx *dst, int64_t n, uint64_t seed, int64_t offset);
+int k_add_scaled(cplx *out, const cplx *a, cplx alpha, const cplx *b, int64_t n);  // out = a + alpha*b
+int k_scale(cplx *v, cplx alpha, int64_t n);
+// generic reductions into a partial slab, then fold to `out` (device, nscal cplx) by a 1-block kernel
+int k_dot_partials(const cplx *a, const cplx *b, int64_t n, double *parts /*[2][RED_MAX_BLOCKS]*/, int *nblk);
+int k_fold(const double *parts, int nblk, int nscal, double *out_dev);
+
+// ---- spmv.hip --------------------------------------------------------------------------------
+int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *h_col,
+                     const double *h_val_ri, CsrDev *out);
+void csr_free(CsrDev *c);
+// y = A x   or (shift) y = x - k*(A x)
+int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k);
+int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
+                      const double *h_blocks, BcsrDev *out);
+void bcsr_free(BcsrDev *b);
+int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y);
+
+// ---- gcr.hip ---------------------------------------------------------------------------------
+int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n);
+int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out);
+void gcr_state_destroy(GcrState *s);
+int gcr_state_set_operator(GcrState *s, Op *A);
+int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n);
+// runs the solve; `nested` = no host round trips (used when GCR is itself applied as an operator)
+int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter,
+            int *converged);
+int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);
+
+}  // namespace mgcr
+
+struct mgcr_vec_s : mgcr::Vec {};
+struct mgcr_op_s : mgcr::Op {};

@@ -1,0 +1,67 @@
+// Deterministic wave64 / workgroup reductions and complex helpers (device side, gfx950).
+#pragma once
+#include "internal.h"
+
+namespace mgcr {
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    // (a.x + i a.y)(b.x + i b.y), the un-fused order of the reference's std::complex operator*
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cconj_mul(cplx a, cplx b) {
+    // conj(a) * b  (src/Fields.h:222): (a.x - i a.y)(b.x + i b.y)
+    return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+// complex division with libgcc's __divdc3 operation order (Smith), which is what the reference's
+// `alpha = r.dot(Ap) / Ap.dot(Ap)` (src/GCR.h:230,258) lowers to
+__device__ __forceinline__ cplx cdiv(cplx n, cplx d) {
+    double a = n.x, b = n.y, c = d.x, e = d.y;
+    if (fabs(c) < fabs(e)) {
+        double ratio = c / e, denom = (c * ratio) + e;
+        return make_double2(((a * ratio) + b) / denom, ((b * ratio) - a) / denom);
+    } else {
+        double ratio = e / c, denom = (e * ratio) + c;
+        return make_double2(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// Sum NV per-thread doubles over the workgroup in a fixed order (lanes by shuffle tree, waves in
+// index order) and broadcast the totals to every thread.  `lds` needs NV * 17 doubles.
+template <int NV>
+__device__ __forceinline__ void block_sum_bcast(double (&v)[NV], double *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) lds[k * 17 + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.;
+        for (int w = 0; w < nwave; w++) s += lds[threadIdx.x * 17 + w];
+        lds[threadIdx.x * 17 + 16] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = lds[k * 17 + 16];
+    __syncthreads();
+}
+
+// Fold a partial slab parts[k][RED_MAX_BLOCKS] (nblk valid entries per scalar) to NV totals,
+// identically in every workgroup that calls it (blockDim.x must be >= RED_MAX_BLOCKS).
+template <int NV>
+__device__ __forceinline__ void fold_partials(const double *__restrict__ parts, int nblk, double (&v)[NV], double *lds) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = (threadIdx.x < nblk) ? parts[k * RED_MAX_BLOCKS + threadIdx.x] : 0.;
+    block_sum_bcast<NV>(v, lds);
+}
+
+}  // namespace mgcr

@@ -1,0 +1,441 @@
+// Sparse operators on the device: Sparse<long> (CSR -> ELL slab + CSR tail) and
+// HierarchicalSparse<long,int> (block-CSR of dense blocks).
+//
+//   reference: Sparse::operator()            src/Operator.h:330-346
+//              DiracOp::operator()           src/Operator.h:569-575   (fused epilogue y = x - k*sum)
+//              HierarchicalSparse::operator()  src/HierarchicalSparse.h:101-161
+//              Dense::operator()             src/Operator.h:159-173
+//
+// All of it is HBM-bound (8 flop per 20 stored bytes): the kernels are built around coalesced
+// 16-B-per-lane streams of the matrix, L2/MALL-served gathers of x, and wave64 shuffle / LDS
+// reductions.  No MFMA.
+#include <algorithm>
+
+#include "internal.h"
+#include "reduce.h"
+
+namespace mgcr {
+
+// ------------------------------------------------------------------------------------------------
+// set-up: raw CSR (int64, as the reference stores it) -> ELL + tail, on the device
+// ------------------------------------------------------------------------------------------------
+
+// one thread per (row, lane): copies the row's first W entries into the slab, pads the rest with
+// (last valid column, 0) so that padding never touches an x entry the row does not already read
+__global__ void ell_fill_kernel(int64_t nrow, int64_t ncol, const int64_t *__restrict__ rowptr,
+                                const int64_t *__restrict__ col, const cplx *__restrict__ val, int32_t W, int32_t L,
+                                int32_t nchunk, int64_t npad, cplx *__restrict__ ell_val, int32_t *__restrict__ ell_col) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t row = t / L;
+    int32_t l = (int32_t)(t % L);
+    if (row >= npad) return;
+    int64_t beg = 0, len = 0;
+    if (row < nrow) {
+        beg = rowptr[row];
+        len = rowptr[row + 1] - beg;
+    }
+    int64_t take = len < W ? len : W;
+    int32_t padcol = 0;
+    if (take > 0) padcol = (int32_t)col[beg + take - 1];
+    else if (row < ncol) padcol = (int32_t)row;
+    for (int32_t c = 0; c < nchunk; c++) {
+        int32_t w = c * L + l;
+        int64_t dst = ((int64_t)c * npad + row) * L + l;
+        if (w < take) {
+            ell_val[dst] = val[beg + w];
+            ell_col[dst] = (int32_t)col[beg + w];
+        } else {
+            ell_val[dst] = make_double2(0., 0.);
+            ell_col[dst] = padcol;
+        }
+    }
+}
+
+__global__ void tail_fill_kernel(int64_t n_tail_rows, const int32_t *__restrict__ tail_rows,
+                                 const int32_t *__restrict__ tail_ptr, const int64_t *__restrict__ rowptr,
+                                 const int64_t *__restrict__ col, const cplx *__restrict__ val, int32_t W,
+                                 int32_t *__restrict__ tail_col, cplx *__restrict__ tail_val) {
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (wave >= n_tail_rows) return;
+    int64_t row = tail_rows[wave];
+    int64_t src = rowptr[row] + W;
+    int32_t dst = tail_ptr[wave], cnt = tail_ptr[wave + 1] - dst;
+    for (int32_t i = lane; i < cnt; i += 64) {
+        tail_col[dst + i] = (int32_t)col[src + i];
+        tail_val[dst + i] = val[src + i];
+    }
+}
+
+// column range check of the uploaded CSR (bad indices would fault inside the SpMV gather)
+__global__ void col_check_kernel(int64_t nnz, const int64_t *__restrict__ col, int64_t ncol, int *__restrict__ bad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz && (col[i] < 0 || col[i] >= ncol)) *bad = 1;
+}
+
+template <typename T>
+static int dev_upload(T **d, const T *h, size_t count) {
+    *d = nullptr;
+    if (count == 0) return MGCR_OK;
+    hipError_t e = hipMalloc((void **)d, sizeof(T) * count);
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", sizeof(T) * count, hipGetErrorString(e));
+        return MGCR_ERR_ALLOC;
+    }
+    if (h) MGCR_HIP(hipMemcpyAsync(*d, h, sizeof(T) * count, hipMemcpyHostToDevice, ctx().stream));
+    return MGCR_OK;
+}
+
+void csr_free(CsrDev *c) {
+    hipFree(c->ell_val); hipFree(c->ell_col);
+    hipFree(c->tail_rows); hipFree(c->tail_ptr); hipFree(c->tail_col); hipFree(c->tail_val);
+    *c = CsrDev();
+}
+
+// Picks the ELL width that minimises the bytes one SpMV streams, from the row-length histogram.
+static int32_t choose_width(const std::vector<int64_t> &hist, int64_t nrow, int32_t maxlen) {
+    // rows_ge[w] = #rows with len >= w ;  tail_nnz(W) = sum_{w > W} rows_ge[w]
+    std::vector<int64_t> rows_ge(maxlen + 2, 0);
+    for (int32_t w = maxlen; w >= 0; w--) rows_ge[w] = rows_ge[w + 1] + hist[w];
+    std::vector<int64_t> tail(maxlen + 2, 0);
+    for (int32_t w = maxlen - 1; w >= 0; w--) tail[w] = tail[w + 1] + rows_ge[w + 1];
+    int32_t best = maxlen;
+    double best_cost = 1e300;
+    for (int32_t W = 0; W <= maxlen; W++) {
+        // 20 B per stored entry; a tail entry also costs an uncoalesced row visit (~x2) and each
+        // tail row a read-modify-write of y plus bookkeeping (~64 B)
+        double cost = 20. * (double)W * (double)nrow + 40. * (double)tail[W] + 64. * (double)rows_ge[W + 1];
+        if (cost < best_cost) { best_cost = cost; best = W; }
+    }
+    return best;
+}
+
+static int32_t choose_lanes(int64_t nrow, int32_t W) {
+    // one thread per row (entries summed in CSR order, like the reference) whenever that alone
+    // fills the machine; otherwise split rows over 2..16 lanes while padding stays below 10 %
+    if (W <= 8 || nrow >= (int64_t)1 << 18) return 1;
+    int32_t best = 1;
+    for (int32_t L = 2; L <= 16; L *= 2) {
+        int32_t padded = (W + L - 1) / L * L;
+        if ((padded - W) * 10 > W) continue;
+        best = L;
+        if (nrow * L >= (int64_t)1 << 17) break;
+    }
+    return best;
+}
+
+// device CSR (already resident) + host row pointers -> CsrDev
+static int ell_from_device_csr(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *d_rowptr,
+                               const int64_t *d_col, const cplx *d_val, CsrDev *out) {
+    Context &c = ctx();
+    CsrDev A;
+    A.nrow = nrow; A.ncol = ncol; A.nnz = h_rowptr[nrow];
+    int64_t maxlen64 = 0;
+    for (int64_t r = 0; r < nrow; r++) maxlen64 = std::max(maxlen64, h_rowptr[r + 1] - h_rowptr[r]);
+    MGCR_CHECK(maxlen64 < ((int64_t)1 << 30), MGCR_ERR_UNSUPPORTED, "row with %lld entries", (long long)maxlen64);
+    int32_t maxlen = (int32_t)maxlen64;
+    std::vector<int64_t> hist((size_t)maxlen + 2, 0);
+    for (int64_t r = 0; r < nrow; r++) hist[(size_t)(h_rowptr[r + 1] - h_rowptr[r])]++;
+    A.W = choose_width(hist, nrow, maxlen);
+    A.L = choose_lanes(nrow, A.W);
+    A.nchunk = (A.W + A.L - 1) / A.L;
+    A.npad = (nrow + 63) / 64 * 64;
+    // tail lists
+    std::vector<int32_t> trows, tptr(1, 0);
+    for (int64_t r = 0; r < nrow; r++) {
+        int64_t len = h_rowptr[r + 1] - h_rowptr[r];
+        if (len > A.W) {
+            trows.push_back((int32_t)r);
+            int64_t nxt = (int64_t)tptr.back() + (len - A.W);
+            MGCR_CHECK(nxt < ((int64_t)1 << 31), MGCR_ERR_UNSUPPORTED, "CSR tail exceeds 2^31 entries");
+            tptr.push_back((int32_t)nxt);
+        }
+    }
+    A.n_tail_rows = (int64_t)trows.size();
+    A.tail_nnz = tptr.back();
+
+    size_t slab = (size_t)A.nchunk * (size_t)A.npad * (size_t)A.L;
+    if (slab) {
+        hipError_t e1 = hipMalloc((void **)&A.ell_val, sizeof(cplx) * slab);
+        hipError_t e2 = hipMalloc((void **)&A.ell_col, sizeof(int32_t) * slab);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            csr_free(&A);
+            set_error("hipMalloc of the ELL slab (%zu entries) failed", slab);
+            return MGCR_ERR_ALLOC;
+        }
+        int64_t threads = A.npad * A.L;
+        hipLaunchKernelGGL(ell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, nrow, ncol,
+                           d_rowptr, d_col, d_val, A.W, A.L, A.nchunk, A.npad, A.ell_val, A.ell_col);
+        MGCR_HIP(hipGetLastError());
+    }
+    if (A.n_tail_rows) {
+        MGCR_TRY(dev_upload(&A.tail_rows, trows.data(), trows.size()));
+        MGCR_TRY(dev_upload(&A.tail_ptr, tptr.data(), tptr.size()));
+        MGCR_TRY(dev_upload<int32_t>(&A.tail_col, nullptr, (size_t)A.tail_nnz));
+        MGCR_TRY(dev_upload<cplx>(&A.tail_val, nullptr, (size_t)A.tail_nnz));
+        int64_t threads = A.n_tail_rows * 64;
+        hipLaunchKernelGGL(tail_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream,
+                           A.n_tail_rows, A.tail_rows, A.tail_ptr, d_rowptr, d_col, d_val, A.W, A.tail_col, A.tail_val);
+        MGCR_HIP(hipGetLastError());
+    }
+    MGCR_HIP(hipStreamSynchronize(c.stream));  // trows/tptr go out of scope
+    *out = A;
+    return MGCR_OK;
+}
+
+int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *h_col, const double *h_val_ri,
+                     CsrDev *out) {
+    Context &c = ctx();
+    MGCR_CHECK(nrow >= 0 && ncol >= 0 && nrow < ((int64_t)1 << 31) && ncol < ((int64_t)1 << 31), MGCR_ERR_UNSUPPORTED,
+               "matrix dimensions must fit int32 per GPU (got %lld x %lld)", (long long)nrow, (long long)ncol);
+    MGCR_CHECK(h_rowptr[0] == 0, MGCR_ERR_INVALID, "rowptr[0] must be 0");
+    for (int64_t r = 0; r < nrow; r++)
+        MGCR_CHECK(h_rowptr[r + 1] >= h_rowptr[r], MGCR_ERR_INVALID, "rowptr is not non-decreasing at row %lld", (long long)r);
+    int64_t nnz = h_rowptr[nrow];
+    int64_t *d_rowptr = nullptr, *d_col = nullptr;
+    cplx *d_val = nullptr;
+    int *d_bad = nullptr;
+    int rc = dev_upload(&d_rowptr, h_rowptr, (size_t)nrow + 1);
+    if (rc == MGCR_OK) rc = dev_upload(&d_col, h_col, (size_t)nnz);
+    if (rc == MGCR_OK) rc = dev_upload(&d_val, (const cplx *)h_val_ri, (size_t)nnz);
+    int bad = 0;
+    if (rc == MGCR_OK && nnz > 0) {
+        rc = dev_upload(&d_bad, &bad, 1);
+        if (rc == MGCR_OK) {
+            hipLaunchKernelGGL(col_check_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c.stream, nnz, d_col, ncol, d_bad);
+            hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c.stream);
+            hipStreamSynchronize(c.stream);
+            if (bad) { set_error("mgcr_csr_create: a column index is outside [0, ncol)"); rc = MGCR_ERR_INVALID; }
+        }
+    }
+    if (rc == MGCR_OK) rc = ell_from_device_csr(nrow, ncol, h_rowptr, d_rowptr, d_col, d_val, out);
+    hipStreamSynchronize(c.stream);
+    hipFree(d_rowptr); hipFree(d_col); hipFree(d_val); hipFree(d_bad);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMV
+// ------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give each XCD
+// one contiguous band of rows, so that the x entries a stencil-like matrix re-reads (row +-1,
+// +-n, +-n^2) stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
+__device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
+    int64_t b = blockIdx.x;
+    int64_t per = (ntiles + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+// L = 1: one thread per row, entries in CSR order (bit-identical to the reference's row sum)
+template <int WT, bool SHIFT, bool XCD>
+__global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t nrow, int64_t npad, int32_t Wrt, int64_t ntiles,
+                                                          const cplx *__restrict__ val, const int32_t *__restrict__ col,
+                                                          const cplx *__restrict__ x, cplx *__restrict__ y, cplx k,
+                                                          const int *__restrict__ skip) {
+    if (skip && *skip) return;
+    int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
+    if (tile >= ntiles) return;
+    int64_t row = tile * 256 + threadIdx.x;
+    if (row >= nrow) return;
+    const int32_t W = WT ? WT : Wrt;
+    cplx sum = make_double2(0., 0.);
+    if (WT) {
+        cplx v[WT ? WT : 1];
+        int32_t j[WT ? WT : 1];
+#pragma unroll
+        for (int32_t c = 0; c < W; c++) {
+            v[c] = val[(int64_t)c * npad + row];
+            j[c] = col[(int64_t)c * npad + row];
+        }
+#pragma unroll
+        for (int32_t c = 0; c < W; c++) sum = cadd(sum, cmul(v[c], x[j[c]]));
+    } else {
+#pragma unroll 4
+        for (int32_t c = 0; c < W; c++) {
+            cplx v = val[(int64_t)c * npad + row];
+            int32_t j = col[(int64_t)c * npad + row];
+            sum = cadd(sum, cmul(v, x[j]));
+        }
+    }
+    y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
+}
+
+// L in {2,4,8,16}: L consecutive lanes share a row; per chunk the (row, lane) pairs are contiguous
+template <int L, bool SHIFT>
+__global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t nrow, int64_t npad, int32_t nchunk,
+                                                      const cplx *__restrict__ val, const int32_t *__restrict__ col,
+                                                      const cplx *__restrict__ x, cplx *__restrict__ y, cplx k,
+                                                      const int *__restrict__ skip) {
+    if (skip && *skip) return;
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t row = t / L;
+    int l = (int)(t % L);
+    cplx sum = make_double2(0., 0.);
+    if (row < nrow) {
+#pragma unroll 4
+        for (int32_t c = 0; c < nchunk; c++) {
+            int64_t idx = ((int64_t)c * npad + row) * L + l;
+            sum = cadd(sum, cmul(val[idx], x[col[idx]]));
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off >= 1; off >>= 1) {
+        sum.x += __shfl_down(sum.x, off, L);
+        sum.y += __shfl_down(sum.y, off, L);
+    }
+    if (row < nrow && l == 0) y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
+}
+
+// CSR tail: one wave per long row, lanes stride the remaining entries, wave64 shuffle reduction
+template <bool SHIFT>
+__global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, const int32_t *__restrict__ tail_rows,
+                                                       const int32_t *__restrict__ tail_ptr,
+                                                       const int32_t *__restrict__ tail_col,
+                                                       const cplx *__restrict__ tail_val, const cplx *__restrict__ x,
+                                                       cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
+    if (skip && *skip) return;
+    int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (wave >= n_tail_rows) return;
+    int32_t beg = tail_ptr[wave], end = tail_ptr[wave + 1];
+    cplx sum = make_double2(0., 0.);
+    for (int32_t i = beg + lane; i < end; i += 64) sum = cadd(sum, cmul(tail_val[i], x[tail_col[i]]));
+    sum.x = wave_sum(sum.x);
+    sum.y = wave_sum(sum.y);
+    if (lane == 0) {
+        int32_t row = tail_rows[wave];
+        y[row] = SHIFT ? csub(y[row], cmul(k, sum)) : cadd(y[row], sum);
+    }
+}
+
+static const int *g_skip_flag = nullptr;  // device flag consulted by apply kernels (set by the GCR driver)
+void set_apply_skip_flag(const int *flag) { g_skip_flag = flag; }
+const int *get_apply_skip_flag() { return g_skip_flag; }
+
+template <bool SHIFT>
+static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k) {
+    Context &c = ctx();
+    if (A.nrow == 0) return MGCR_OK;
+    if (A.L == 1) {
+        int64_t ntiles = (A.nrow + 255) / 256;
+        bool xcd = ntiles >= 64;
+        unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
+#define RT(WT, X)                                                                                                    \
+    hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X>), dim3(grid), dim3(256), 0, c.stream, A.nrow, A.npad, A.W, \
+                       ntiles, A.ell_val, A.ell_col, x, y, k, g_skip_flag)
+        if (A.W == 7) { if (xcd) RT(7, true); else RT(7, false); }
+        else { if (xcd) RT(0, true); else RT(0, false); }
+#undef RT
+    } else {
+        int64_t threads = A.nrow * A.L;
+        unsigned grid = (unsigned)((threads + 255) / 256);
+#define LN(LL)                                                                                                     \
+    hipLaunchKernelGGL((ell_spmv_lanes<LL, SHIFT>), dim3(grid), dim3(256), 0, c.stream, A.nrow, A.npad, A.nchunk, \
+                       A.ell_val, A.ell_col, x, y, k, g_skip_flag)
+        switch (A.L) {
+            case 2: LN(2); break;
+            case 4: LN(4); break;
+            case 8: LN(8); break;
+            default: LN(16); break;
+        }
+#undef LN
+    }
+    MGCR_HIP(hipGetLastError());
+    if (A.n_tail_rows) {
+        int64_t threads = A.n_tail_rows * 64;
+        hipLaunchKernelGGL((csr_tail_kernel<SHIFT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream,
+                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, y, k, g_skip_flag);
+        MGCR_HIP(hipGetLastError());
+    }
+    return MGCR_OK;
+}
+
+int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k) {
+    MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
+    return shift ? csr_apply_t<true>(A, x, y, k) : csr_apply_t<false>(A, x, y, k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-CSR of dense bs x bs blocks (HierarchicalSparse).  One wave per block-row.  Per block the
+// wave streams the bs*bs entries with coalesced 16-B loads, stages the products m[r][c]*x[c] in
+// LDS, and lanes r < bs then add their row's products in column order — the order of
+// Dense::operator() (src/Operator.h:165-170) — onto the block-row accumulator
+// (value += ..., src/HierarchicalSparse.h:144).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
+                                                       const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
+                                                       const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                       const int *__restrict__ skip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
+    if (skip && *skip) return;
+    const int32_t brow = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int32_t bs2 = bs * bs, ld = bs + 1;
+    const int32_t beg = browptr[brow], end = browptr[brow + 1];
+    // rows of a block owned by this lane: r = lane, lane+64 (bs <= 128)
+    cplx acc0 = make_double2(0., 0.), acc1 = make_double2(0., 0.);
+    for (int32_t l = beg; l < end; l++) {
+        const cplx *m = blocks + (int64_t)l * bs2;
+        const cplx *xb = x + (int64_t)bcol[l] * bs;
+        for (int32_t e = lane; e < bs2; e += 64) {
+            int32_t r = e / bs, cc = e - r * bs;
+            prod[r * ld + cc] = cmul(m[e], xb[cc]);
+        }
+        __syncthreads();
+        if (lane < bs) {
+            cplx o = make_double2(0., 0.);
+            for (int32_t cc = 0; cc < bs; cc++) o = cadd(o, prod[lane * ld + cc]);
+            acc0 = cadd(acc0, o);
+        }
+        if (lane + 64 < bs) {
+            cplx o = make_double2(0., 0.);
+            for (int32_t cc = 0; cc < bs; cc++) o = cadd(o, prod[(lane + 64) * ld + cc]);
+            acc1 = cadd(acc1, o);
+        }
+        __syncthreads();
+    }
+    if (lane < bs) y[(int64_t)brow * bs + lane] = acc0;
+    if (lane + 64 < bs) y[(int64_t)brow * bs + lane + 64] = acc1;
+}
+
+void bcsr_free(BcsrDev *b) {
+    hipFree(b->browptr); hipFree(b->bcol); hipFree(b->blocks);
+    *b = BcsrDev();
+}
+
+int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
+                      const double *h_blocks, BcsrDev *out) {
+    MGCR_CHECK(nbrow >= 0 && nbcol >= 0 && bs >= 1 && bs <= 128, MGCR_ERR_UNSUPPORTED,
+               "block-CSR: block size must be in [1,128] (got %d)", bs);
+    MGCR_CHECK(h_browptr[0] == 0, MGCR_ERR_INVALID, "browptr[0] must be 0");
+    for (int32_t r = 0; r < nbrow; r++) MGCR_CHECK(h_browptr[r + 1] >= h_browptr[r], MGCR_ERR_INVALID, "browptr not monotone");
+    int32_t nb = h_browptr[nbrow];
+    for (int32_t i = 0; i < nb; i++) MGCR_CHECK(h_bcol[i] >= 0 && h_bcol[i] < nbcol, MGCR_ERR_INVALID, "block column out of range");
+    BcsrDev B;
+    B.nbrow = nbrow; B.nbcol = nbcol; B.bs = bs; B.nblocks = nb;
+    MGCR_TRY(dev_upload(&B.browptr, h_browptr, (size_t)nbrow + 1));
+    MGCR_TRY(dev_upload(&B.bcol, h_bcol, (size_t)nb));
+    MGCR_TRY(dev_upload(&B.blocks, (const cplx *)h_blocks, (size_t)nb * bs * bs));
+    MGCR_HIP(hipStreamSynchronize(ctx().stream));
+    *out = B;
+    return MGCR_OK;
+}
+
+int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y) {
+    MGCR_CHECK(x != y, MGCR_ERR_INVALID, "block SpMV cannot run in place");
+    if (A.nbrow == 0) return MGCR_OK;
+    size_t lds = sizeof(cplx) * (size_t)A.bs * (size_t)(A.bs + 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MGCR_HIP(hipFuncSetAttribute((const void *)bcsr_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    MGCR_CHECK(lds <= 160 * 1024, MGCR_ERR_UNSUPPORTED, "block size %d needs more than 160 KiB of LDS", A.bs);
+    hipLaunchKernelGGL(bcsr_wave_kernel, dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr,
+                       A.bcol, A.blocks, x, y, g_skip_flag);
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
+}  // namespace mgcr

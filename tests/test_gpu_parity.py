@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors of the real
+reference, against the CPU oracle on seeded inputs, and through size-independent properties at
+the full BASELINE sizes.  Tolerances (stated here):
+
+  * SpMV / element-wise Field algebra: component-wise |diff| <= 1e-13 * row scale (the kernels
+    keep the reference's operation order; only multi-lane rows re-associate);
+  * dots / norms: relative 1e-12 (reduction order differs from the reference's sequential sum);
+  * GCR residual history: per step relative 1e-9 while the reference value is >= 1e-9, 1e-6
+    below; iterations to convergence within +-1.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+mg = pytest.importorskip("mgpreconditionedgcr_amd")
+from mgpreconditionedgcr_amd import (DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MgcrError,  # noqa: E402
+                                     Sparse, problems, read_data)
+from oracle import oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    mg.init()  # raises loudly when no GPU / no library: there is no fallback
+    yield
+
+
+def hist_close(h, ref, what=""):
+    n = min(h.size, ref.size)
+    for k in range(1, n):
+        tol = 1e-9 if ref[k] >= 1e-9 else 1e-6
+        assert abs(h[k] - ref[k]) <= tol * ref[k], "%s step %d: %.12e vs ref %.12e" % (what, k, h[k], ref[k])
+
+
+@pytest.fixture(scope="module")
+def sample(sample_matrix_path):
+    import os
+    D = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path))
+    return D
+
+
+DIMS = (4, 4, 4, 4, 4, 3)
+
+
+def test_read_data_and_layout(sample):
+    assert sample.get_dim() == 3072 and sample.get_nrow() == 3072 and sample.get_nnz() == 119808
+    sb = sample.stored_bytes()
+    assert sb["tail_nnz"] == 0 and 39 <= sb["ell_width"] <= 40  # perfectly regular: 39 nnz / row
+
+
+def test_g1_spmv(sample, sample_gold):
+    g = sample_gold
+    x = Field(DIMS, g["g1_x"])
+    y = sample(x).to_numpy()
+    scale = np.abs(g["g1_Dx"]).max()
+    assert np.abs(y - g["g1_Dx"]).max() <= 1e-13 * scale
+    dirac = DiracOp(sample, 0.15)
+    y = dirac(x).to_numpy()
+    assert np.abs(y - g["g1_dirac_x"]).max() <= 1e-13 * np.abs(g["g1_dirac_x"]).max()
+
+
+def test_g2_blas1(sample_gold):
+    g = sample_gold
+    a, b = Field(DIMS, g["g2_a"]), Field(DIMS, g["g2_b"])
+    dot_ab, norms, alpha = g["g2_scalars"]
+    assert abs(a.dot(b) - dot_ab) <= 1e-12 * abs(dot_ab)
+    assert abs(a.squarednorm() - norms.real) <= 1e-12 * norms.real
+    assert abs(b.squarednorm() - norms.imag) <= 1e-12 * norms.imag
+    # element-wise: same operation order and no FMA contraction => identical bits
+    assert np.array_equal(a.add_scaled(alpha, b).to_numpy(), g["g2_a_plus_alpha_b"])
+    assert np.array_equal(a.add_scaled(-alpha, b).to_numpy(), g["g2_a_minus_alpha_b"])
+    c = a.copy()
+    c += b
+    assert np.array_equal(c.to_numpy(), g["g2_a"] + g["g2_b"])
+
+
+GCR_CASES = [
+    ("g3_restart5", dict(re=5, max_it=4000, tau=1e-13), 118),
+    ("g4_restart2", dict(re=2, max_it=4000, tau=1e-13), 116),
+    ("g5_trunc8", dict(trunc=8, max_it=300, tau=1e-3), 46),
+    ("g10_maxiter0", dict(re=10, max_it=0, tau=1e-8), 1),
+]
+
+
+@pytest.mark.parametrize("tag,kw,iters", GCR_CASES)
+def test_gcr_history_vs_reference(sample, sample_gold, tag, kw, iters):
+    g = sample_gold
+    dirac = DiracOp(sample, 0.15)
+    rhs = Field(DIMS, g["gcr_rhs"])
+    x = Field(DIMS).set_zero()
+    gcr = GCR(dirac, GCR_Param(verb=False, **kw))
+    gcr.solve(rhs, x)
+    assert abs(gcr.last_iterations - iters) <= 1
+    hist_close(gcr.last_history, g[tag + "_hist"], tag)
+    xr = g[tag + "_x"]
+    if gcr.last_iterations == iters:
+        assert np.abs(x.to_numpy() - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+def test_gcr_full_mode_prefix(sample, sample_gold):
+    """Full GCR (no restart, no truncation) stalls on the non-Hermitian sample because of the
+    reference's conjugation order and amplifies rounding; pin 60 steps."""
+    g = sample_gold
+    dirac = DiracOp(sample, 0.15)
+    gcr = GCR(dirac, GCR_Param(0, 0, 60, 1e-13, False))
+    x = Field(DIMS).set_zero()
+    gcr.solve(Field(DIMS, g["gcr_rhs"]), x)
+    assert gcr.last_iterations == 60 and not gcr.last_converged
+    hist_close(gcr.last_history, g["g6_full_hist"][:61], "full")
+
+
+def test_gcr_check_every_does_not_change_results(sample, sample_gold):
+    g = sample_gold
+    dirac = DiracOp(sample, 0.15)
+    rhs = Field(DIMS, g["gcr_rhs"])
+    res = []
+    for ce in (1, 7, 50):
+        x = Field(DIMS).set_zero()
+        gcr = GCR(dirac, GCR_Param(0, 5, 4000, 1e-13, False, check_every=ce))
+        gcr.solve(rhs, x)
+        res.append((gcr.last_iterations, gcr.last_history.copy(), x.to_numpy()))
+    for r in res[1:]:
+        assert r[0] == res[0][0] and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+
+
+def test_gcr_complex_k_and_x0_quirk(sample, sample_gold):
+    g = sample_gold
+    rhs = Field(DIMS, g["gcr_rhs"])
+    x = Field(DIMS).set_zero()
+    gcr = GCR(DiracOp(sample, 0.12 + 0.05j), GCR_Param(0, 5, 40, 1e-13, False))
+    gcr.solve(rhs, x)
+    hist_close(gcr.last_history, g["g3b_complexk_hist"], "complex k")
+    # r0 = b whatever x0 is (src/GCR.h:189): history independent of x0, x_final = x0 + x(zero start)
+    dirac = DiracOp(sample, 0.15)
+    x0 = problems.rhs_grid(3072, 11)
+    xa, xb = Field(DIMS, x0), Field(DIMS).set_zero()
+    ga, gb = GCR(dirac, GCR_Param(0, 5, 20, 1e-13, False)), GCR(dirac, GCR_Param(0, 5, 20, 1e-13, False))
+    ga.solve(rhs, xa)
+    gb.solve(rhs, xb)
+    assert np.array_equal(ga.last_history, gb.last_history)
+    hist_close(ga.last_history, g["g10_x0rand_hist"], "x0 quirk")
+    assert np.abs(xa.to_numpy() - x0 - xb.to_numpy()).max() <= 1e-12
+
+
+def test_precond_hooks_literal(sample, sample_gold):
+    """r = M(r) / Ar = Ml(Ar) literal hooks (src/GCR.h:197-204,236-247) with M = 1 + kD."""
+    g = sample_gold
+    dirac = DiracOp(sample, 0.15)
+    M = DiracOp(sample, -0.15)
+    rhs = Field(DIMS, g["gcr_rhs"])
+    x = Field(DIMS).set_zero()
+    gcr = GCR(dirac, GCR_Param(0, 5, 20, 1e-13, False, None, M))
+    gcr.solve(rhs, x)
+    # this (reference-literal) right-preconditioned recurrence diverges: compare loosely in the tail
+    ref = g["g11_right_neumann_hist"]
+    assert np.allclose(gcr.last_history[1:], ref[1:], rtol=1e-8)
+    x = Field(DIMS).set_zero()
+    gcr = GCR(dirac, GCR_Param(0, 5, 60, 1e-13, False, M, None))
+    gcr.solve(rhs, x)
+    hist_close(gcr.last_history, g["g11_left_neumann_hist"], "left precond")
+
+
+def test_poisson_goldens(poisson_gold):
+    g = poisson_gold
+    for n, kw, tag in [(32, dict(re=5, max_it=10, tau=1e-13), "p32"),
+                       (8, dict(trunc=4, max_it=300, tau=1e-10), "p8_trunc4"),
+                       (8, dict(max_it=25, tau=1e-10), "p8_full"),
+                       (16, dict(re=3, max_it=300, tau=1e-12), "p16_restart3")]:
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        A = Sparse(N, ncol, rowptr, col, val)
+        assert A.stored_bytes()["ell_width"] == 7
+        rhs = Field((n, n, n)).fill_rhs(0)
+        assert np.array_equal(rhs.to_numpy(), problems.rhs_grid(N, 0))
+        x = Field((n, n, n)).set_zero()
+        gcr = GCR(A, GCR_Param(verb=False, **kw))
+        gcr.solve(rhs, x)
+        ref = g[tag + "_hist"]
+        assert abs(gcr.last_iterations - (ref.size - 1)) <= 1
+        hist_close(gcr.last_history, ref, tag)
+        if tag + "_x" in g and gcr.last_iterations == ref.size - 1:
+            assert np.abs(x.to_numpy() - g[tag + "_x"]).max() <= 1e-8 * np.abs(g[tag + "_x"]).max()
+
+
+def test_poisson128_first_steps_vs_reference(poisson_gold):
+    """BASELINE config 2 matrix: first 10 steps against the real reference run on the same RHS."""
+    n = 128
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    rhs = Field((n, n, n)).fill_rhs(0)
+    x = Field((n, n, n)).set_zero()
+    gcr = GCR(A, GCR_Param(0, 5, 10, 1e-13, False))
+    gcr.solve(rhs, x)
+    hist_close(gcr.last_history, poisson_gold["p128_hist"], "poisson128")
+    # size-independent property: the recurrence residual equals the true residual b - A x
+    r = rhs - A(x)
+    assert abs(r.norm() / rhs.norm() - gcr.last_history[-1]) <= 1e-10 * gcr.last_history[-1]
+
+
+def test_g8_hsparse(hsparse_gold):
+    g = hsparse_gold
+    nb, bs = int(g["nb"]), int(g["bs"])
+    H = HierarchicalSparse(nb, nb, g["rows"], g["cols"], g["blocks"])
+    assert H.get_dim() == nb * bs
+    y = H(Field((nb * bs,), g["x"])).to_numpy()
+    assert np.abs(y - g["y"]).max() <= 1e-13 * np.abs(g["y"]).max()
+
+
+@pytest.mark.parametrize("bs,nb", [(1, 50), (3, 40), (20, 64), (33, 10), (64, 5), (70, 3)])
+def test_block_csr_vs_oracle(bs, nb):
+    rng = np.random.default_rng(bs * 100 + nb)
+    rows, cols = [], []
+    for r in range(nb):
+        k = int(rng.integers(1, min(nb, 9) + 1))
+        cs = rng.choice(nb, size=k, replace=True)  # duplicates allowed (kept and summed at apply time)
+        rows += [r] * k
+        cols += list(cs)
+    perm = rng.permutation(len(rows))
+    rows, cols = np.array(rows, np.int32)[perm], np.array(cols, np.int32)[perm]
+    blocks = rng.uniform(-1, 1, (rows.size, bs, bs)) + 1j * rng.uniform(-1, 1, (rows.size, bs, bs))
+    x = problems.rhs_grid(nb * bs, 5)
+    H = HierarchicalSparse(nb, nb, rows, cols, blocks)
+    ref = orc.bcsr_from_triplets(nb, nb, bs, rows, cols, blocks)(x)
+    y = H(Field((nb * bs,), x)).to_numpy()
+    # same stable sort and same per-row / per-block order as the oracle => identical bits
+    assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("nrow,ncol,kw", [
+    (1, 1, dict(min_len=1, max_len=1)),
+    (257, 300, dict(min_len=0, max_len=9)),             # empty rows, ragged
+    (5000, 5000, dict(min_len=1, max_len=7)),
+    (3000, 2500, dict(min_len=0, max_len=6, long_rows=5, long_len=900)),   # CSR tail
+    (700, 700, dict(min_len=30, max_len=45)),           # multi-lane rows
+    (64, 4096, dict(min_len=1000, max_len=1500)),       # everything long
+])
+def test_spmv_vs_oracle_irregular(nrow, ncol, kw):
+    rng = np.random.default_rng(nrow * 7 + ncol)
+    rowptr, col, val = problems.random_csr(nrow, ncol, rng, **kw)
+    x = problems.rhs_grid(ncol, 3)
+    ref = orc.csr(nrow, ncol, rowptr, col, val)(x)
+    A = Sparse(nrow, ncol, rowptr, col, val)
+    y = A(Field((ncol,), x)).to_numpy()
+    scale = max(np.abs(ref).max(), 1.0)
+    assert np.abs(y - ref).max() <= 1e-13 * scale * max(1, kw.get("max_len", 1) // 8)
+    if nrow == ncol:
+        k = 0.3 - 0.2j
+        refd = orc.dirac(orc.csr(nrow, ncol, rowptr, col, val), k)(x)
+        yd = DiracOp(A, k)(Field((ncol,), x)).to_numpy()
+        assert np.abs(yd - refd).max() <= 1e-13 * max(np.abs(refd).max(), 1.0) * max(1, kw.get("max_len", 1) // 8)
+
+
+def test_spmv_bit_exact_when_one_thread_per_row():
+    """L = 1 layout keeps the reference's per-row summation order (src/Operator.h:338-341)."""
+    n = 24
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    val = val * (1.0 + 0.25j)
+    x = problems.rhs_grid(N, 9)
+    ref = orc.csr(N, ncol, rowptr, col, val)(x)
+    y = Sparse(N, ncol, rowptr, col, val)(Field((n, n, n), x)).to_numpy()
+    assert np.array_equal(y, ref)
+
+
+def test_gcr_vs_oracle_random_nonhermitian():
+    """Seeded diagonally dominant complex matrix, every mode, against the CPU oracle."""
+    rng = np.random.default_rng(42)
+    n = 4000
+    rowptr, col, val = problems.random_csr(n, n, rng, min_len=3, max_len=10)
+    # make it diagonally dominant: add a diagonal entry larger than the row sum
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    rowsum = np.bincount(rows, weights=np.abs(val), minlength=n)
+    newptr = rowptr + np.arange(n + 1)
+    ncol_arr, nval = np.empty(newptr[-1], np.int64), np.empty(newptr[-1], np.complex128)
+    for r in range(n):
+        s, e = rowptr[r], rowptr[r + 1]
+        ncol_arr[newptr[r]:newptr[r] + (e - s)] = col[s:e]
+        nval[newptr[r]:newptr[r] + (e - s)] = val[s:e]
+        ncol_arr[newptr[r + 1] - 1] = r
+        nval[newptr[r + 1] - 1] = 2.0 * rowsum[r] + 1.0
+    b = problems.rhs_grid(n, 1)
+    Ao = orc.csr(n, n, newptr, ncol_arr, nval)
+    A = Sparse(n, n, newptr, ncol_arr, nval)
+    for kw_o, kw_g in [(dict(restart=4, max_iter=200, tol=1e-11), dict(re=4, max_it=200, tau=1e-11)),
+                       (dict(truncation=3, max_iter=200, tol=1e-11), dict(trunc=3, max_it=200, tau=1e-11)),
+                       (dict(truncation=11, max_iter=200, tol=1e-11), dict(trunc=11, max_it=200, tau=1e-11)),
+                       (dict(max_iter=30, tol=1e-11), dict(max_it=30, tau=1e-11))]:
+        xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(**kw_o), b)
+        x = Field((n,)).set_zero()
+        gcr = GCR(A, GCR_Param(verb=False, **kw_g))
+        gcr.solve(Field((n,), b), x)
+        assert abs(gcr.last_iterations - ito) <= 1, (kw_g, gcr.last_iterations, ito)
+        hist_close(gcr.last_history, ho, str(kw_g))
+        if gcr.last_iterations == ito:
+            assert np.abs(x.to_numpy() - xo).max() <= 1e-9 * np.abs(xo).max()
+
+
+def test_gcr_as_operator_and_flexible_precond():
+    """GCR used as an Operator (src/GCR.h:62-68) with x0 = 0, nested as a flexible right
+    preconditioner — against the same construction in the oracle."""
+    n = 12
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    b = problems.rhs_grid(N, 2)
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    inner_o = orc.gcr_op(Ao, orc.gcr_param(restart=4, max_iter=4, tol=1e-30), x0_mode=1)
+    xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=60, tol=1e-10, right=inner_o, flexible=True), b)
+    A = Sparse(N, ncol, rowptr, col, val)
+    inner = GCR(A, GCR_Param(0, 4, 4, 1e-30, False))
+    y = inner(Field((n, n, n), b)).to_numpy()
+    assert np.abs(y - inner_o(b)).max() <= 1e-12 * np.abs(y).max()
+    outer = GCR(A, GCR_Param(0, 5, 60, 1e-10, False, None, inner, flexible=True))
+    x = Field((n, n, n)).set_zero()
+    outer.solve(Field((n, n, n), b), x)
+    assert abs(outer.last_iterations - ito) <= 1 and outer.last_converged
+    hist_close(outer.last_history, ho, "flexible")
+    assert outer.last_iterations < 30  # the preconditioner helps
+    r = Field((n, n, n), b) - A(x)
+    assert r.norm() / np.linalg.norm(b) <= 2e-10
+
+
+def test_use_x0_extension():
+    n = 10
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    b, x0 = problems.rhs_grid(N, 2), problems.rhs_grid(N, 8)
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=100, tol=1e-10, use_x0=True), b, x0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    x = Field((n, n, n), x0)
+    gcr = GCR(A, GCR_Param(0, 5, 100, 1e-10, False, use_x0=True))
+    gcr.solve(Field((n, n, n), b), x)
+    assert abs(gcr.last_iterations - ito) <= 1
+    hist_close(gcr.last_history, ho, "use_x0")
+    assert np.abs(x.to_numpy() - xo).max() <= 1e-8 * np.abs(xo).max()
+
+
+def test_linearity_and_row_sums_full_size():
+    """Size-independent checks at BASELINE config 3's matrix size (256^3, 117 M nnz)."""
+    n = 256
+    slabs = []
+    # build on the host slab by slab to bound memory, then one CSR
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    ones = Field((n, n, n)).set_constant(1.0)
+    y = A(ones).to_numpy().reshape(n, n, n)
+    # row sum = 6 - (#in-range neighbours): 0 in the interior, 1 per missing neighbour
+    idx = np.arange(n)
+    edge = ((idx == 0) | (idx == n - 1)).astype(np.float64)
+    expect = edge[:, None, None] + edge[None, :, None] + edge[None, None, :]
+    assert np.array_equal(y.real, expect) and not y.imag.any()
+    del y, slabs
+    a, b = Field((n, n, n)).fill_rhs(1), Field((n, n, n)).fill_rhs(2)
+    alpha = 0.5 - 0.25j  # exactly representable: A(a + alpha b) == A a + alpha A b up to rounding
+    lhs = A(a.add_scaled(alpha, b))
+    rhs = A(a).add_scaled(alpha, A(b))
+    d = lhs - rhs
+    assert d.norm() <= 1e-14 * lhs.norm()
+
+
+def test_error_paths(sample):
+    with pytest.raises(MgcrError):
+        sample(Field((10,)))  # Sparse matrix dimension does not match Field dimension!
+    with pytest.raises(MgcrError):
+        Field((4,)).assign(Field((5,)))  # Dimension mismatch.
+    with pytest.raises(MgcrError):
+        GCR(sample, GCR_Param(3, 3, 10, 1e-8, False))  # Do not support concurrent restarting and truncation.
+    with pytest.raises(MgcrError):
+        Sparse(2, 2, [0, 1, 2], [0, 5], [1.0, 1.0])  # column out of range
