@@ -29,17 +29,38 @@ typedef double _Complex cplx;
 
 /* ------------------------------------------------------------------ Field algebra -------- */
 
+/* Summation order of the two reductions below.  0 (default) = the reference's: sequential in
+ * index order.  1 = reverse index order, 2 = pairwise tree: equally valid orders, used by the
+ * tests ONLY to measure how sensitive a residual history is to re-association, which is the one
+ * thing a parallel reduction cannot reproduce. */
+static int g_sum_order = 0;
+void orc_set_sum_order(int mode) { g_sum_order = mode; }
+
+static cplx dot_pairwise(int64_t n, const cplx *a, const cplx *b) {
+    if (n <= 8) {
+        cplx s = 0.0;
+        for (int64_t i = 0; i < n; i++) s += conj(a[i]) * b[i];
+        return s;
+    }
+    int64_t h = n / 2;
+    return dot_pairwise(h, a, b) + dot_pairwise(n - h, a + h, b + h);
+}
+
 /* src/Fields.h:216-226  dot(a,b) = sum_i conj(a_i) * b_i, sequential, index order */
 void orc_dot(int64_t n, const cplx *a, const cplx *b, cplx *out) {
     cplx s = 0.0;
-    for (int64_t i = 0; i < n; i++) s += conj(a[i]) * b[i];
+    if (g_sum_order == 1) for (int64_t i = n - 1; i >= 0; i--) s += conj(a[i]) * b[i];
+    else if (g_sum_order == 2) s = dot_pairwise(n, a, b);
+    else for (int64_t i = 0; i < n; i++) s += conj(a[i]) * b[i];
     *out = s;
 }
 
 /* src/Fields.h:228-235  squarednorm = Re sum_i conj(a_i) * a_i (complex accumulator) */
 double orc_sqnorm(int64_t n, const cplx *a) {
     cplx s = 0.0;
-    for (int64_t i = 0; i < n; i++) s += conj(a[i]) * a[i];
+    if (g_sum_order == 1) for (int64_t i = n - 1; i >= 0; i--) s += conj(a[i]) * a[i];
+    else if (g_sum_order == 2) s = dot_pairwise(n, a, a);
+    else for (int64_t i = 0; i < n; i++) s += conj(a[i]) * a[i];
     return creal(s);
 }
 
@@ -204,6 +225,12 @@ void orc_bcsr_val_at(const orc_op *op, int64_t row, int64_t col, cplx *out) {
 }
 
 int64_t orc_op_dim(const orc_op *op) { return op->dim; }
+/* number of rows of the output (differs from dim for rectangular CSR / block-CSR) */
+int64_t orc_op_nrow(const orc_op *op) {
+    if (op->kind == OP_CSR) return op->nrow;
+    if (op->kind == OP_BCSR) return (int64_t)op->nbrow * op->bs;
+    return op->dim;
+}
 
 /* ------------------------------------------------------------------ GCR ------------------ */
 

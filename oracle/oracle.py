@@ -58,6 +58,9 @@ def lib():
         L.orc_bcsr_val_at.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _cp]
         L.orc_op_dim.argtypes = [C.c_void_p]
         L.orc_op_dim.restype = C.c_int64
+        L.orc_set_sum_order.argtypes = [C.c_int]
+        L.orc_op_nrow.argtypes = [C.c_void_p]
+        L.orc_op_nrow.restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
         L.orc_op_free.argtypes = [C.c_void_p]
         L.orc_op_gcr.argtypes = [C.c_void_p, C.POINTER(GcrParamC), C.c_int]
@@ -115,7 +118,9 @@ class Op:
         return lib().orc_op_dim(self.h)
 
     def __call__(self, x):
-        y = np.empty(self.dim, c128)
+        if np.size(x) != self.dim:
+            raise ValueError("operator has %d columns, field has %d entries" % (self.dim, np.size(x)))
+        y = np.empty(lib().orc_op_nrow(self.h), c128)
         lib().orc_op_apply(self.h, _c(x), y)
         return y
 
@@ -173,6 +178,27 @@ def gcr_solve(A, param, rhs, x0=None):
     conv = C.c_int(0)
     it = lib().orc_gcr_solve(A.h, C.byref(param), _c(rhs), x, hist, cap, C.byref(conv))
     return x, hist[: it + 1].copy(), it, bool(conv.value)
+
+
+def gcr_reorder_sensitivity(A, param, rhs, x0=None):
+    """How much the residual history of THIS solve moves when the reference's own dot products are
+    summed in another, equally valid order (reverse, pairwise).  Returns (h_ref, s, (it_min, it_max)):
+    s[k] = max over the orders of |h_order(k) - h_ref(k)|, and the range of iteration counts the
+    orders (index order included) needed.  A parallel reduction cannot do better than this."""
+    _, ref, it0, _ = gcr_solve(A, param, rhs, x0)
+    dev = np.zeros(ref.size)
+    its = [it0]
+    try:
+        for mode in (1, 2):
+            lib().orc_set_sum_order(mode)
+            _, h, it, _ = gcr_solve(A, param, rhs, x0)
+            its.append(it)
+            m = min(h.size, ref.size)
+            dev[:m] = np.maximum(dev[:m], np.abs(h[:m] - ref[:m]))
+            dev[m:] = np.inf  # that order had already converged: steps beyond it are not comparable
+    finally:
+        lib().orc_set_sum_order(0)
+    return ref, dev, (min(its), max(its))
 
 
 def gcr_op(A, param, x0_mode=1):
