@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *
     double s[4];
     fold_partials<4>(partsA, nblkA, s, lds);
     const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
-    const cplx alpha = cdiv(num, den);
+    const cplx alpha = to_sgpr(cdiv(num, den));
     if (blockIdx.x == 0 && threadIdx.x == 0) *den_slot = den;
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
@@ -160,32 +160,57 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *
     if (threadIdx.x == 0) partsR[blockIdx.x] = v[0];
 }
 
-// <Ar, Aps[j]> for j < nd (conj on Ar, src/GCR.h:258) -> partsB[(base+j)*2 + {0,1}][blk].
+// <Ar, Aps[j]> for j < NDT (conj on Ar, src/GCR.h:258) -> partsB[(base+j)*2 + {0,1}][blk].
+// NDT is a template parameter so that the (1 + NDT) * U loads of one trip are issued back to back
+// with no branch between them: the kernel is latency-bound otherwise (a wave with a single 1-KiB
+// load in flight cannot cover HBM latency, even at 32 waves per CU).
 // When `book` is set, workgroup 0 also closes the step: folds |r|^2, bumps the iteration
 // counter, records the history entry and raises the convergence flag (src/GCR.h:270-274,288).
+template <int NDT, int U>
 __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(DevState *__restrict__ st, const cplx *__restrict__ ar,
-                                                               DirPtrs d, int nd, int base, int64_t n,
+                                                               DirPtrs d, int base, int64_t n,
                                                                double *__restrict__ partsB, int book,
                                                                const double *__restrict__ partsR, int nblkR,
                                                                double *__restrict__ hist, int hist_cap) {
-    __shared__ double lds[2 * ND * 17];
+    __shared__ double lds[2 * NDT * 17];
     if (st->done) return;
-    double v[2 * ND];
+    double v[2 * NDT];
 #pragma unroll
-    for (int j = 0; j < 2 * ND; j++) v[j] = 0.;
-    GRID_STRIDE(i, n) {
-        cplx a = ar[i];
+    for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+        cplx a[U], b[U][NDT];
 #pragma unroll
-        for (int j = 0; j < ND; j++) {
-            if (j < nd) {
-                cplx t = cconj_mul(a, d.aps[j][i]);
+        for (int u = 0; u < U; u++) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
+                a[u] = ar[i];
+#pragma unroll
+                for (int j = 0; j < NDT; j++) b[u][j] = d.aps[j][i];
+            } else {
+                a[u] = make_double2(0., 0.);
+#pragma unroll
+                for (int j = 0; j < NDT; j++) b[u][j] = make_double2(0., 0.);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int j = 0; j < NDT; j++) {
+                cplx t = cconj_mul(a[u], b[u][j]);
                 v[2 * j] += t.x;
                 v[2 * j + 1] += t.y;
             }
         }
     }
-    block_sum_bcast<2 * ND>(v, lds);
-    if (threadIdx.x < 2 * nd) partsB[(size_t)(2 * base + threadIdx.x) * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+    block_sum_bcast<2 * NDT>(v, lds);
+    if (threadIdx.x < 2 * NDT) {
+        double mine = 0.;
+#pragma unroll
+        for (int j = 0; j < 2 * NDT; j++)
+            if (j == (int)threadIdx.x) mine = v[j];
+        partsB[(size_t)(2 * base + threadIdx.x) * RED_MAX_BLOCKS + blockIdx.x] = mine;
+    }
     if (book && blockIdx.x == 0) {
         double rr[1];
         fold_partials<1>(partsR, nblkR, rr, lds);
@@ -201,48 +226,61 @@ __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(DevState *__restr
 }
 
 // beta_j = <Ar,Aps_j>/<Aps_j,Aps_j>;  p_corr -= ps_j*beta_j;  Ap_corr -= Aps_j*beta_j  (src/GCR.h:257-262)
-// first: accumulators start at 0 (else read from accp/accap); last: p' = dir + p_corr, Ap' = Ar + Ap_corr
+// FIRST: accumulators start at 0 (else read from accp/accap); LAST: p' = dir + p_corr, Ap' = Ar + Ap_corr
 // are written to the ring slot (src/GCR.h:265-266,286-287) and <r,Ap'>, <Ap',Ap'> partials emitted.
+// RDIR: r is a different vector from dir (flexible preconditioning) and has to be loaded as well.
+template <int NDT, bool FIRST, bool LAST, bool RDIR>
 __global__ void __launch_bounds__(RED_THREADS) build_kernel(const DevState *__restrict__ st, const double *__restrict__ partsB,
-                                                            int nblkB, const cplx *__restrict__ den, DirPtrs d, int nd, int base,
-                                                            int first, int last, const cplx *__restrict__ dir,
-                                                            const cplx *__restrict__ r, const cplx *__restrict__ ar,
-                                                            cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n,
+                                                            int nblkB, const cplx *__restrict__ den, DirPtrs d, int base,
+                                                            const cplx *__restrict__ dir, const cplx *__restrict__ r,
+                                                            const cplx *__restrict__ ar, cplx *accp, cplx *accap,
+                                                            cplx *p_out, cplx *ap_out, int64_t n,
                                                             double *__restrict__ partsA) {
-    __shared__ double lds[2 * ND * 17];
-    __shared__ cplx sbeta[ND];
+    __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
+    __shared__ cplx sbeta[NDT];
     if (st->done) return;
-    double s[2 * ND];
-    fold_partials<2 * ND>(partsB + (size_t)(2 * base) * RED_MAX_BLOCKS, nblkB, s, lds);
-    if (threadIdx.x < nd) {
+    double s[2 * NDT];
+    fold_partials<2 * NDT>(partsB + (size_t)(2 * base) * RED_MAX_BLOCKS, nblkB, s, lds);
+    if (threadIdx.x < NDT) {
         // s[] is identical in every thread; pick this thread's pair without dynamic register indexing
         cplx num = make_double2(0., 0.);
 #pragma unroll
-        for (int j = 0; j < ND; j++)
+        for (int j = 0; j < NDT; j++)
             if (j == (int)threadIdx.x) num = make_double2(s[2 * j], s[2 * j + 1]);
         sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
     }
     __syncthreads();
-    cplx beta[ND];
+    cplx beta[NDT];
 #pragma unroll
-    for (int j = 0; j < ND; j++) beta[j] = (j < nd) ? sbeta[j] : make_double2(0., 0.);
+    for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
     double v[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
-        cplx pc = first ? make_double2(0., 0.) : accp[i];
-        cplx ac = first ? make_double2(0., 0.) : accap[i];
+        // all loads of the trip first, no branches in between
+        cplx pj[NDT], aj[NDT];
 #pragma unroll
-        for (int j = 0; j < ND; j++) {
-            if (j < nd) {
-                pc = csub(pc, cmul(beta[j], d.ps[j][i]));
-                ac = csub(ac, cmul(beta[j], d.aps[j][i]));
-            }
+        for (int j = 0; j < NDT; j++) {
+            pj[j] = d.ps[j][i];
+            aj[j] = d.aps[j][i];
         }
-        if (last) {
-            cplx pn = cadd(dir[i], pc);
-            cplx an = cadd(ar[i], ac);
+        cplx pc = FIRST ? make_double2(0., 0.) : accp[i];
+        cplx ac = FIRST ? make_double2(0., 0.) : accap[i];
+        cplx dv = make_double2(0., 0.), av = make_double2(0., 0.), rv = make_double2(0., 0.);
+        if (LAST) {
+            dv = dir[i];
+            av = ar[i];
+            rv = RDIR ? r[i] : dv;
+        }
+#pragma unroll
+        for (int j = 0; j < NDT; j++) {
+            pc = csub(pc, cmul(beta[j], pj[j]));
+            ac = csub(ac, cmul(beta[j], aj[j]));
+        }
+        if (LAST) {
+            cplx pn = cadd(dv, pc);
+            cplx an = cadd(av, ac);
             p_out[i] = pn;
             ap_out[i] = an;
-            cplx t = cconj_mul(r[i], an);
+            cplx t = cconj_mul(rv, an);
             v[0] += t.x; v[1] += t.y;
             cplx u = cconj_mul(an, an);
             v[2] += u.x; v[3] += u.y;
@@ -251,9 +289,12 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(const DevState *__re
             accap[i] = ac;
         }
     }
-    if (last) {
+    if (LAST) {
         block_sum_bcast<4>(v, lds);
-        if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+        if (threadIdx.x < 4) {
+            double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
+            partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
+        }
     }
 }
 
@@ -405,6 +446,53 @@ struct SkipGuard {
     ~SkipGuard() { set_apply_skip_flag(prev); }
 };
 
+static int launch_multidot(int g, int nd, DevState *st, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB,
+                           int book, const double *partsR, int nblkR, double *hist, int hist_cap) {
+#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, ar, d, base, n, partsB, book, partsR, nblkR, hist, hist_cap)
+    switch (nd) {
+        case 1: MD(1, 2); break;
+        case 2: MD(2, 2); break;
+        case 3: MD(3, 1); break;
+        case 4: MD(4, 1); break;
+        case 5: MD(5, 1); break;
+        case 6: MD(6, 1); break;
+        case 7: MD(7, 1); break;
+        default: MD(8, 1); break;
+    }
+#undef MD
+    return MGCR_OK;
+}
+
+template <int NDT>
+static int launch_build_n(int g, bool first, bool last, bool rdir, const DevState *st, const double *partsB, int nblkB,
+                          const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r, const cplx *ar,
+                          cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
+#define BK(F, L, R) KLAUNCH((build_kernel<NDT, F, L, R>), g, st, partsB, nblkB, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
+    if (first && last) { if (rdir) BK(true, true, true); else BK(true, true, false); }
+    else if (first) BK(true, false, false);
+    else if (last) { if (rdir) BK(false, true, true); else BK(false, true, false); }
+    else BK(false, false, false);
+#undef BK
+    return MGCR_OK;
+}
+
+static int launch_build(int g, int nd, bool first, bool last, bool rdir, const DevState *st, const double *partsB, int nblkB,
+                        const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r, const cplx *ar,
+                        cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
+#define LB(NDT) return launch_build_n<NDT>(g, first, last, rdir, st, partsB, nblkB, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
+    switch (nd) {
+        case 1: LB(1);
+        case 2: LB(2);
+        case 3: LB(3);
+        case 4: LB(4);
+        case 5: LB(5);
+        case 6: LB(6);
+        case 7: LB(7);
+        default: LB(8);
+    }
+#undef LB
+}
+
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged) {
     Context &c = ctx();
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
@@ -482,8 +570,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 int sl = ch * ND + (j < nd ? j : 0);
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
-            KLAUNCH(multidot_kernel, g, s->st, (const cplx *)s->ar, d, nd, ch * ND, n, s->partsB, ch == nchunk - 1 ? 1 : 0,
-                    (const double *)s->partsR, g, s->hist, s->hist_cap);
+            MGCR_TRY(launch_multidot(g, nd, s->st, (const cplx *)s->ar, d, ch * ND, n, s->partsB, ch == nchunk - 1 ? 1 : 0,
+                                     (const double *)s->partsR, g, s->hist, s->hist_cap));
         }
         for (int ch = 0; ch < nchunk; ch++) {
             DirPtrs d;
@@ -492,9 +580,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 int sl = ch * ND + (j < nd ? j : 0);
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
-            KLAUNCH(build_kernel, g, (const DevState *)s->st, (const double *)s->partsB, g, (const cplx *)s->den, d, nd,
-                    ch * ND, ch == 0 ? 1 : 0, ch == nchunk - 1 ? 1 : 0, dir, (const cplx *)s->r, (const cplx *)s->ar,
-                    s->accp, s->accap, s->ps[nxt], s->aps[nxt], n, s->partsA);
+            MGCR_TRY(launch_build(g, nd, ch == 0, ch == nchunk - 1, dir != s->r, (const DevState *)s->st,
+                                  (const double *)s->partsB, g, (const cplx *)s->den, d, ch * ND, dir, (const cplx *)s->r,
+                                  (const cplx *)s->ar, s->accp, s->accap, s->ps[nxt], s->aps[nxt], n, s->partsA));
         }
         iter_count = ic_next;
         cur = nxt;

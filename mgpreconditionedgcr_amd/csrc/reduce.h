@@ -27,6 +27,14 @@ __device__ __forceinline__ cplx cdiv(cplx n, cplx d) {
     }
 }
 
+// Re-materialise a wave-uniform double in scalar registers (frees 2 VGPRs per value)
+__device__ __forceinline__ double to_sgpr(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cplx to_sgpr(cplx v) { return make_double2(to_sgpr(v.x), to_sgpr(v.y)); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
