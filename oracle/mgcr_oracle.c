@@ -381,6 +381,13 @@ void orc_op_apply(orc_op *op, const cplx *x, cplx *y) {
     }
 }
 
+/* multigrid cycle as an Operator (what MG::operator() was meant to be, src/MG.h:124-129) */
+orc_op *orc_op_mg(orc_mg *mg, int64_t dim) {
+    orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+    op->kind = OP_MG; op->dim = dim; op->mg = mg;
+    return op;
+}
+
 void orc_op_free(orc_op *op) {
     if (!op) return;
     if (op->owns) { free(op->browptr); free(op->bcol); free(op->blocks); }

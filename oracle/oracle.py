@@ -72,6 +72,29 @@ def lib():
         L.orc_read_text_csr.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_read_text_csr.restype = C.c_int
+        L.orc_mg_aggregates.argtypes = [C.c_int, _i64p, _i32p, C.c_int64, _i32p]
+        L.orc_mg_aggregates.restype = C.c_int64
+        L.orc_mg_prolongator.argtypes = [C.c_int64, C.c_int, C.c_int64, _i32p, _cp, _cp]
+        L.orc_mg_restrict.argtypes = [C.c_int64, C.c_int, C.c_int64, _i32p, _cp, _cp, _cp]
+        L.orc_mg_expand.argtypes = [C.c_int64, C.c_int, _i32p, _cp, _cp, _cp]
+        L.orc_mg_galerkin.argtypes = [C.c_int64, _i64p, _i64p, _cp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int64,
+                                      _i32p, _cp, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mg_galerkin.restype = C.c_int64
+        L.orc_mg_create.argtypes = [C.c_void_p, C.c_int64, _i64p, _i64p, _cp, C.c_int, C.c_double, C.c_double, C.c_int,
+                                    _i64p, _i32p, C.c_int64, C.c_int, _cp, C.c_int, C.POINTER(GcrParamC),
+                                    C.POINTER(GcrParamC), C.c_double]
+        L.orc_mg_create.restype = C.c_void_p
+        L.orc_mg_level_dim.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_dim.restype = C.c_int64
+        L.orc_mg_level_ne.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_nagg.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_nagg.restype = C.c_int64
+        L.orc_mg_level_op.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_op.restype = C.c_void_p
+        L.orc_mg_level_restrict.argtypes = [C.c_void_p, C.c_int, _cp, _cp]
+        L.orc_mg_level_expand.argtypes = [C.c_void_p, C.c_int, _cp, _cp]
+        L.orc_op_mg.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_op_mg.restype = C.c_void_p
         L.orc_fill_rhs.argtypes = [C.c_int64, C.c_uint64, _cp]
         L.orc_poisson3d.argtypes = [C.c_int64, _i64p, _i64p, _cp]
         _lib = L
@@ -254,3 +277,92 @@ def poisson3d(n):
     val = np.empty(nnz, c128)
     lib().orc_poisson3d(n, rowptr, col, val)
     return N, rowptr, col, val
+
+
+# ---------------------------------------------------------------- multigrid pieces
+def mg_aggregates(dims, blocked, sub):
+    """Mesh::blocking (src/Mesh.h:236-298): aggregate index of every unknown. Returns (agg, nagg)."""
+    dims = np.ascontiguousarray(dims, np.int64)
+    blocked = np.ascontiguousarray(blocked, np.int32)
+    agg = np.empty(int(np.prod(dims)), np.int32)
+    nagg = lib().orc_mg_aggregates(dims.size, dims, blocked, sub, agg)
+    if nagg < 0:
+        raise ValueError("Dimension not exactly divisible by block size!")
+    return agg, int(nagg)
+
+
+def mg_prolongator(agg, nagg, vecs):
+    """Block-local restriction + per-aggregate Gram-Schmidt (src/MG.h:171-198). vecs: [ne][n]."""
+    vecs = _c(vecs)
+    ne, n = vecs.shape
+    pv = np.empty((n, ne), c128)
+    lib().orc_mg_prolongator(n, ne, nagg, np.ascontiguousarray(agg, np.int32), vecs, pv)
+    return pv
+
+
+def mg_restrict(agg, nagg, pv, x):
+    n, ne = pv.shape
+    xc = np.empty(nagg * ne, c128)
+    lib().orc_mg_restrict(n, ne, nagg, np.ascontiguousarray(agg, np.int32), _c(pv), _c(x), xc)
+    return xc
+
+
+def mg_expand(agg, pv, xc):
+    n, ne = pv.shape
+    x = np.empty(n, c128)
+    lib().orc_mg_expand(n, ne, np.ascontiguousarray(agg, np.int32), _c(pv), _c(xc), x)
+    return x
+
+
+def mg_galerkin(rowptr, col, val, agg, nagg, pv, shift=None):
+    """Galerkin blocks P^H A P (src/MG.h:204-281). Returns (rows, cols, blocks[nblk][ne][ne])."""
+    n, ne = pv.shape
+    rowptr = np.ascontiguousarray(rowptr, np.int64)
+    col = np.ascontiguousarray(col, np.int64)
+    val = _c(val)
+    agg = np.ascontiguousarray(agg, np.int32)
+    pv = _c(pv)
+    k = complex(shift) if shift is not None else 0j
+    hs = int(shift is not None)
+    nblk = lib().orc_mg_galerkin(n, rowptr, col, val, hs, k.real, k.imag, ne, nagg, agg, pv, None, None, None)
+    rows, cols = np.empty(nblk, np.int32), np.empty(nblk, np.int32)
+    blocks = np.empty((nblk, ne, ne), c128)
+    lib().orc_mg_galerkin(n, rowptr, col, val, hs, k.real, k.imag, ne, nagg, agg, pv,
+                          rows.ctypes.data, cols.ctypes.data, blocks.ctypes.data)
+    return rows, cols, blocks
+
+
+class MG(Op):
+    """Corrected multigrid cycle as an operator (see oracle/mgcr_oracle_mg.c)."""
+
+    def __init__(self, A, rowptr, col, val, dims, blocked, sub, vecs, nlev, smoother, coarse, damping=1.0, shift=None):
+        rowptr = np.ascontiguousarray(rowptr, np.int64)
+        col = np.ascontiguousarray(col, np.int64)
+        val = _c(val)
+        dims = np.ascontiguousarray(dims, np.int64)
+        blocked = np.ascontiguousarray(blocked, np.int32)
+        vecs = _c(vecs)
+        ne, n = vecs.shape
+        k = complex(shift) if shift is not None else 0j
+        self.mg = lib().orc_mg_create(A.h, n, rowptr, col, val, int(shift is not None), k.real, k.imag, dims.size, dims,
+                                      blocked, sub, ne, vecs, nlev, C.byref(smoother), C.byref(coarse), damping)
+        if not self.mg:
+            raise ValueError("orc_mg_create failed")
+        self.nlev = nlev
+        super().__init__(lib().orc_op_mg(self.mg, n), keep=(A, rowptr, col, val, smoother, coarse))
+
+    def level_dim(self, l):
+        return lib().orc_mg_level_dim(self.mg, l)
+
+    def level_op(self, l):
+        return Op(lib().orc_mg_level_op(self.mg, l), keep=(self,))
+
+    def restrict(self, l, x):
+        xc = np.empty(self.level_dim(l + 1), c128)
+        lib().orc_mg_level_restrict(self.mg, l, _c(x), xc)
+        return xc
+
+    def expand(self, l, xc):
+        x = np.empty(self.level_dim(l), c128)
+        lib().orc_mg_level_expand(self.mg, l, _c(xc), x)
+        return x

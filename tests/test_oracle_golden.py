@@ -133,3 +133,87 @@ def test_g8_hsparse(hsparse_gold):
     for (r, c) in [(0, 0), (17, 18), (16, 17), (23, 1), (9, 22)]:
         assert np.isclose(orc.bcsr_val_at(H, r, c), dense[r, c], rtol=1e-15, atol=0)
     assert np.allclose(dense @ g["x"], g["y"], rtol=1e-13)
+
+
+# ------------------------------------------------------------------ multigrid pieces (G9)
+def _doubled(mg_gold, spinor_axis=4):
+    """Chirality doubling v+- = (v +- g5 v) * 0.5 (src/MG.h:316-345, src/Fields.h:310-339)."""
+    dims = (4, 4, 4, 4, 4, 3)
+    out_p, out_m = [], []
+    for name in ("eigvec0", "eigvec1"):
+        v = mg_gold[name].reshape(dims)
+        g5 = np.empty_like(v)
+        perm = [2, 3, 0, 1]
+        for s in range(4):
+            idx = [slice(None)] * 6
+            idx[spinor_axis] = perm[s]
+            src = [slice(None)] * 6
+            src[spinor_axis] = s
+            g5[tuple(idx)] = v[tuple(src)]
+        if name == "eigvec0":
+            assert np.array_equal(g5.ravel(), mg_gold["gamma5_eigvec0"])
+        out_p.append(((v + g5) * 0.5).ravel())
+        out_m.append(((v - g5) * 0.5).ravel())
+    return np.array(out_p + out_m)
+
+
+def test_g9_mg_pieces(sample_ops, sample_matrix_path, mg_gold):
+    g = mg_gold
+    nblocks, bsz, ne, sub = int(g["nblocks"]), int(g["block_size"]), int(g["ne"]), int(g["sub"])
+    dims, blocked = (4, 4, 4, 4, 4, 3), (1, 1, 1, 1, 0, 0)
+    agg, nagg = orc.mg_aggregates(dims, blocked, sub)
+    assert nagg == nblocks
+    # block map of the reference (src/Mesh.h:236-298): spacetime site -> (block, offset)
+    site = np.arange(3072) // 12
+    for b in range(nblocks):
+        assert set(np.unique(site[agg == b])) == set(g["block_map"][b])
+    vecs = _doubled(g)
+    pv = orc.mg_prolongator(agg, nagg, vecs)
+    # reference prolongator columns are full-length fields, zero outside their block
+    P = g["P"]  # [block][k][N]
+    for b in (0, 5, 15):
+        for k in range(ne):
+            ref = P[b, k]
+            assert not ref[agg != b].any()
+            assert np.array_equal(pv[agg == b, k], ref[agg == b])
+    Rv = orc.mg_restrict(agg, nagg, pv, g["v"])
+    assert np.array_equal(Rv, g["Rv"])
+    PRv = orc.mg_expand(agg, pv, Rv)
+    assert np.allclose(PRv, g["PRv"], rtol=0, atol=1e-15)
+    # Galerkin coarse operator of DiracOp(D, 0.1) vs the reference's m_coarse (dense view)
+    nrow, ncol, rowptr, col, val = orc.read_text_csr(sample_matrix_path)
+    rows, cols, blocks = orc.mg_galerkin(rowptr, col, val, agg, nagg, pv, shift=float(g["k"]))
+    Ac = np.zeros((nagg * ne, nagg * ne), np.complex128)
+    for r, c, blk in zip(rows, cols, blocks):
+        Ac[r * ne:(r + 1) * ne, c * ne:(c + 1) * ne] += blk
+    ref = g["Ac_dense"]
+    assert np.abs(Ac - ref).max() <= 1e-15 * np.abs(ref).max()
+    assert np.array_equal(Ac != 0, ref != 0) or np.abs(Ac[ref == 0]).max() < 1e-16
+    H = orc.bcsr_from_triplets(nagg, nagg, ne, rows, cols, blocks)
+    assert np.abs(H(Rv) - g["AcRv"]).max() <= 1e-14 * np.abs(g["AcRv"]).max()
+    # projector identities of test_MG_property (src/main.cpp:899-909)
+    i2 = orc.mg_expand(agg, pv, Rv)
+    i3 = orc.mg_restrict(agg, nagg, pv, i2)
+    assert np.linalg.norm(i3 - Rv) <= 1e-14 and np.linalg.norm(orc.mg_expand(agg, pv, i3) - i2) <= 1e-14
+
+
+def test_mg_cycle_oracle_converges():
+    """Corrected V-cycle (no reference output exists): sanity of the oracle
+    itself — 3-level piecewise-constant aggregation on Poisson 16^3 as a flexible right
+    preconditioner cuts the GCR iteration count several-fold."""
+    n = 16
+    N, rowptr, col, val = orc.poisson3d(n)
+    A = orc.csr(N, N, rowptr, col, val)
+    b = orc.fill_rhs(N, 0)
+    sm = orc.gcr_param(restart=10, max_iter=2, tol=1e-30)
+    co = orc.gcr_param(restart=10, max_iter=50, tol=1e-2)
+    M = orc.MG(A, rowptr, col, val, (n, n, n), (1, 1, 1), 2, np.ones((1, N)), 3, sm, co)
+    assert M.level_dim(1) == 512 and M.level_dim(2) == 64
+    # Galerkin of the 7-point operator with piecewise-constant P is again a 7-point operator
+    Ac = M.level_op(1)
+    y = Ac(np.ones(512, np.complex128))
+    assert abs(y.reshape(8, 8, 8)[3, 3, 3]) < 1e-13  # interior row sum 0
+    x0, h0, it0, c0 = orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=400, tol=1e-8), b)
+    x1, h1, it1, c1 = orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=400, tol=1e-8, right=M, flexible=True), b)
+    assert c0 and c1 and it1 * 3 < it0
+    assert np.linalg.norm(b - A(x1)) / np.linalg.norm(b) < 2e-8
