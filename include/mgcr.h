@@ -130,6 +130,43 @@ int mgcr_gcr_create(mgcr_op_t A, const mgcr_gcr_param *param, int32_t x0_mode, m
 int mgcr_gcr_set_operator(mgcr_op_t gcr, mgcr_op_t A);
 int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0);
 
+/* ---- MG: src/MG.h, src/Mesh.h, src/SolverParam.h:38-59 ------------------------------------ */
+typedef struct mgcr_mg_param {
+    /* MG_Param::mesh + spacetime mask (src/SolverParam.h:41,47): row-major mesh of the fine
+     * operator; dimensions with blocked[d] != 0 are cut into blocks of edge subblock_dim
+     * (Mesh::blocking, src/Mesh.h:236-298), the others (spinor, colour) stay inside an aggregate.
+     * The reference hard-wires 4 blocked dimensions; 1..4 are accepted here. */
+    int32_t ndim;
+    int64_t dims[8];
+    int32_t blocked[8];
+    int64_t subblock_dim;    /* MG_Param::subblock_dim */
+    /* near-null vectors the prolongator is built from, [n_vec][N] interleaved re/im on the host.
+     * (The reference computes n_eigen vectors by inverse iteration and doubles them by chirality,
+     * src/MG.h:90-122,316-345; the host mirror does that and passes the 2*n_eigen vectors in.) */
+    int32_t n_vec;
+    const double *vecs_ri;
+    int32_t n_level;         /* MG_Param::n_level = number of COARSE grids (1 = the reference's
+                                two-level method; the reference stores it and never reads it) */
+    mgcr_gcr_param smoother; /* GCR_Param of MG_Param::smoother_solver (max_iter = sweeps) */
+    mgcr_gcr_param coarse;   /* GCR_Param of MG_Param::coarse_solver (coarsest level) */
+    double damping;          /* x += damping * P x_c; the reference hard-codes 0.1 (src/MG.h:426) */
+} mgcr_mg_param;
+
+/* MG(Operator*, MG_Param*) + initialise (src/MG.h:131-285): aggregates, block-local prolongator
+ * with per-aggregate Gram-Schmidt, Galerkin coarse operators for every level.  A must be a
+ * Sparse or a DiracOp.  The result is an Operator whose apply is the corrected V-cycle described
+ * in DESIGN.md (MG::operator() of the reference returns uninitialised memory, src/MG.h:124-129). */
+int mgcr_mg_create(mgcr_op_t A, const mgcr_mg_param *param, mgcr_op_t *out);
+/* number of operator levels, and per level: dimension, vectors per aggregate, aggregates */
+int mgcr_mg_level_info(mgcr_op_t mg, int32_t level, int64_t *dim, int32_t *ne, int64_t *nagg);
+/* MG::restrict / MG::expand between level and level+1 (src/MG.h:347-383) */
+int mgcr_mg_restrict(mgcr_op_t mg, int32_t level, mgcr_vec_t fine, mgcr_vec_t coarse);
+int mgcr_mg_expand(mgcr_op_t mg, int32_t level, mgcr_vec_t coarse, mgcr_vec_t fine);
+/* borrowed handle of the level's operator (level 0 = A, level >= 1 = Galerkin m_coarse, src/MG.h:281) */
+int mgcr_mg_level_op(mgcr_op_t mg, int32_t level, mgcr_op_t *out);
+/* prolongator of `level` as [n][ne] block-local values plus the aggregate index of every row */
+int mgcr_mg_download_prolongator(mgcr_op_t mg, int32_t level, double *pv_ri, int32_t *agg);
+
 /* ---- measurement helpers (bench.py) ------------------------------------------------------- */
 /* runs `reps` applies back to back on the library stream, bracketed by hipEvents there;
  * returns the average milliseconds per apply */

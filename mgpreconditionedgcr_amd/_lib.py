@@ -27,6 +27,13 @@ class GcrParamC(C.Structure):
                 ("use_x0", C.c_int32), ("flexible", C.c_int32), ("check_every", C.c_int32)]
 
 
+class MgParamC(C.Structure):
+    """struct mgcr_mg_param (include/mgcr.h) — mirror of MG_Param (src/SolverParam.h:38-59)."""
+    _fields_ = [("ndim", C.c_int32), ("dims", C.c_int64 * 8), ("blocked", C.c_int32 * 8),
+                ("subblock_dim", C.c_int64), ("n_vec", C.c_int32), ("vecs_ri", C.c_void_p),
+                ("n_level", C.c_int32), ("smoother", GcrParamC), ("coarse", GcrParamC), ("damping", C.c_double)]
+
+
 _lib = None
 _initialised_device = None
 
@@ -70,6 +77,12 @@ _SIGS = {
     "mgcr_gcr_create": (C.c_int, [_vp, C.POINTER(GcrParamC), C.c_int32, C.POINTER(_vp)]),
     "mgcr_gcr_set_operator": (C.c_int, [_vp, _vp]),
     "mgcr_gcr_set_x0": (C.c_int, [_vp, _vp]),
+    "mgcr_mg_create": (C.c_int, [_vp, C.POINTER(MgParamC), C.POINTER(_vp)]),
+    "mgcr_mg_level_info": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "mgcr_mg_restrict": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
+    "mgcr_mg_expand": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
+    "mgcr_mg_level_op": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
+    "mgcr_mg_download_prolongator": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
     "mgcr_bench_op_apply": (C.c_int, [_vp, _vp, _vp, C.c_int32, _dp]),
     "mgcr_timer_start": (C.c_int, []),
     "mgcr_timer_stop": (C.c_int, [_dp]),

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import GcrParamC, MgcrError, check
+from ._lib import GcrParamC, MgParamC, MgcrError, check
 
 c128 = np.complex128
 
@@ -289,6 +289,188 @@ class GCR(Operator):
         self.last_converged = bool(conv.value)
         self.last_history = hist[: it.value + 1].copy()
         return x
+
+
+class Mesh:
+    """Mesh<num_type> (src/Mesh.h:13-64): row-major N-D index algebra (host side)."""
+
+    def __init__(self, index_dims, num_dims=None):
+        self.dims = tuple(int(d) for d in (index_dims[:num_dims] if num_dims else index_dims))
+
+    def get_ndim(self):
+        return len(self.dims)
+
+    def get_size(self):
+        return int(np.prod(self.dims, dtype=np.int64))
+
+    def ind_loc(self, index):  # src/Mesh.h:156-165
+        loc = int(index[0])
+        for i in range(1, len(self.dims)):
+            loc = loc * self.dims[i] + int(index[i])
+        return loc
+
+    def loc_ind(self, loc):  # alloc_loc_ind src/Mesh.h:368-398
+        return tuple(int(v) for v in np.unravel_index(loc, self.dims))
+
+
+def gamma5(field_values, dims, spinor_index=4):
+    """Field::gamma5 (src/Fields.h:310-339): output[index with spinor 0<->2, 1<->3] = field[i]."""
+    v = np.asarray(field_values, c128).reshape(dims)
+    out = np.empty_like(v)
+    perm = [2, 3, 0, 1]
+    for s_ in range(4):
+        dst = [slice(None)] * len(dims)
+        src = [slice(None)] * len(dims)
+        dst[spinor_index] = perm[s_]
+        src[spinor_index] = s_
+        out[tuple(dst)] = v[tuple(src)]
+    return out.reshape(-1)
+
+
+def vec_double(vecs, dims, spinor_index=4):
+    """MG::vec_double (src/MG.h:316-345): [v+ ..., v- ...] with v+- = (v +- gamma5 v) * 0.5."""
+    plus, minus = [], []
+    for v in vecs:
+        v = np.asarray(v, c128).reshape(-1)
+        g = gamma5(v, dims, spinor_index)
+        plus.append((v + g) * 0.5)
+        minus.append((v - g) * 0.5)
+    return np.array(plus + minus)
+
+
+class MG_Param:
+    """MG_Param(mesh, subblock, eigenvecs, eigen_param, solver_coarse, solver_smooth, levels,
+    solver_l, solver_r) (src/SolverParam.h:38-59,142-158).
+
+    solver_coarse / solver_smooth are GCR objects created with `GCR(GCR_Param)` exactly as in the
+    reference (src/main.cpp:851-853); MG takes their GCR_Param.  Extras the reference lacks:
+    `null_vectors` (use these near-null vectors instead of computing n_eigen of them),
+    `spacetime` mask for meshes that are not 6-D, `damping` (reference literal: 0.1)."""
+
+    def __init__(self, m, subblock, eigenvecs, eigen_param, solver_coarse, solver_smooth, levels=1,
+                 solver_l=None, solver_r=None, spacetime=None, spinor=None, null_vectors=None, damping=1.0):
+        self.mesh = m if isinstance(m, Mesh) else Mesh(m)
+        self.subblock_dim = int(subblock)
+        self.n_eigen = int(eigenvecs)
+        self.eigenvector_precomp_param = eigen_param
+        self.coarse_solver, self.smoother_solver = solver_coarse, solver_smooth
+        nd = self.mesh.get_ndim()
+        default_st = [True, True, True, True, False, False]
+        self.spacetime = list(spacetime) if spacetime is not None else (default_st[:nd] if nd == 6 else [True] * nd)
+        self.spinor = list(spinor) if spinor is not None else ([False] * 4 + [True, False] if nd == 6 else [False] * nd)
+        self.n_level = int(levels)
+        self.left_precond, self.right_precond = solver_l, solver_r
+        self.null_vectors = null_vectors
+        self.damping = float(damping)
+
+
+class MG(Operator):
+    """MG<num_type> (src/MG.h:20-61): `MG(M, param)` or `MG(param)` + `initialise(M)`.
+
+    apply = corrected V-cycle; restrict / expand as in src/MG.h:347-383."""
+
+    def __init__(self, M=None, parameter=None):
+        super().__init__()
+        if isinstance(M, MG_Param) and parameter is None:
+            M, parameter = None, M
+        self.param = parameter
+        self.m = None
+        if M is not None:
+            self.initialise(M)
+
+    def near_null_vectors(self, M):
+        """Arnoldi::solve (src/MG.h:90-122): inverse iteration with GCR for the smallest modes,
+        Gram-Schmidt between them, then chirality doubling when the mesh has a spinor dimension.
+        The start vector is the repo's deterministic RHS (seed 9) instead of libc rand(), and each
+        inverse-iteration solve starts from x0 = 0 (the reference aliases rhs and x there)."""
+        prm = self.param
+        dims = prm.mesh.dims
+        gp = prm.eigenvector_precomp_param
+        gcr = GCR(M, GCR_Param(gp.truncation, gp.restart, gp.max_iter, gp.tol, False))
+        b = Field(dims).fill_rhs(9)
+        x = Field(dims)
+        for _ in range(10):
+            x.set_zero()
+            gcr.solve(b, x)
+            b.assign(x).normalise()
+        vecs = [b.to_numpy()]
+        for count in range(1, prm.n_eigen):
+            x.set_zero()
+            gcr.solve(Field(dims, vecs[-1]), x)
+            t = x.to_numpy()
+            for v in vecs:
+                t = t - v * np.vdot(v, t)
+            vecs.append(t / np.linalg.norm(t))
+        if any(prm.spinor):
+            return vec_double(vecs, dims, prm.spinor.index(True))
+        return np.array(vecs)
+
+    def initialise(self, M):  # src/MG.h:131-285
+        _lib.init()
+        prm = self.param
+        self.m = M
+        vecs = prm.null_vectors if prm.null_vectors is not None else self.near_null_vectors(M)
+        vecs = np.ascontiguousarray(vecs, c128)
+        if vecs.ndim == 1:
+            vecs = vecs[None, :]
+        nd = prm.mesh.get_ndim()
+        pc = MgParamC()
+        pc.ndim = nd
+        for d in range(nd):
+            pc.dims[d] = prm.mesh.dims[d]
+            pc.blocked[d] = int(bool(prm.spacetime[d]))
+        pc.subblock_dim = prm.subblock_dim
+        pc.n_vec = vecs.shape[0]
+        pc.vecs_ri = vecs.ctypes.data
+        pc.n_level = prm.n_level
+        pc.smoother = prm.smoother_solver.param._c()
+        pc.coarse = prm.coarse_solver.param._c()
+        pc.damping = prm.damping
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_mg_create(M.h, C.byref(pc), C.byref(h)))
+        if self.h:
+            _lib.lib().mgcr_op_destroy(self.h)
+        self.h = h
+        self._keep += [M, prm]
+        self.n_levels = prm.n_level + 1
+
+    def level_info(self, level):
+        dim, ne, nagg = C.c_int64(), C.c_int32(), C.c_int64()
+        check(_lib.lib().mgcr_mg_level_info(self.h, level, C.byref(dim), C.byref(ne), C.byref(nagg)))
+        return dict(dim=dim.value, ne=ne.value, nagg=nagg.value)
+
+    def restrict(self, x_fine, level=0):  # src/MG.h:366-383
+        out = Field((self.level_info(level + 1)["dim"],))
+        check(_lib.lib().mgcr_mg_restrict(self.h, level, x_fine.h, out.h))
+        return out
+
+    def expand(self, x_coarse, level=0):  # src/MG.h:347-364
+        info = self.level_info(level)
+        out = Field(self.param.mesh.dims if level == 0 else (info["dim"],))
+        check(_lib.lib().mgcr_mg_expand(self.h, level, x_coarse.h, out.h))
+        return out
+
+    def level_operator(self, level):
+        """Borrowed view of the level's operator (level >= 1: the Galerkin m_coarse, src/MG.h:281)."""
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_mg_level_op(self.h, level, C.byref(h)))
+        op = Operator()
+        op.h = h
+        op._keep.append(self)
+        op.__class__ = _BorrowedOperator
+        return op
+
+    def prolongator(self, level=0):
+        info = self.level_info(level)
+        pv = np.empty((info["dim"], info["ne"]), c128)
+        agg = np.empty(info["dim"], np.int32)
+        check(_lib.lib().mgcr_mg_download_prolongator(self.h, level, pv.ctypes.data, agg.ctypes.data))
+        return pv, agg
+
+
+class _BorrowedOperator(Operator):
+    def __del__(self):  # owned by the MG object
+        self.h = None
 
 
 def read_data(filename, directory=None):

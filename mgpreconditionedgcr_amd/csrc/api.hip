@@ -101,6 +101,7 @@ int mgcr_op_destroy(mgcr_op_t op) {
         case OP_CSR: csr_free(&op->csr); break;
         case OP_BCSR: bcsr_free(&op->bcsr); break;
         case OP_GCR: gcr_state_destroy(op->gcr); break;
+        case OP_MG: mg_destroy(op->mg); break;
         default: break;  // OP_DIRAC borrows its Sparse (src/Operator.h:117,555-560)
     }
     delete op;

@@ -30,9 +30,6 @@
 
 namespace mgcr {
 
-void set_apply_skip_flag(const int *flag);
-const int *get_apply_skip_flag();
-
 constexpr int ND = 8;  // directions per multidot / build launch
 
 struct DevState {
@@ -329,6 +326,8 @@ int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n) {
             return bcsr_apply(op->bcsr, x, y);
         case OP_GCR:
             return gcr_apply_as_operator(op->gcr, x, y);
+        case OP_MG:
+            return mg_apply(op->mg, x, y);
         default:
             set_error("operator kind %d cannot be applied", (int)op->kind);
             return MGCR_ERR_UNSUPPORTED;
@@ -371,6 +370,8 @@ int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out
     *out = s;
     return MGCR_OK;
 }
+
+void gcr_state_set_use_x0(GcrState *s, bool use_x0) { s->p.use_x0 = use_x0 ? 1 : 0; }
 
 int gcr_state_set_operator(GcrState *s, Op *A) {
     s->A = A;

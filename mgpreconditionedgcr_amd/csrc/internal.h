@@ -131,6 +131,21 @@ int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h
 void bcsr_free(BcsrDev *b);
 int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y);
 
+// reconstructs a host CSR (int64 indices; padding entries appear as explicit zeros) from the device layout
+struct HostCsr {
+    int64_t nrow = 0, ncol = 0;
+    std::vector<int64_t> rowptr, col;
+    std::vector<double> val_ri;
+};
+int csr_download_host(const CsrDev &A, HostCsr *out);
+void set_apply_skip_flag(const int *flag);
+const int *get_apply_skip_flag();
+
+// ---- mg.hip ----------------------------------------------------------------------------------
+int mg_create(Op *A, const mgcr_mg_param *p, MgState **out);
+void mg_destroy(MgState *m);
+int mg_apply(MgState *m, const cplx *f, cplx *y);
+
 // ---- gcr.hip ---------------------------------------------------------------------------------
 int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n);
 int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out);
@@ -140,6 +155,7 @@ int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n);
 // runs the solve; `nested` = no host round trips (used when GCR is itself applied as an operator)
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter,
             int *converged);
+void gcr_state_set_use_x0(GcrState *s, bool use_x0);
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);
 
 }  // namespace mgcr
