@@ -167,6 +167,45 @@ int mgcr_mg_level_op(mgcr_op_t mg, int32_t level, mgcr_op_t *out);
 /* prolongator of `level` as [n][ne] block-local values plus the aggregate index of every row */
 int mgcr_mg_download_prolongator(mgcr_op_t mg, int32_t level, double *pv_ri, int32_t *agg);
 
+/* ---- multi-GPU: one process per GPU, row-block partition (new design — the reference has no
+ *      distribution at all) ------------------------------------------ */
+typedef struct mgcr_comm_s *mgcr_comm_t;
+typedef struct mgcr_plan_s *mgcr_plan_t;
+#define MGCR_RCCL_ID_BYTES 128
+/* RCCL over xGMI.  Rank 0 obtains an id, the launcher broadcasts the 128 bytes (bench.py does it
+ * with torch.distributed), every rank then creates its communicator.  librccl is dlopen()ed on
+ * first use, so single-GPU users do not need it. */
+int mgcr_rccl_unique_id(void *id128);
+int mgcr_comm_create_rccl(int rank, int nranks, const void *id128, mgcr_comm_t *out);
+/* Host-staged transport through caller-supplied callbacks (bring-up and tests: lets several ranks
+ * share one GPU, or run the partition logic with no GPU at all).  Buffers are host memory, counts
+ * are in doubles.  allreduce: in-place sum over all ranks.  exchange: post all sends / receives
+ * to the listed peers and complete them. */
+typedef int (*mgcr_allreduce_cb)(void *user, double *buf, int64_t count);
+typedef int (*mgcr_exchange_cb)(void *user, int32_t npeers, const int32_t *peers, const double *const *send,
+                                const int64_t *send_count, double *const *recv, const int64_t *recv_count);
+int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgcr_exchange_cb exchange, void *user,
+                          mgcr_comm_t *out);
+int mgcr_comm_destroy(mgcr_comm_t comm);
+/* Partition plan of a row block [row0, row0 + nrow_local) of an n_global-row matrix given with
+ * GLOBAL column indices: which remote x entries this rank needs (halo), from whom, what it has
+ * to send to whom, and where the rows that touch no remote column sit (they can be multiplied
+ * while the halo is in flight).  Pure host code: works without a GPU.  Collective over `comm`. */
+int mgcr_plan_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t nrow_local, const int64_t *rowptr,
+                     const int64_t *col_global, mgcr_plan_t *out);
+int mgcr_plan_info(mgcr_plan_t plan, int64_t *n_halo, int32_t *npeers, int64_t *interior_begin, int64_t *interior_end);
+int mgcr_plan_peers(mgcr_plan_t plan, int32_t *peers, int64_t *send_counts, int64_t *recv_counts);
+/* column indices in the local numbering: owned -> col - row0, halo -> nrow_local + slot */
+int mgcr_plan_local_columns(mgcr_plan_t plan, int64_t *col_local);
+int mgcr_plan_send_indices(mgcr_plan_t plan, int32_t peer_slot, int64_t *local_rows);
+int mgcr_plan_halo_globals(mgcr_plan_t plan, int64_t *global_cols);
+int mgcr_plan_destroy(mgcr_plan_t plan);
+/* Row block of a distributed Sparse: Fields it applies to hold this rank's nrow_local entries;
+ * apply = halo exchange (overlapped with the interior rows) + local SpMV; GCR on it all-reduces
+ * its dot products (2 small all-reduces per iteration).  Collective over `comm`. */
+int mgcr_dcsr_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t nrow_local, const int64_t *rowptr,
+                     const int64_t *col_global, const double *val_ri, mgcr_op_t *out);
+
 /* ---- measurement helpers (bench.py) ------------------------------------------------------- */
 /* runs `reps` applies back to back on the library stream, bracketed by hipEvents there;
  * returns the average milliseconds per apply */

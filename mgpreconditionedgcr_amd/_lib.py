@@ -34,6 +34,10 @@ class MgParamC(C.Structure):
                 ("n_level", C.c_int32), ("smoother", GcrParamC), ("coarse", GcrParamC), ("damping", C.c_double)]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_double)),
+                          C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64))
+
 _lib = None
 _initialised_device = None
 
@@ -83,6 +87,18 @@ _SIGS = {
     "mgcr_mg_expand": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
     "mgcr_mg_level_op": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
     "mgcr_mg_download_prolongator": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
+    "mgcr_rccl_unique_id": (C.c_int, [_vp]),
+    "mgcr_comm_create_rccl": (C.c_int, [C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "mgcr_comm_create_host": (C.c_int, [C.c_int, C.c_int, ALLREDUCE_CB, EXCHANGE_CB, _vp, C.POINTER(_vp)]),
+    "mgcr_comm_destroy": (C.c_int, [_vp]),
+    "mgcr_plan_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, C.POINTER(_vp)]),
+    "mgcr_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mgcr_plan_peers": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "mgcr_plan_local_columns": (C.c_int, [_vp, _vp]),
+    "mgcr_plan_send_indices": (C.c_int, [_vp, C.c_int32, _vp]),
+    "mgcr_plan_halo_globals": (C.c_int, [_vp, _vp]),
+    "mgcr_plan_destroy": (C.c_int, [_vp]),
+    "mgcr_dcsr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "mgcr_bench_op_apply": (C.c_int, [_vp, _vp, _vp, C.c_int32, _dp]),
     "mgcr_timer_start": (C.c_int, []),
     "mgcr_timer_stop": (C.c_int, [_dp]),

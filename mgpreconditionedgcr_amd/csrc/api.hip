@@ -98,7 +98,7 @@ int mgcr_op_destroy(mgcr_op_t op) {
     LOCK();
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     switch (op->kind) {
-        case OP_CSR: csr_free(&op->csr); break;
+        case OP_CSR: csr_free(&op->csr); dist_free(op->dist); break;
         case OP_BCSR: bcsr_free(&op->bcsr); break;
         case OP_GCR: gcr_state_destroy(op->gcr); break;
         case OP_MG: mg_destroy(op->mg); break;

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(RED_THREADS) fold_kernel(const double *__restr
     __shared__ double lds[17];
     for (int k = 0; k < nscal; k++) {
         double v[1];
-        fold_partials<1>(parts + (size_t)k * RED_MAX_BLOCKS, nblk, v, lds);
+        fold_partials<1>(parts + (size_t)k * RED_MAX_BLOCKS, nblk, RED_MAX_BLOCKS, v, lds);
         if (threadIdx.x == 0) out[k] = v[0];
     }
 }

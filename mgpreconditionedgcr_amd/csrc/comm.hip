@@ -1,0 +1,589 @@
+// Multi-GPU layer: communicators (RCCL over xGMI, or a host-staged callback transport), the
+// row-block partition plan, and the distributed Sparse operator.
+//
+// The reference is a single-process CPU code: everything here is new design for
+// one process per MI355X.  Data path collectives per GCR iteration:
+//   * 1 halo exchange per SpMV: ncclSend/ncclRecv pairs inside one group on a dedicated stream,
+//     overlapped with the rows that touch no remote column;
+//   * 2 all-reduces of a handful of doubles (4, then 1 + 2*lim), in place on device memory, on the
+//     compute stream — results never visit the host.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <map>
+
+#include "internal.h"
+#include "reduce.h"
+
+namespace mgcr {
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, bound at run time
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi &rccl() {
+    static RcclApi api;
+    return api;
+}
+
+static int rccl_load() {
+    RcclApi &a = rccl();
+    if (a.handle) return MGCR_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (a.handle) break;
+    }
+    MGCR_CHECK(a.handle, MGCR_ERR_COMM, "cannot dlopen librccl.so.1: %s", dlerror());
+#define SYM(field, name)                                                        \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, name));       \
+    MGCR_CHECK(a.field, MGCR_ERR_COMM, "librccl lacks symbol %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return MGCR_OK;
+}
+
+#define MGCR_NCCL(call)                                                                              \
+    do {                                                                                             \
+        ncclResult_t r__ = (call);                                                                   \
+        if (r__ != ncclSuccess) {                                                                    \
+            set_error("RCCL error %d (%s) in %s", (int)r__, rccl().GetErrorString(r__), #call);       \
+            return MGCR_ERR_COMM;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct Comm {
+    int rank = 0, nranks = 1;
+    bool is_rccl = false;
+    ncclComm_t nccl = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    mgcr_allreduce_cb allreduce = nullptr;
+    mgcr_exchange_cb exchange = nullptr;
+    void *user = nullptr;
+    // staging for host-level collectives over RCCL (set-up only)
+    double *d_stage = nullptr;
+    size_t d_stage_cap = 0;
+    double *h_pin = nullptr;  // pinned, for the host-staged transport's scalar all-reduces
+};
+
+static int comm_device_ready(Comm *c) {
+    if (c->comm_stream) return MGCR_OK;
+    MGCR_TRY(require_ctx());
+    MGCR_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    MGCR_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    MGCR_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    MGCR_HIP(hipHostMalloc((void **)&c->h_pin, sizeof(double) * 1024, hipHostMallocDefault));
+    return MGCR_OK;
+}
+
+static int stage_reserve(Comm *c, size_t doubles) {
+    if (doubles <= c->d_stage_cap) return MGCR_OK;
+    if (c->d_stage) hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    MGCR_HIP(hipMalloc((void **)&c->d_stage, sizeof(double) * doubles));
+    c->d_stage_cap = doubles;
+    return MGCR_OK;
+}
+
+bool comm_collectives(Comm *c);
+
+// host-level all-reduce (set-up): in-place sum of `count` doubles over all ranks
+static int comm_allreduce_host(Comm *c, double *buf, int64_t count) {
+    if (c->nranks == 1 && !(c->is_rccl && comm_collectives(c))) return MGCR_OK;
+    if (!c->is_rccl) {
+        int rc = c->allreduce(c->user, buf, count);
+        MGCR_CHECK(rc == 0, MGCR_ERR_COMM, "allreduce callback failed (%d)", rc);
+        return MGCR_OK;
+    }
+    MGCR_TRY(comm_device_ready(c));
+    MGCR_TRY(stage_reserve(c, (size_t)count));
+    hipStream_t st = ctx().stream;
+    MGCR_HIP(hipMemcpyAsync(c->d_stage, buf, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, st));
+    MGCR_NCCL(rccl().AllReduce(c->d_stage, c->d_stage, (size_t)count, ncclDouble, ncclSum, c->nccl, st));
+    MGCR_HIP(hipMemcpyAsync(buf, c->d_stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+    MGCR_HIP(hipStreamSynchronize(st));
+    return MGCR_OK;
+}
+
+// host-level neighbour exchange (set-up): counts in doubles
+static int comm_exchange_host(Comm *c, int npeers, const int *peers, const double *const *send, const int64_t *scount,
+                              double *const *recv, const int64_t *rcount) {
+    if (npeers == 0) return MGCR_OK;
+    if (!c->is_rccl) {
+        int rc = c->exchange(c->user, npeers, peers, send, scount, recv, rcount);
+        MGCR_CHECK(rc == 0, MGCR_ERR_COMM, "exchange callback failed (%d)", rc);
+        return MGCR_OK;
+    }
+    MGCR_TRY(comm_device_ready(c));
+    size_t tot = 0;
+    for (int p = 0; p < npeers; p++) tot += (size_t)scount[p] + (size_t)rcount[p];
+    MGCR_TRY(stage_reserve(c, tot));
+    hipStream_t st = ctx().stream;
+    std::vector<double *> ds((size_t)npeers), dr((size_t)npeers);
+    size_t off = 0;
+    for (int p = 0; p < npeers; p++) {
+        ds[(size_t)p] = c->d_stage + off; off += (size_t)scount[p];
+        dr[(size_t)p] = c->d_stage + off; off += (size_t)rcount[p];
+        if (scount[p]) MGCR_HIP(hipMemcpyAsync(ds[(size_t)p], send[p], sizeof(double) * (size_t)scount[p], hipMemcpyHostToDevice, st));
+    }
+    MGCR_NCCL(rccl().GroupStart());
+    for (int p = 0; p < npeers; p++) {
+        if (scount[p]) MGCR_NCCL(rccl().Send(ds[(size_t)p], (size_t)scount[p], ncclDouble, peers[p], c->nccl, st));
+        if (rcount[p]) MGCR_NCCL(rccl().Recv(dr[(size_t)p], (size_t)rcount[p], ncclDouble, peers[p], c->nccl, st));
+    }
+    MGCR_NCCL(rccl().GroupEnd());
+    for (int p = 0; p < npeers; p++)
+        if (rcount[p]) MGCR_HIP(hipMemcpyAsync(recv[p], dr[(size_t)p], sizeof(double) * (size_t)rcount[p], hipMemcpyDeviceToHost, st));
+    MGCR_HIP(hipStreamSynchronize(st));
+    return MGCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// partition plan (host only)
+// ------------------------------------------------------------------------------------------------
+struct Plan {
+    Comm *comm = nullptr;
+    int64_t n_global = 0, row0 = 0, nloc = 0, nnz = 0;
+    std::vector<int64_t> offsets;       // row0 of every rank, + n_global
+    std::vector<int64_t> halo_gid;      // sorted global ids of the remote columns (grouped by owner, ascending)
+    std::vector<int32_t> peers;         // ranks exchanged with (ascending)
+    std::vector<int64_t> recv_count, recv_off;            // per peer: entries of the halo segment
+    std::vector<std::vector<int64_t>> send_rows;          // per peer: my local rows it needs, in its halo order
+    std::vector<int64_t> col_local;     // nnz
+    int64_t interior_begin = 0, interior_end = 0;         // rows [begin, end) reference no halo column
+};
+
+bool comm_collectives(Comm *c);
+
+static int owner_of(const std::vector<int64_t> &offsets, int64_t gid) {
+    return (int)(std::upper_bound(offsets.begin(), offsets.end(), gid) - offsets.begin()) - 1;
+}
+
+static int plan_build(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col, Plan **out) {
+    MGCR_CHECK(c && rowptr && row0 >= 0 && nloc >= 0 && row0 + nloc <= n_global, MGCR_ERR_INVALID, "mgcr_plan_create: bad row block");
+    Plan *P = new Plan();
+    P->comm = c; P->n_global = n_global; P->row0 = row0; P->nloc = nloc; P->nnz = rowptr[nloc];
+    const int R = c->nranks;
+    // row offsets of all ranks
+    std::vector<double> tmp((size_t)R + 0, 0.);
+    tmp[(size_t)c->rank] = (double)row0;
+    int rc = comm_allreduce_host(c, tmp.data(), R);
+    if (rc != MGCR_OK) { delete P; return rc; }
+    P->offsets.resize((size_t)R + 1);
+    for (int r = 0; r < R; r++) P->offsets[(size_t)r] = (int64_t)tmp[(size_t)r];
+    P->offsets[(size_t)R] = n_global;
+    for (int r = 0; r < R; r++)
+        if (P->offsets[(size_t)r] > P->offsets[(size_t)r + 1]) {
+            delete P;
+            set_error("mgcr_plan_create: row blocks must be ordered by rank and contiguous");
+            return MGCR_ERR_INVALID;
+        }
+    // remote columns
+    std::vector<int64_t> remote;
+    for (int64_t l = 0; l < P->nnz; l++) {
+        int64_t g = col[l];
+        if (g < 0 || g >= n_global) { delete P; set_error("mgcr_plan_create: column %lld out of range", (long long)g); return MGCR_ERR_INVALID; }
+        if (g < row0 || g >= row0 + nloc) remote.push_back(g);
+    }
+    std::sort(remote.begin(), remote.end());
+    remote.erase(std::unique(remote.begin(), remote.end()), remote.end());
+    P->halo_gid = remote;  // ascending global id == grouped by owner rank
+    std::map<int64_t, int64_t> slot;
+    for (size_t h = 0; h < remote.size(); h++) slot[remote[h]] = (int64_t)h;
+    // what I need from whom
+    std::vector<int64_t> need_cnt((size_t)R, 0);
+    for (int64_t g : remote) need_cnt[(size_t)owner_of(P->offsets, g)]++;
+    // counts matrix: cnt[r][q] = number of entries rank r needs from rank q
+    std::vector<double> M((size_t)R * R, 0.);
+    for (int q = 0; q < R; q++) M[(size_t)c->rank * R + q] = (double)need_cnt[(size_t)q];
+    rc = comm_allreduce_host(c, M.data(), (int64_t)R * R);
+    if (rc != MGCR_OK) { delete P; return rc; }
+    for (int q = 0; q < R; q++) {
+        if (q == c->rank) continue;
+        int64_t rc_ = (int64_t)M[(size_t)c->rank * R + q], sc_ = (int64_t)M[(size_t)q * R + c->rank];
+        if (rc_ || sc_) P->peers.push_back(q);
+    }
+    const int np = (int)P->peers.size();
+    P->recv_count.assign((size_t)np, 0);
+    P->recv_off.assign((size_t)np, 0);
+    P->send_rows.assign((size_t)np, {});
+    std::vector<int64_t> send_count((size_t)np, 0);
+    int64_t off = 0;
+    for (int p = 0; p < np; p++) {
+        int q = P->peers[(size_t)p];
+        P->recv_count[(size_t)p] = (int64_t)M[(size_t)c->rank * R + q];
+        P->recv_off[(size_t)p] = off;
+        off += P->recv_count[(size_t)p];
+        send_count[(size_t)p] = (int64_t)M[(size_t)q * R + c->rank];
+        P->send_rows[(size_t)p].resize((size_t)send_count[(size_t)p]);
+    }
+    // tell every peer which of its rows I need (global ids, sent as bit patterns in doubles)
+    {
+        std::vector<const double *> sp((size_t)np);
+        std::vector<double *> rp((size_t)np);
+        std::vector<int64_t> sc((size_t)np), rcv((size_t)np);
+        for (int p = 0; p < np; p++) {
+            sp[(size_t)p] = reinterpret_cast<const double *>(P->halo_gid.data() + P->recv_off[(size_t)p]);
+            sc[(size_t)p] = P->recv_count[(size_t)p];
+            rp[(size_t)p] = reinterpret_cast<double *>(P->send_rows[(size_t)p].data());
+            rcv[(size_t)p] = send_count[(size_t)p];
+        }
+        rc = comm_exchange_host(c, np, P->peers.data(), sp.data(), sc.data(), rp.data(), rcv.data());
+        if (rc != MGCR_OK) { delete P; return rc; }
+        for (int p = 0; p < np; p++)
+            for (int64_t &g : P->send_rows[(size_t)p]) {
+                if (g < row0 || g >= row0 + nloc) { delete P; set_error("mgcr_plan_create: peer asked for a row this rank does not own"); return MGCR_ERR_COMM; }
+                g -= row0;
+            }
+    }
+    // local column numbering and the interior row range
+    P->col_local.resize((size_t)P->nnz);
+    int64_t first_b = nloc, last_b = -1;
+    std::vector<char> touches((size_t)nloc, 0);
+    for (int64_t r = 0; r < nloc; r++)
+        for (int64_t l = rowptr[r]; l < rowptr[r + 1]; l++) {
+            int64_t g = col[l];
+            if (g >= row0 && g < row0 + nloc) P->col_local[(size_t)l] = g - row0;
+            else { P->col_local[(size_t)l] = nloc + slot[g]; touches[(size_t)r] = 1; }
+        }
+    // longest run of rows without halo columns (for a slab partition: everything but the first and last plane)
+    int64_t best_b = 0, best_e = 0, cur_b = 0;
+    for (int64_t r = 0; r <= nloc; r++) {
+        if (r == nloc || touches[(size_t)r]) {
+            if (r - cur_b > best_e - best_b) { best_b = cur_b; best_e = r; }
+            cur_b = r + 1;
+        }
+    }
+    (void)first_b; (void)last_b;
+    P->interior_begin = best_b;
+    P->interior_end = best_e;
+    *out = P;
+    return MGCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// distributed operator state
+// ------------------------------------------------------------------------------------------------
+struct DistCsr {
+    Comm *comm = nullptr;
+    Plan *plan = nullptr;
+    cplx *xh = nullptr;        // halo segment [n_halo]
+    cplx *sendbuf = nullptr;   // packed send data (all peers)
+    int32_t *send_idx = nullptr;
+    std::vector<int64_t> send_off, send_cnt;
+    std::vector<int64_t> send_contig;  // >= 0: the peer's rows are the contiguous range starting here (no packing)
+    std::vector<double> h_send, h_recv;  // host staging (callback transport)
+};
+
+__global__ void __launch_bounds__(256) pack_kernel(int64_t n, const int32_t *__restrict__ idx, const cplx *__restrict__ x,
+                                                   cplx *__restrict__ out, const int *__restrict__ skip) {
+    if (skip && *skip) return;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = x[idx[i]];
+}
+
+int dist_halo_begin(DistCsr *d, const cplx *x) {
+    Comm *c = d->comm;
+    Plan *P = d->plan;
+    const int np = (int)P->peers.size();
+    if (np == 0) return MGCR_OK;
+    hipStream_t main = ctx().stream;
+    int64_t tot_send = d->send_off.empty() ? 0 : d->send_off.back() + d->send_cnt.back();
+    // pack the non-contiguous send lists
+    for (int p = 0; p < np; p++)
+        if (d->send_contig[(size_t)p] < 0 && d->send_cnt[(size_t)p]) {
+            hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((d->send_cnt[(size_t)p] + 255) / 256)), dim3(256), 0, main,
+                               d->send_cnt[(size_t)p], d->send_idx + d->send_off[(size_t)p], x, d->sendbuf + d->send_off[(size_t)p],
+                               get_apply_skip_flag());
+            MGCR_HIP(hipGetLastError());
+        }
+    if (c->is_rccl) {
+        MGCR_HIP(hipEventRecord(c->ev_ready, main));
+        MGCR_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+        MGCR_NCCL(rccl().GroupStart());
+        for (int p = 0; p < np; p++) {
+            const cplx *src = d->send_contig[(size_t)p] >= 0 ? x + d->send_contig[(size_t)p] : d->sendbuf + d->send_off[(size_t)p];
+            if (d->send_cnt[(size_t)p])
+                MGCR_NCCL(rccl().Send(src, (size_t)d->send_cnt[(size_t)p] * 2, ncclDouble, P->peers[(size_t)p], c->nccl, c->comm_stream));
+            if (P->recv_count[(size_t)p])
+                MGCR_NCCL(rccl().Recv(d->xh + P->recv_off[(size_t)p], (size_t)P->recv_count[(size_t)p] * 2, ncclDouble, P->peers[(size_t)p], c->nccl, c->comm_stream));
+        }
+        MGCR_NCCL(rccl().GroupEnd());
+        MGCR_HIP(hipEventRecord(c->ev_done, c->comm_stream));
+        return MGCR_OK;
+    }
+    // host-staged transport: device -> host, callback, host -> device (synchronous)
+    d->h_send.resize((size_t)tot_send * 2);
+    d->h_recv.resize(P->halo_gid.size() * 2);
+    for (int p = 0; p < np; p++) {
+        const cplx *src = d->send_contig[(size_t)p] >= 0 ? x + d->send_contig[(size_t)p] : d->sendbuf + d->send_off[(size_t)p];
+        if (d->send_cnt[(size_t)p])
+            MGCR_HIP(hipMemcpyAsync(d->h_send.data() + 2 * d->send_off[(size_t)p], src, sizeof(cplx) * (size_t)d->send_cnt[(size_t)p], hipMemcpyDeviceToHost, main));
+    }
+    MGCR_HIP(hipStreamSynchronize(main));
+    std::vector<const double *> sp((size_t)np);
+    std::vector<double *> rp((size_t)np);
+    std::vector<int64_t> sc((size_t)np), rcv((size_t)np);
+    for (int p = 0; p < np; p++) {
+        sp[(size_t)p] = d->h_send.data() + 2 * d->send_off[(size_t)p];
+        sc[(size_t)p] = 2 * d->send_cnt[(size_t)p];
+        rp[(size_t)p] = d->h_recv.data() + 2 * P->recv_off[(size_t)p];
+        rcv[(size_t)p] = 2 * P->recv_count[(size_t)p];
+    }
+    MGCR_TRY(comm_exchange_host(c, np, P->peers.data(), sp.data(), sc.data(), rp.data(), rcv.data()));
+    if (!P->halo_gid.empty())
+        MGCR_HIP(hipMemcpyAsync(d->xh, d->h_recv.data(), sizeof(cplx) * P->halo_gid.size(), hipMemcpyHostToDevice, main));
+    return MGCR_OK;
+}
+
+int dist_halo_end(DistCsr *d) {
+    Comm *c = d->comm;
+    if (c->is_rccl && !d->plan->peers.empty()) MGCR_HIP(hipStreamWaitEvent(ctx().stream, c->ev_done, 0));
+    return MGCR_OK;
+}
+
+void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *interior_end) {
+    *xh = d->xh;
+    *interior_begin = d->plan->interior_begin;
+    *interior_end = d->plan->interior_end;
+}
+
+Comm *dist_comm(DistCsr *d) { return d->comm; }
+
+void dist_free(DistCsr *d) {
+    if (!d) return;
+    hipFree(d->xh); hipFree(d->sendbuf); hipFree(d->send_idx);
+    delete d->plan;
+    delete d;
+}
+
+int comm_nranks(Comm *c) { return c ? c->nranks : 1; }
+
+// does a solve on this communicator go through the fold + all-reduce path?  (MGCR_TEST_FORCE_COLLECTIVES=1
+// turns it on for a 1-rank communicator too, so that the RCCL calls can be exercised on a single GPU)
+bool comm_collectives(Comm *c) {
+    if (!c) return false;
+    if (c->nranks > 1) return true;
+    static const bool force = getenv("MGCR_TEST_FORCE_COLLECTIVES") && atoi(getenv("MGCR_TEST_FORCE_COLLECTIVES")) != 0;
+    return force;
+}
+
+// in-place sum over ranks of `count` doubles in device memory, ordered on the compute stream
+int comm_allreduce_dev(Comm *c, double *dbuf, int count) {
+    if (!c || !comm_collectives(c)) return MGCR_OK;
+    hipStream_t st = ctx().stream;
+    if (c->is_rccl) {
+        MGCR_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, c->nccl, st));
+        return MGCR_OK;
+    }
+    MGCR_TRY(comm_device_ready(c));
+    MGCR_CHECK(count <= 1024, MGCR_ERR_UNSUPPORTED, "all-reduce of %d scalars exceeds the staging buffer", count);
+    MGCR_HIP(hipMemcpyAsync(c->h_pin, dbuf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+    MGCR_HIP(hipStreamSynchronize(st));
+    MGCR_TRY(comm_allreduce_host(c, c->h_pin, count));
+    MGCR_HIP(hipMemcpyAsync(dbuf, c->h_pin, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, st));
+    MGCR_HIP(hipStreamSynchronize(st));  // h_pin is reused by the next call
+    return MGCR_OK;
+}
+
+int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col,
+                    const double *val_ri, Op *op) {
+    Plan *P = nullptr;
+    MGCR_TRY(plan_build(c, n_global, row0, nloc, rowptr, col, &P));
+    DistCsr *d = new DistCsr();
+    d->comm = c;
+    d->plan = P;
+    const int64_t nh = (int64_t)P->halo_gid.size();
+    int rc = csr_build_device(nloc, nloc + nh, rowptr, P->col_local.data(), val_ri, &op->csr);
+    if (rc != MGCR_OK) { dist_free(d); return rc; }
+    std::vector<int64_t>().swap(P->col_local);
+    const int np = (int)P->peers.size();
+    int64_t off = 0;
+    std::vector<int32_t> idx;
+    for (int p = 0; p < np; p++) {
+        const std::vector<int64_t> &rows = P->send_rows[(size_t)p];
+        d->send_off.push_back(off);
+        d->send_cnt.push_back((int64_t)rows.size());
+        bool contig = !rows.empty();
+        for (size_t i = 1; i < rows.size() && contig; i++) contig = rows[i] == rows[i - 1] + 1;
+        d->send_contig.push_back(contig ? rows[0] : -1);
+        for (int64_t r : rows) idx.push_back((int32_t)r);
+        off += (int64_t)rows.size();
+    }
+    hipError_t e = hipSuccess;
+    if (nh) e = hipMalloc((void **)&d->xh, sizeof(cplx) * (size_t)nh);
+    if (e == hipSuccess && off) e = hipMalloc((void **)&d->sendbuf, sizeof(cplx) * (size_t)off);
+    if (e == hipSuccess && off) e = hipMalloc((void **)&d->send_idx, sizeof(int32_t) * (size_t)off);
+    if (e == hipSuccess && off) e = hipMemcpy(d->send_idx, idx.data(), sizeof(int32_t) * (size_t)off, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        csr_free(&op->csr);
+        dist_free(d);
+        set_error("dist_csr_create: device allocation failed: %s", hipGetErrorString(e));
+        return MGCR_ERR_ALLOC;
+    }
+    if (c->is_rccl || true) rc = comm_device_ready(c);
+    if (rc != MGCR_OK) { csr_free(&op->csr); dist_free(d); return rc; }
+    op->dist = d;
+    op->comm = c;
+    return MGCR_OK;
+}
+
+}  // namespace mgcr
+
+using namespace mgcr;
+struct mgcr_comm_s : mgcr::Comm {};
+struct mgcr_plan_s : mgcr::Plan {};
+
+#define LOCK() std::lock_guard<std::recursive_mutex> lk__(ctx().mtx)
+
+extern "C" {
+
+int mgcr_rccl_unique_id(void *id128) {
+    MGCR_CHECK(id128, MGCR_ERR_INVALID, "null id buffer");
+    MGCR_TRY(rccl_load());
+    ncclUniqueId id;
+    MGCR_NCCL(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == MGCR_RCCL_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof(id));
+    return MGCR_OK;
+}
+
+int mgcr_comm_create_rccl(int rank, int nranks, const void *id128, mgcr_comm_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(out && id128 && nranks >= 1 && rank >= 0 && rank < nranks, MGCR_ERR_INVALID, "mgcr_comm_create_rccl: bad argument");
+    MGCR_TRY(rccl_load());
+    LOCK();
+    mgcr_comm_s *c = new mgcr_comm_s();
+    c->rank = rank; c->nranks = nranks; c->is_rccl = true;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = rccl().CommInitRank(&c->nccl, nranks, id, rank);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitRank failed: %s", rccl().GetErrorString(r));
+        delete c;
+        return MGCR_ERR_COMM;
+    }
+    int rc = comm_device_ready(c);
+    if (rc != MGCR_OK) { delete c; return rc; }
+    *out = c;
+    return MGCR_OK;
+}
+
+int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgcr_exchange_cb exchange, void *user, mgcr_comm_t *out) {
+    MGCR_CHECK(out && nranks >= 1 && rank >= 0 && rank < nranks && (nranks == 1 || (allreduce && exchange)), MGCR_ERR_INVALID,
+               "mgcr_comm_create_host: bad argument");
+    mgcr_comm_s *c = new mgcr_comm_s();
+    c->rank = rank; c->nranks = nranks; c->is_rccl = false;
+    c->allreduce = allreduce; c->exchange = exchange; c->user = user;
+    *out = c;
+    return MGCR_OK;
+}
+
+int mgcr_comm_destroy(mgcr_comm_t c) {
+    if (!c) return MGCR_OK;
+    if (ctx().ready) {
+        hipStreamSynchronize(ctx().stream);
+        if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    }
+    if (c->is_rccl && c->nccl) rccl().CommDestroy(c->nccl);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    if (c->ev_ready) hipEventDestroy(c->ev_ready);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->d_stage) hipFree(c->d_stage);
+    if (c->h_pin) hipHostFree(c->h_pin);
+    delete c;
+    return MGCR_OK;
+}
+
+int mgcr_plan_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t nrow_local, const int64_t *rowptr,
+                     const int64_t *col_global, mgcr_plan_t *out) {
+    MGCR_CHECK(comm && out && rowptr, MGCR_ERR_INVALID, "mgcr_plan_create: null argument");
+    Plan *P = nullptr;
+    MGCR_TRY(plan_build(comm, n_global, row0, nrow_local, rowptr, col_global, &P));
+    *out = static_cast<mgcr_plan_s *>(P);
+    return MGCR_OK;
+}
+
+int mgcr_plan_info(mgcr_plan_t plan, int64_t *n_halo, int32_t *npeers, int64_t *interior_begin, int64_t *interior_end) {
+    MGCR_CHECK(plan, MGCR_ERR_INVALID, "null plan");
+    if (n_halo) *n_halo = (int64_t)plan->halo_gid.size();
+    if (npeers) *npeers = (int32_t)plan->peers.size();
+    if (interior_begin) *interior_begin = plan->interior_begin;
+    if (interior_end) *interior_end = plan->interior_end;
+    return MGCR_OK;
+}
+
+int mgcr_plan_peers(mgcr_plan_t plan, int32_t *peers, int64_t *send_counts, int64_t *recv_counts) {
+    MGCR_CHECK(plan, MGCR_ERR_INVALID, "null plan");
+    for (size_t p = 0; p < plan->peers.size(); p++) {
+        if (peers) peers[p] = plan->peers[p];
+        if (send_counts) send_counts[p] = (int64_t)plan->send_rows[p].size();
+        if (recv_counts) recv_counts[p] = plan->recv_count[p];
+    }
+    return MGCR_OK;
+}
+
+int mgcr_plan_local_columns(mgcr_plan_t plan, int64_t *col_local) {
+    MGCR_CHECK(plan && col_local, MGCR_ERR_INVALID, "null argument");
+    MGCR_CHECK((int64_t)plan->col_local.size() == plan->nnz, MGCR_ERR_INVALID, "plan no longer holds its column map");
+    memcpy(col_local, plan->col_local.data(), sizeof(int64_t) * (size_t)plan->nnz);
+    return MGCR_OK;
+}
+
+int mgcr_plan_send_indices(mgcr_plan_t plan, int32_t peer_slot, int64_t *local_rows) {
+    MGCR_CHECK(plan && local_rows && peer_slot >= 0 && peer_slot < (int32_t)plan->peers.size(), MGCR_ERR_INVALID, "bad argument");
+    const std::vector<int64_t> &r = plan->send_rows[(size_t)peer_slot];
+    memcpy(local_rows, r.data(), sizeof(int64_t) * r.size());
+    return MGCR_OK;
+}
+
+int mgcr_plan_halo_globals(mgcr_plan_t plan, int64_t *global_cols) {
+    MGCR_CHECK(plan && global_cols, MGCR_ERR_INVALID, "null argument");
+    memcpy(global_cols, plan->halo_gid.data(), sizeof(int64_t) * plan->halo_gid.size());
+    return MGCR_OK;
+}
+
+int mgcr_plan_destroy(mgcr_plan_t plan) {
+    delete static_cast<mgcr::Plan *>(plan);
+    return MGCR_OK;
+}
+
+int mgcr_dcsr_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t nrow_local, const int64_t *rowptr,
+                     const int64_t *col_global, const double *val_ri, mgcr_op_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(comm && out && rowptr, MGCR_ERR_INVALID, "mgcr_dcsr_create: null argument");
+    LOCK();
+    mgcr_op_s *op = new mgcr_op_s();
+    op->kind = OP_CSR;
+    op->dim = nrow_local;
+    op->nrow = nrow_local;
+    int rc = dist_csr_create(comm, n_global, row0, nrow_local, rowptr, col_global, val_ri, op);
+    if (rc != MGCR_OK) { delete op; return rc; }
+    *out = op;
+    return MGCR_OK;
+}
+
+}  // extern "C"

@@ -63,6 +63,10 @@ struct GcrState {
     double *hist = nullptr;
     int hist_cap = 0;
     int partsB_dirs = 0;
+    // multi-GPU: folded scalars that are all-reduced over the ranks
+    double *dA = nullptr;   // [4]
+    double *dRB = nullptr;  // [1 + 2 * dirs]: |r|^2, then the beta numerators
+    double *dN = nullptr;   // [2]: |b|^2, |r0|^2
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -119,13 +123,13 @@ __global__ void __launch_bounds__(RED_THREADS) dot2_partials_kernel(const cplx *
 
 // step 0 bookkeeping (src/GCR.h:213-216)
 __global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const double *__restrict__ partsN, int nblkN,
-                                                           const double *__restrict__ partsR, int nblkR,
-                                                           double *__restrict__ hist) {
+                                                           int strideN, const double *__restrict__ partsR, int nblkR,
+                                                           int strideR, double *__restrict__ hist) {
     __shared__ double lds[17];
     if (st->done) return;
     double b[1], r[1];
-    fold_partials<1>(partsN, nblkN, b, lds);
-    fold_partials<1>(partsR, nblkR, r, lds);
+    fold_partials<1>(partsN, nblkN, strideN, b, lds);
+    fold_partials<1>(partsR, nblkR, strideR, r, lds);
     if (threadIdx.x == 0) {
         st->bnorm2 = b[0];
         st->rr = r[0];
@@ -135,14 +139,14 @@ __global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const d
 
 // alpha = <r,Ap>/<Ap,Ap>;  x = x + p*alpha;  r = r - Ap*alpha  (src/GCR.h:230-233) + |r|^2 partials
 __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *__restrict__ st, const double *__restrict__ partsA,
-                                                                int nblkA, const cplx *__restrict__ p,
+                                                                int nblkA, int strideA, const cplx *__restrict__ p,
                                                                 const cplx *__restrict__ ap, cplx *__restrict__ x,
                                                                 cplx *__restrict__ r, int64_t n, double *__restrict__ partsR,
                                                                 cplx *__restrict__ den_slot) {
     __shared__ double lds[4 * 17];
     if (st->done) return;
     double s[4];
-    fold_partials<4>(partsA, nblkA, s, lds);
+    fold_partials<4>(partsA, nblkA, strideA, s, lds);
     const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
     const cplx alpha = to_sgpr(cdiv(num, den));
     if (blockIdx.x == 0 && threadIdx.x == 0) *den_slot = den;
@@ -161,14 +165,10 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *
 // NDT is a template parameter so that the (1 + NDT) * U loads of one trip are issued back to back
 // with no branch between them: the kernel is latency-bound otherwise (a wave with a single 1-KiB
 // load in flight cannot cover HBM latency, even at 32 waves per CU).
-// When `book` is set, workgroup 0 also closes the step: folds |r|^2, bumps the iteration
-// counter, records the history entry and raises the convergence flag (src/GCR.h:270-274,288).
 template <int NDT, int U>
-__global__ void __launch_bounds__(RED_THREADS) multidot_kernel(DevState *__restrict__ st, const cplx *__restrict__ ar,
+__global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *__restrict__ st, const cplx *__restrict__ ar,
                                                                DirPtrs d, int base, int64_t n,
-                                                               double *__restrict__ partsB, int book,
-                                                               const double *__restrict__ partsR, int nblkR,
-                                                               double *__restrict__ hist, int hist_cap) {
+                                                               double *__restrict__ partsB) {
     __shared__ double lds[2 * NDT * 17];
     if (st->done) return;
     double v[2 * NDT];
@@ -208,9 +208,34 @@ __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(DevState *__restr
             if (j == (int)threadIdx.x) mine = v[j];
         partsB[(size_t)(2 * base + threadIdx.x) * RED_MAX_BLOCKS + blockIdx.x] = mine;
     }
+}
+
+// beta_j = <Ar,Aps_j>/<Aps_j,Aps_j>;  p_corr -= ps_j*beta_j;  Ap_corr -= Aps_j*beta_j  (src/GCR.h:257-262)
+// FIRST: accumulators start at 0 (else read from accp/accap); LAST: p' = dir + p_corr, Ap' = Ar + Ap_corr
+// are written to the ring slot (src/GCR.h:265-266,286-287) and <r,Ap'>, <Ap',Ap'> partials emitted.
+// RDIR: r is a different vector from dir (flexible preconditioning) and has to be loaded as well.
+// When `book` is set, workgroup 0 also closes the step (src/GCR.h:270-274,288): folds |r|^2, bumps
+// the iteration counter, records the history entry and raises the convergence flag.  The flag only
+// takes effect from the next kernel on, so this step's directions are still built, as in the
+// reference.
+template <int NDT, bool FIRST, bool LAST, bool RDIR>
+__global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict__ st, const double *__restrict__ partsB,
+                                                            int nblkB, int strideB, int book,
+                                                            const double *__restrict__ partsR, int nblkR, int strideR,
+                                                            double *__restrict__ hist, int hist_cap,
+                                                            const cplx *__restrict__ den, DirPtrs d, int base,
+                                                            const cplx *__restrict__ dir, const cplx *__restrict__ r,
+                                                            const cplx *__restrict__ ar, cplx *accp, cplx *accap,
+                                                            cplx *p_out, cplx *ap_out, int64_t n,
+                                                            double *__restrict__ partsA) {
+    __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
+    __shared__ cplx sbeta[NDT];
+    if (st->done) return;
+    double s[2 * NDT];
+    fold_partials<2 * NDT>(partsB + (size_t)(2 * base) * strideB, nblkB, strideB, s, lds);
     if (book && blockIdx.x == 0) {
         double rr[1];
-        fold_partials<1>(partsR, nblkR, rr, lds);
+        fold_partials<1>(partsR, nblkR, strideR, rr, lds);
         if (threadIdx.x == 0) {
             int it = st->iter + 1;
             st->iter = it;
@@ -220,24 +245,6 @@ __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(DevState *__restr
             if (!((rr[0] / st->bnorm2) > st->tol2)) st->done = 1;
         }
     }
-}
-
-// beta_j = <Ar,Aps_j>/<Aps_j,Aps_j>;  p_corr -= ps_j*beta_j;  Ap_corr -= Aps_j*beta_j  (src/GCR.h:257-262)
-// FIRST: accumulators start at 0 (else read from accp/accap); LAST: p' = dir + p_corr, Ap' = Ar + Ap_corr
-// are written to the ring slot (src/GCR.h:265-266,286-287) and <r,Ap'>, <Ap',Ap'> partials emitted.
-// RDIR: r is a different vector from dir (flexible preconditioning) and has to be loaded as well.
-template <int NDT, bool FIRST, bool LAST, bool RDIR>
-__global__ void __launch_bounds__(RED_THREADS) build_kernel(const DevState *__restrict__ st, const double *__restrict__ partsB,
-                                                            int nblkB, const cplx *__restrict__ den, DirPtrs d, int base,
-                                                            const cplx *__restrict__ dir, const cplx *__restrict__ r,
-                                                            const cplx *__restrict__ ar, cplx *accp, cplx *accap,
-                                                            cplx *p_out, cplx *ap_out, int64_t n,
-                                                            double *__restrict__ partsA) {
-    __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
-    __shared__ cplx sbeta[NDT];
-    if (st->done) return;
-    double s[2 * NDT];
-    fold_partials<2 * NDT>(partsB + (size_t)(2 * base) * RED_MAX_BLOCKS, nblkB, s, lds);
     if (threadIdx.x < NDT) {
         // s[] is identical in every thread; pick this thread's pair without dynamic register indexing
         cplx num = make_double2(0., 0.);
@@ -312,14 +319,14 @@ int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n) {
     MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
     switch (op->kind) {
         case OP_CSR:
-            MGCR_CHECK(op->csr.ncol == n, MGCR_ERR_INVALID, "Sparse matrix dimension does not match Field dimension!");
-            return csr_apply(op->csr, x, y, false, make_double2(0., 0.));
+            MGCR_CHECK((op->dist ? op->csr.nrow : op->csr.ncol) == n, MGCR_ERR_INVALID, "Sparse matrix dimension does not match Field dimension!");
+            return csr_apply(op->csr, x, y, false, make_double2(0., 0.), op->dist);
         case OP_DIRAC:
-            MGCR_CHECK(op->base->csr.ncol == n && op->base->csr.nrow == n, MGCR_ERR_INVALID,
+            MGCR_CHECK(op->base->csr.nrow == n && (op->base->dist || op->base->csr.ncol == n), MGCR_ERR_INVALID,
                        "DiracOp needs a square matrix matching the Field dimension");
             // assertm(k != 0., ...) src/Operator.h:571
             MGCR_CHECK(op->k.x != 0. || op->k.y != 0., MGCR_ERR_INVALID, "No k value supplied for Dirac Operator!");
-            return csr_apply(op->base->csr, x, y, true, op->k);
+            return csr_apply(op->base->csr, x, y, true, op->k, op->base->dist);
         case OP_BCSR:
             MGCR_CHECK((int64_t)op->bcsr.nbcol * op->bcsr.bs == n, MGCR_ERR_INVALID,
                        "Sparse matrix dimension does not match Field dimension!");
@@ -339,9 +346,9 @@ static void gcr_free_vectors(GcrState *s) {
     for (cplx *p : s->aps) hipFree(p);
     s->ps.clear(); s->aps.clear();
     hipFree(s->r); hipFree(s->ar); hipFree(s->z); hipFree(s->tmp); hipFree(s->accp); hipFree(s->accap);
-    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB);
+    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB); hipFree(s->dRB);
     s->r = s->ar = s->z = s->tmp = s->accp = s->accap = nullptr;
-    s->den = nullptr; s->hist = nullptr; s->partsB = nullptr;
+    s->den = nullptr; s->hist = nullptr; s->partsB = nullptr; s->dRB = nullptr;
     s->alloc_slots = 0; s->n = 0; s->partsB_dirs = 0; s->hist_cap = 0;
 }
 
@@ -350,6 +357,7 @@ void gcr_state_destroy(GcrState *s) {
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     gcr_free_vectors(s);
     hipFree(s->x0); hipFree(s->st); hipFree(s->partsA); hipFree(s->partsR); hipFree(s->partsN);
+    hipFree(s->dA); hipFree(s->dN);
     delete s;
 }
 
@@ -366,6 +374,8 @@ int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out
     if (rc == MGCR_OK) rc = dalloc(&s->partsA, 4 * RED_MAX_BLOCKS);
     if (rc == MGCR_OK) rc = dalloc(&s->partsR, RED_MAX_BLOCKS);
     if (rc == MGCR_OK) rc = dalloc(&s->partsN, RED_MAX_BLOCKS);
+    if (rc == MGCR_OK) rc = dalloc(&s->dA, 4);
+    if (rc == MGCR_OK) rc = dalloc(&s->dN, 2);
     if (rc != MGCR_OK) { gcr_state_destroy(s); return rc; }
     *out = s;
     return MGCR_OK;
@@ -421,6 +431,8 @@ static int gcr_prepare(GcrState *s, int64_t n) {
         MGCR_TRY(dalloc(&s->partsB, (size_t)2 * bd * RED_MAX_BLOCKS));
         MGCR_HIP(hipMemsetAsync(s->partsB, 0, sizeof(double) * (size_t)2 * bd * RED_MAX_BLOCKS, ctx().stream));
         s->partsB_dirs = bd;
+        MGCR_TRY(dalloc(&s->dRB, (size_t)1 + 2 * bd));
+        MGCR_HIP(hipMemsetAsync(s->dRB, 0, sizeof(double) * ((size_t)1 + 2 * bd), ctx().stream));
     }
     s->restart = restart;
     if (precond && !s->tmp) MGCR_TRY(dalloc(&s->tmp, (size_t)n));
@@ -447,9 +459,8 @@ struct SkipGuard {
     ~SkipGuard() { set_apply_skip_flag(prev); }
 };
 
-static int launch_multidot(int g, int nd, DevState *st, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB,
-                           int book, const double *partsR, int nblkR, double *hist, int hist_cap) {
-#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, ar, d, base, n, partsB, book, partsR, nblkR, hist, hist_cap)
+static int launch_multidot(int g, int nd, const DevState *st, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB) {
+#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, ar, d, base, n, partsB)
     switch (nd) {
         case 1: MD(1, 2); break;
         case 2: MD(2, 2); break;
@@ -464,11 +475,16 @@ static int launch_multidot(int g, int nd, DevState *st, const cplx *ar, const Di
     return MGCR_OK;
 }
 
+struct RedRef {  // where a consumer finds a reduction: slab of per-workgroup partials, or folded + all-reduced scalars
+    const double *p;
+    int nblk, stride;
+};
+
 template <int NDT>
-static int launch_build_n(int g, bool first, bool last, bool rdir, const DevState *st, const double *partsB, int nblkB,
-                          const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r, const cplx *ar,
-                          cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
-#define BK(F, L, R) KLAUNCH((build_kernel<NDT, F, L, R>), g, st, partsB, nblkB, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
+static int launch_build_n(int g, bool first, bool last, bool rdir, DevState *st, RedRef B, int book, RedRef R, double *hist,
+                          int hist_cap, const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r,
+                          const cplx *ar, cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
+#define BK(F, L, R_) KLAUNCH((build_kernel<NDT, F, L, R_>), g, st, B.p, B.nblk, B.stride, book, R.p, R.nblk, R.stride, hist, hist_cap, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
     if (first && last) { if (rdir) BK(true, true, true); else BK(true, true, false); }
     else if (first) BK(true, false, false);
     else if (last) { if (rdir) BK(false, true, true); else BK(false, true, false); }
@@ -477,10 +493,10 @@ static int launch_build_n(int g, bool first, bool last, bool rdir, const DevStat
     return MGCR_OK;
 }
 
-static int launch_build(int g, int nd, bool first, bool last, bool rdir, const DevState *st, const double *partsB, int nblkB,
-                        const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r, const cplx *ar,
+static int launch_build(int g, int nd, bool first, bool last, bool rdir, DevState *st, RedRef B, int book, RedRef R, double *hist,
+                        int hist_cap, const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r, const cplx *ar,
                         cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
-#define LB(NDT) return launch_build_n<NDT>(g, first, last, rdir, st, partsB, nblkB, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
+#define LB(NDT) return launch_build_n<NDT>(g, first, last, rdir, st, B, book, R, hist, hist_cap, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
     switch (nd) {
         case 1: LB(1);
         case 2: LB(2);
@@ -527,10 +543,29 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         if (p.right_precond) { MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
         if (p.left_precond) { MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
     }
+    // Reductions.  Single GPU: consumers fold the producers' per-workgroup partials themselves.
+    // Multi-GPU: a one-workgroup fold writes the local sums, RCCL all-reduces them in place on the
+    // compute stream, and consumers read the global scalars (stride 1, one "partial").
+    Comm *comm = s->A->kind == OP_DIRAC ? s->A->base->comm : s->A->comm;
+    const bool multi = comm_collectives(comm);
+    MGCR_CHECK(!multi || (!p.left_precond && !p.right_precond), MGCR_ERR_UNSUPPORTED,
+               "preconditioned GCR on a distributed operator is not available yet");
     KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, s->st);
     KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, s->st);
     KLAUNCH(dot2_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, s->partsA, s->st);
-    KLAUNCH(init_kernel, 1, s->st, s->partsN, g, s->partsR, g, s->hist);
+    RedRef refA = {s->partsA, g, RED_MAX_BLOCKS}, refR = {s->partsR, g, RED_MAX_BLOCKS};
+    if (multi) {
+        MGCR_TRY(k_fold(s->partsN, g, 1, s->dN));
+        MGCR_TRY(k_fold(s->partsR, g, 1, s->dN + 1));
+        MGCR_TRY(comm_allreduce_dev(comm, s->dN, 2));
+        MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
+        MGCR_TRY(comm_allreduce_dev(comm, s->dA, 4));
+        KLAUNCH(init_kernel, 1, s->st, (const double *)s->dN, 1, 1, (const double *)(s->dN + 1), 1, 1, s->hist);
+        refA = {s->dA, 1, 1};
+        refR = {s->dRB, 1, 1};
+    } else {
+        KLAUNCH(init_kernel, 1, s->st, (const double *)s->partsN, g, RED_MAX_BLOCKS, (const double *)s->partsR, g, RED_MAX_BLOCKS, s->hist);
+    }
 
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
     int check_every = p.check_every > 0 ? p.check_every : 10;
@@ -540,7 +575,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         global++;
         iter_count++;
         // alpha, x, r
-        KLAUNCH(xr_update_kernel, g, (const DevState *)s->st, (const double *)s->partsA, g, (const cplx *)s->ps[cur],
+        KLAUNCH(xr_update_kernel, g, (const DevState *)s->st, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
                 (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur);
         const cplx *dir = s->r;
         if (flex) {
@@ -571,8 +606,14 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 int sl = ch * ND + (j < nd ? j : 0);
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
-            MGCR_TRY(launch_multidot(g, nd, s->st, (const cplx *)s->ar, d, ch * ND, n, s->partsB, ch == nchunk - 1 ? 1 : 0,
-                                     (const double *)s->partsR, g, s->hist, s->hist_cap));
+            MGCR_TRY(launch_multidot(g, nd, (const DevState *)s->st, (const cplx *)s->ar, d, ch * ND, n, s->partsB));
+        }
+        RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
+        if (multi) {  // one all-reduce for |r|^2 and all beta numerators of the step
+            MGCR_TRY(k_fold(s->partsR, g, 1, s->dRB));
+            MGCR_TRY(k_fold(s->partsB, g, 2 * lim, s->dRB + 1));
+            MGCR_TRY(comm_allreduce_dev(comm, s->dRB, 1 + 2 * lim));
+            refB = {s->dRB + 1, 1, 1};
         }
         for (int ch = 0; ch < nchunk; ch++) {
             DirPtrs d;
@@ -581,9 +622,13 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 int sl = ch * ND + (j < nd ? j : 0);
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
-            MGCR_TRY(launch_build(g, nd, ch == 0, ch == nchunk - 1, dir != s->r, (const DevState *)s->st,
-                                  (const double *)s->partsB, g, (const cplx *)s->den, d, ch * ND, dir, (const cplx *)s->r,
+            MGCR_TRY(launch_build(g, nd, ch == 0, ch == nchunk - 1, dir != s->r, s->st, refB, ch == nchunk - 1 ? 1 : 0, refR,
+                                  s->hist, s->hist_cap, (const cplx *)s->den, d, ch * ND, dir, (const cplx *)s->r,
                                   (const cplx *)s->ar, s->accp, s->accap, s->ps[nxt], s->aps[nxt], n, s->partsA));
+        }
+        if (multi) {
+            MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
+            MGCR_TRY(comm_allreduce_dev(comm, s->dA, 4));
         }
         iter_count = ic_next;
         cur = nxt;

@@ -96,6 +96,8 @@ struct BcsrDev {
 
 struct GcrState;
 struct MgState;
+struct Comm;
+struct DistCsr;
 
 struct Op {
     OpKind kind;
@@ -106,6 +108,8 @@ struct Op {
     BcsrDev bcsr;        // OP_BCSR
     GcrState *gcr = nullptr;  // OP_GCR
     MgState *mg = nullptr;    // OP_MG
+    DistCsr *dist = nullptr;  // OP_CSR row block of a distributed matrix (comm.hip)
+    Comm *comm = nullptr;     // communicator the operator's Fields are distributed over (borrowed)
 };
 
 // ---- blas1.hip -------------------------------------------------------------------------------
@@ -124,8 +128,8 @@ int k_fold(const double *parts, int nblk, int nscal, double *out_dev);
 int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *h_col,
                      const double *h_val_ri, CsrDev *out);
 void csr_free(CsrDev *c);
-// y = A x   or (shift) y = x - k*(A x)
-int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k);
+// y = A x   or (shift) y = x - k*(A x); dist != nullptr: row block with halo exchange
+int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
                       const double *h_blocks, BcsrDev *out);
 void bcsr_free(BcsrDev *b);
@@ -140,6 +144,15 @@ struct HostCsr {
 int csr_download_host(const CsrDev &A, HostCsr *out);
 void set_apply_skip_flag(const int *flag);
 const int *get_apply_skip_flag();
+
+// ---- comm.hip --------------------------------------------------------------------------------
+int dist_halo_begin(DistCsr *d, const cplx *x);
+int dist_halo_end(DistCsr *d);
+void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *interior_end);
+void dist_free(DistCsr *d);
+int comm_nranks(Comm *c);
+bool comm_collectives(Comm *c);
+int comm_allreduce_dev(Comm *c, double *dbuf, int count);
 
 // ---- mg.hip ----------------------------------------------------------------------------------
 int mg_create(Op *A, const mgcr_mg_param *p, MgState **out);

@@ -63,12 +63,14 @@ __device__ __forceinline__ void block_sum_bcast(double (&v)[NV], double *lds) {
     __syncthreads();
 }
 
-// Fold a partial slab parts[k][RED_MAX_BLOCKS] (nblk valid entries per scalar) to NV totals,
+// Fold a partial slab parts[k * stride + blk] (nblk valid entries per scalar) to NV totals,
 // identically in every workgroup that calls it (blockDim.x must be >= RED_MAX_BLOCKS).
+// stride = RED_MAX_BLOCKS for a slab written by a producer kernel; stride = 1, nblk = 1 for scalars
+// that were already folded and all-reduced over the ranks (multi-GPU).
 template <int NV>
-__device__ __forceinline__ void fold_partials(const double *__restrict__ parts, int nblk, double (&v)[NV], double *lds) {
+__device__ __forceinline__ void fold_partials(const double *__restrict__ parts, int nblk, int stride, double (&v)[NV], double *lds) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = (threadIdx.x < nblk) ? parts[k * RED_MAX_BLOCKS + threadIdx.x] : 0.;
+    for (int k = 0; k < NV; k++) v[k] = ((int)threadIdx.x < nblk) ? parts[(size_t)k * stride + threadIdx.x] : 0.;
     block_sum_bcast<NV>(v, lds);
 }
 

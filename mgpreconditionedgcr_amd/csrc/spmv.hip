@@ -10,6 +10,7 @@
 // 16-B-per-lane streams of the matrix, L2/MALL-served gathers of x, and wave64 shuffle / LDS
 // reductions.  No MFMA.
 #include <algorithm>
+#include <climits>
 
 #include "internal.h"
 #include "reduce.h"
@@ -227,16 +228,24 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
 }
 
 // L = 1: one thread per row, entries in CSR order (bit-identical to the reference's row sum)
+// gather of x: columns >= n_own live in the halo segment xh (multi-GPU row blocks); n_own is
+// INT32_MAX and xh unused otherwise
+__device__ __forceinline__ cplx gather_x(const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own, int32_t j) {
+    return j < n_own ? x[j] : xh[j - n_own];
+}
+
 template <int WT, bool SHIFT, bool XCD>
-__global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t nrow, int64_t npad, int32_t Wrt, int64_t ntiles,
-                                                          const cplx *__restrict__ val, const int32_t *__restrict__ col,
-                                                          const cplx *__restrict__ x, cplx *__restrict__ y, cplx k,
-                                                          const int *__restrict__ skip) {
+__global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int64_t row_count, int64_t npad, int32_t Wrt,
+                                                          int64_t ntiles, const cplx *__restrict__ val,
+                                                          const int32_t *__restrict__ col, const cplx *__restrict__ x,
+                                                          const cplx *__restrict__ xh, int32_t n_own,
+                                                          cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
     if (skip && *skip) return;
     int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
-    int64_t row = tile * 256 + threadIdx.x;
-    if (row >= nrow) return;
+    int64_t rloc = tile * 256 + threadIdx.x;
+    if (rloc >= row_count) return;
+    int64_t row = row_begin + rloc;
     const int32_t W = WT ? WT : Wrt;
     cplx sum = make_double2(0., 0.);
     if (WT) {
@@ -248,13 +257,13 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t nrow, int64_t 
             j[c] = col[(int64_t)c * npad + row];
         }
 #pragma unroll
-        for (int32_t c = 0; c < W; c++) sum = cadd(sum, cmul(v[c], x[j[c]]));
+        for (int32_t c = 0; c < W; c++) sum = cadd(sum, cmul(v[c], gather_x(x, xh, n_own, j[c])));
     } else {
 #pragma unroll 4
         for (int32_t c = 0; c < W; c++) {
             cplx v = val[(int64_t)c * npad + row];
             int32_t j = col[(int64_t)c * npad + row];
-            sum = cadd(sum, cmul(v, x[j]));
+            sum = cadd(sum, cmul(v, gather_x(x, xh, n_own, j)));
         }
     }
     y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
@@ -262,20 +271,22 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t nrow, int64_t 
 
 // L in {2,4,8,16}: L consecutive lanes share a row; per chunk the (row, lane) pairs are contiguous
 template <int L, bool SHIFT>
-__global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t nrow, int64_t npad, int32_t nchunk,
+__global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t row_count, int64_t npad, int32_t nchunk,
                                                       const cplx *__restrict__ val, const int32_t *__restrict__ col,
-                                                      const cplx *__restrict__ x, cplx *__restrict__ y, cplx k,
-                                                      const int *__restrict__ skip) {
+                                                      const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
+                                                      cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
     if (skip && *skip) return;
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int64_t row = t / L;
+    int64_t rloc = t / L;
+    int64_t row = row_begin + rloc;
+    int64_t nrow = row_begin + row_count;
     int l = (int)(t % L);
     cplx sum = make_double2(0., 0.);
     if (row < nrow) {
 #pragma unroll 4
         for (int32_t c = 0; c < nchunk; c++) {
             int64_t idx = ((int64_t)c * npad + row) * L + l;
-            sum = cadd(sum, cmul(val[idx], x[col[idx]]));
+            sum = cadd(sum, cmul(val[idx], gather_x(x, xh, n_own, col[idx])));
         }
     }
 #pragma unroll
@@ -292,6 +303,7 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
                                                        const int32_t *__restrict__ tail_ptr,
                                                        const int32_t *__restrict__ tail_col,
                                                        const cplx *__restrict__ tail_val, const cplx *__restrict__ x,
+                                                       const cplx *__restrict__ xh, int32_t n_own,
                                                        cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
     if (skip && *skip) return;
     int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -299,7 +311,7 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
     if (wave >= n_tail_rows) return;
     int32_t beg = tail_ptr[wave], end = tail_ptr[wave + 1];
     cplx sum = make_double2(0., 0.);
-    for (int32_t i = beg + lane; i < end; i += 64) sum = cadd(sum, cmul(tail_val[i], x[tail_col[i]]));
+    for (int32_t i = beg + lane; i < end; i += 64) sum = cadd(sum, cmul(tail_val[i], gather_x(x, xh, n_own, tail_col[i])));
     sum.x = wave_sum(sum.x);
     sum.y = wave_sum(sum.y);
     if (lane == 0) {
@@ -312,26 +324,27 @@ static const int *g_skip_flag = nullptr;  // device flag consulted by apply kern
 void set_apply_skip_flag(const int *flag) { g_skip_flag = flag; }
 const int *get_apply_skip_flag() { return g_skip_flag; }
 
+// rows [row_begin, row_begin + row_count) of the ELL part
 template <bool SHIFT>
-static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k) {
+static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const cplx *x, const cplx *xh, int32_t n_own, cplx *y, cplx k) {
     Context &c = ctx();
-    if (A.nrow == 0) return MGCR_OK;
+    if (row_count <= 0) return MGCR_OK;
     if (A.L == 1) {
-        int64_t ntiles = (A.nrow + 255) / 256;
+        int64_t ntiles = (row_count + 255) / 256;
         bool xcd = ntiles >= 64;
         unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
-#define RT(WT, X)                                                                                                    \
-    hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X>), dim3(grid), dim3(256), 0, c.stream, A.nrow, A.npad, A.W, \
-                       ntiles, A.ell_val, A.ell_col, x, y, k, g_skip_flag)
+#define RT(WT, X)                                                                                                        \
+    hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, \
+                       A.W, ntiles, A.ell_val, A.ell_col, x, xh, n_own, y, k, g_skip_flag)
         if (A.W == 7) { if (xcd) RT(7, true); else RT(7, false); }
         else { if (xcd) RT(0, true); else RT(0, false); }
 #undef RT
     } else {
-        int64_t threads = A.nrow * A.L;
+        int64_t threads = row_count * A.L;
         unsigned grid = (unsigned)((threads + 255) / 256);
-#define LN(LL)                                                                                                     \
-    hipLaunchKernelGGL((ell_spmv_lanes<LL, SHIFT>), dim3(grid), dim3(256), 0, c.stream, A.nrow, A.npad, A.nchunk, \
-                       A.ell_val, A.ell_col, x, y, k, g_skip_flag)
+#define LN(LL)                                                                                                            \
+    hipLaunchKernelGGL((ell_spmv_lanes<LL, SHIFT>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, A.nchunk, \
+                       A.ell_val, A.ell_col, x, xh, n_own, y, k, g_skip_flag)
         switch (A.L) {
             case 2: LN(2); break;
             case 4: LN(4); break;
@@ -341,18 +354,40 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k) {
 #undef LN
     }
     MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
+template <bool SHIFT>
+static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr *dist) {
+    Context &c = ctx();
+    if (A.nrow == 0) return MGCR_OK;
+    const cplx *xh = nullptr;
+    int32_t n_own = INT32_MAX;
+    if (dist) {
+        // halo exchange on the communication stream, overlapped with the rows that need no halo
+        int64_t ib = 0, ie = 0;
+        dist_info(dist, &xh, &ib, &ie);
+        n_own = (int32_t)A.nrow;
+        MGCR_TRY(dist_halo_begin(dist, x));
+        MGCR_TRY(ell_rows<SHIFT>(A, ib, ie - ib, x, xh, n_own, y, k));
+        MGCR_TRY(dist_halo_end(dist));
+        MGCR_TRY(ell_rows<SHIFT>(A, 0, ib, x, xh, n_own, y, k));
+        MGCR_TRY(ell_rows<SHIFT>(A, ie, A.nrow - ie, x, xh, n_own, y, k));
+    } else {
+        MGCR_TRY(ell_rows<SHIFT>(A, 0, A.nrow, x, xh, n_own, y, k));
+    }
     if (A.n_tail_rows) {
         int64_t threads = A.n_tail_rows * 64;
         hipLaunchKernelGGL((csr_tail_kernel<SHIFT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream,
-                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, y, k, g_skip_flag);
+                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, g_skip_flag);
         MGCR_HIP(hipGetLastError());
     }
     return MGCR_OK;
 }
 
-int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k) {
+int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
-    return shift ? csr_apply_t<true>(A, x, y, k) : csr_apply_t<false>(A, x, y, k);
+    return shift ? csr_apply_t<true>(A, x, y, k, dist) : csr_apply_t<false>(A, x, y, k, dist);
 }
 
 // ------------------------------------------------------------------------------------------------

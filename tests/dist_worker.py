@@ -1,0 +1,118 @@
+"""Worker process of the multi-rank tests (launched by test_dist_cpu.py / test_gpu_dist.py).
+
+    python tests/dist_worker.py <mode> <rank> <world> <port> <outdir>
+
+modes
+  plan   (CPU, gloo)  partition plan + numpy SpMV through the plan's halo lists vs the global SpMV
+  gcr    (GPU, gloo-staged transport; all ranks may share GPU 0) distributed SpMV and GCR on the
+         HIP path vs what the caller computes in one process
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def split_rows(n, world):
+    base = n // world
+    offs = [r * base for r in range(world)] + [n]
+    return offs
+
+
+def problem(kind):
+    from mgpreconditionedgcr_amd import problems
+    if kind == "poisson":
+        n = 6
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        return N, rowptr, col, val, (n * n)  # rows per plane: slabs must hold whole planes
+    rng = np.random.default_rng(7)
+    N = 1000
+    rowptr, col, val = problems.random_csr(N, N, rng, min_len=1, max_len=9)
+    # diagonally dominant so that GCR converges
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    rowsum = np.bincount(rows, weights=np.abs(val), minlength=N)
+    newptr = rowptr + np.arange(N + 1)
+    ncol_arr, nval = np.empty(newptr[-1], np.int64), np.empty(newptr[-1], np.complex128)
+    for r in range(N):
+        s, e = rowptr[r], rowptr[r + 1]
+        ncol_arr[newptr[r]:newptr[r] + (e - s)] = col[s:e]
+        nval[newptr[r]:newptr[r] + (e - s)] = val[s:e]
+        ncol_arr[newptr[r + 1] - 1] = r
+        nval[newptr[r + 1] - 1] = 2.0 * rowsum[r] + 1.0
+    return N, newptr, ncol_arr, nval, 1
+
+
+def local_block(rowptr, col, val, r0, r1):
+    lp = rowptr[r0:r1 + 1] - rowptr[r0]
+    return lp, col[rowptr[r0]:rowptr[r1]], val[rowptr[r0]:rowptr[r1]]
+
+
+def main():
+    mode, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from mgpreconditionedgcr_amd import Comm, Plan, problems
+    comm = Comm.host(dist)
+    results = {}
+    for kind in ("poisson", "random"):
+        N, rowptr, col, val, gran = problem(kind)
+        offs = split_rows(N // gran, world)
+        r0, r1 = offs[rank] * gran, offs[rank + 1] * gran
+        lp, lc, lv = local_block(rowptr, col, val, r0, r1)
+        x = problems.rhs_grid(N, 5)
+        if mode == "plan":
+            plan = Plan(comm, N, r0, lp, lc)
+            # halo exchange by the plan's lists, with plain gloo point-to-point
+            xl = x[r0:r1]
+            halo = np.empty(plan.n_halo, np.complex128)
+            reqs, bufs = [], []
+            off = 0
+            for p in range(plan.npeers):
+                t = torch.empty(2 * int(plan.recv_counts[p]), dtype=torch.float64)
+                reqs.append(dist.irecv(t, src=int(plan.peers[p])))
+                bufs.append((off, t))
+                off += int(plan.recv_counts[p])
+            for p in range(plan.npeers):
+                s = np.ascontiguousarray(xl[plan.send_rows[p]]).view(np.float64)
+                reqs.append(dist.isend(torch.from_numpy(s.copy()), dst=int(plan.peers[p])))
+            for r in reqs:
+                r.wait()
+            for o, t in bufs:
+                halo[o:o + t.numel() // 2] = t.numpy().view(np.complex128)
+            assert np.array_equal(halo, x[plan.halo_globals])  # every halo slot got the right global entry
+            xe = np.concatenate([xl, halo])
+            y = np.zeros(r1 - r0, np.complex128)
+            rows = np.repeat(np.arange(r1 - r0), np.diff(lp))
+            np.add.at(y, rows, lv * xe[plan.col_local])
+            # rows in the "interior" range touch no halo column
+            ib, ie = plan.interior
+            for r in range(ib, ie):
+                assert (plan.col_local[lp[r]:lp[r + 1]] < (r1 - r0)).all()
+            results[kind] = dict(y=y, r0=r0, n_halo=plan.n_halo, peers=plan.peers.copy(), interior=plan.interior)
+        else:
+            from mgpreconditionedgcr_amd import DistSparse, Field, GCR, GCR_Param
+            import mgpreconditionedgcr_amd as mg
+            mg.init(0)
+            A = DistSparse(comm, N, r0, lp, lc, lv)
+            xf = Field((r1 - r0,), x[r0:r1])
+            y = A(xf).to_numpy()
+            b = Field((r1 - r0,), problems.rhs_grid(N, 1)[r0:r1])
+            xs = Field((r1 - r0,)).set_zero()
+            gcr = GCR(A, GCR_Param(0, 4, 25, 1e-30, False, check_every=5))
+            gcr.solve(b, xs)
+            g2 = GCR(A, GCR_Param(11, 0, 25, 1e-30, False))
+            xt = Field((r1 - r0,)).set_zero()
+            g2.solve(b, xt)
+            results[kind] = dict(y=y, r0=r0, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations,
+                                 hist_trunc=g2.last_history, x_trunc=xt.to_numpy())
+    np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
