@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=128, help="Poisson grid edge per GPU shard (128 = BASELINE configs[1])")
+    ap.add_argument("--grid", dest="n", type=int, default=128, help="Poisson grid edge per GPU shard (128 = BASELINE configs[1])")
     ap.add_argument("--restart", type=int, default=5)
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,30 +91,57 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    # bring-up switch: MGCR_BENCH_TRANSPORT=host runs the N > 1 code path with every rank on GPU 0 and
+    # the host-staged (gloo) transport, so that it can be rehearsed on a one-GPU box; numbers
+    # obtained that way are not benchmark results
+    host_transport = os.environ.get("MGCR_BENCH_TRANSPORT", "rccl") == "host"
+    if host_transport:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        raise SystemExit("multi-GPU bench: distributed path not wired yet in this revision")
     mg.init(local_rank)
-
+    dist = None
     n = args.n
-    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
-    nnz = int(rowptr[-1])
-    A = Sparse(N, ncol, rowptr, col, val)
+    if world > 1:
+        # control plane (barriers, id broadcast, max-reduce of the timing) over gloo; the data path
+        # (halo exchange + dot-product all-reduces) is RCCL inside libmgcr_hip.so
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from mgpreconditionedgcr_amd import Comm, DistSparse
+        comm = Comm.host(dist) if host_transport else Comm.rccl(dist)
+        # weak scaling: the grid grows along i, every GPU owns n planes (= the N=1 problem)
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n, rank * n, (rank + 1) * n, ni=world * n)
+        nnz = int(rowptr[-1])
+        A = DistSparse(comm, ncol, rank * N, rowptr, col, val)
+        ncol = N  # per-shard accounting below
+    else:
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        nnz = int(rowptr[-1])
+        A = Sparse(N, ncol, rowptr, col, val)
     del rowptr, col, val
     dims = (n, n, n)
-    rhs = Field(dims).fill_rhs(0)
+    rhs = Field(dims).fill_rhs(0, global_offset=rank * N)
     x = Field(dims)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
 
     def run(iters):
         x.set_zero()
         gcr = GCR(A, GCR_Param(0, args.restart, iters, 0.0, False, check_every=max(iters, 1)))
         torch.cuda.synchronize()
         mg.lib().mgcr_synchronize()
+        barrier()
         t0 = time.perf_counter()
         gcr.solve(rhs, x)
         mg.lib().mgcr_synchronize()
         torch.cuda.synchronize()
+        barrier()
         dt = time.perf_counter() - t0
+        if dist is not None:  # max over ranks
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
         assert gcr.last_iterations == iters, (gcr.last_iterations, iters)
         return dt, gcr
 
@@ -152,8 +179,10 @@ def main():
         "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, fp64 complex, x0=0, "
                                "RHS splitmix64 seed 0" % (n, args.restart),
                    "rows": N, "nnz": nnz, "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],
-                   "partition": "1 GPU" if world == 1 else "slab x%d" % world},
-        "spmv": {"ms": spmv_ms, "algorithmic_bytes": b_spmv, "stored_matrix_bytes": stored["matrix_bytes"],
+                   "partition": "1 GPU" if world == 1 else "slab x%d (grid %dx%dx%d), %s" % (
+                       world, world * n, n, n, "host-staged transport (bring-up, not a result)" if host_transport
+                       else "RCCL halo exchange + all-reduce")},
+        "spmv": {"ms": spmv_ms, "includes_halo_exchange": world > 1, "algorithmic_bytes": b_spmv, "stored_matrix_bytes": stored["matrix_bytes"],
                  "GBps": achieved, "frac_hbm_peak": achieved / HBM_PEAK_GBS},
         "iteration": {"algorithmic_bytes_survey": iter_bytes_model, "bytes_moved_model": iter_bytes_ours,
                       "GBps_survey": iter_bytes_model / (ms_per_step * 1e-3) / 1e9,
@@ -168,7 +197,11 @@ def main():
         except Exception as e:  # the baseline leg must never take the GPU numbers down with it
             out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        del A, gcr
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -136,6 +136,8 @@ def init(device=None):
     """mgcr_init on `device` (default: LOCAL_RANK or 0). Raises if no GPU is usable."""
     global _initialised_device
     if device is None:
+        if _initialised_device is not None:
+            return
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if _initialised_device is not None:
         if _initialised_device != device:

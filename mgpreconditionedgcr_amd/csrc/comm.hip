@@ -298,6 +298,11 @@ struct DistCsr {
     std::vector<double> h_send, h_recv;  // host staging (callback transport)
 };
 
+static bool halo_overlap() {
+    static const bool on = getenv("MGCR_HALO_OVERLAP") && atoi(getenv("MGCR_HALO_OVERLAP")) != 0;
+    return on;
+}
+
 __global__ void __launch_bounds__(256) pack_kernel(int64_t n, const int32_t *__restrict__ idx, const cplx *__restrict__ x,
                                                    cplx *__restrict__ out, const int *__restrict__ skip) {
     if (skip && *skip) return;
@@ -321,18 +326,25 @@ int dist_halo_begin(DistCsr *d, const cplx *x) {
             MGCR_HIP(hipGetLastError());
         }
     if (c->is_rccl) {
-        MGCR_HIP(hipEventRecord(c->ev_ready, main));
-        MGCR_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+        // Default: the exchange is ordered on the compute stream, like the all-reduces — every RCCL
+        // call of this communicator then sits on one stream, in the same order on every rank.
+        // MGCR_HALO_OVERLAP=1 moves it to the communication stream so that it overlaps the interior
+        // rows (to be switched on once it has been exercised on a multi-GPU node).
+        hipStream_t cs = halo_overlap() ? c->comm_stream : main;
+        if (cs != main) {
+            MGCR_HIP(hipEventRecord(c->ev_ready, main));
+            MGCR_HIP(hipStreamWaitEvent(cs, c->ev_ready, 0));
+        }
         MGCR_NCCL(rccl().GroupStart());
         for (int p = 0; p < np; p++) {
             const cplx *src = d->send_contig[(size_t)p] >= 0 ? x + d->send_contig[(size_t)p] : d->sendbuf + d->send_off[(size_t)p];
             if (d->send_cnt[(size_t)p])
-                MGCR_NCCL(rccl().Send(src, (size_t)d->send_cnt[(size_t)p] * 2, ncclDouble, P->peers[(size_t)p], c->nccl, c->comm_stream));
+                MGCR_NCCL(rccl().Send(src, (size_t)d->send_cnt[(size_t)p] * 2, ncclDouble, P->peers[(size_t)p], c->nccl, cs));
             if (P->recv_count[(size_t)p])
-                MGCR_NCCL(rccl().Recv(d->xh + P->recv_off[(size_t)p], (size_t)P->recv_count[(size_t)p] * 2, ncclDouble, P->peers[(size_t)p], c->nccl, c->comm_stream));
+                MGCR_NCCL(rccl().Recv(d->xh + P->recv_off[(size_t)p], (size_t)P->recv_count[(size_t)p] * 2, ncclDouble, P->peers[(size_t)p], c->nccl, cs));
         }
         MGCR_NCCL(rccl().GroupEnd());
-        MGCR_HIP(hipEventRecord(c->ev_done, c->comm_stream));
+        if (cs != main) MGCR_HIP(hipEventRecord(c->ev_done, cs));
         return MGCR_OK;
     }
     // host-staged transport: device -> host, callback, host -> device (synchronous)
@@ -361,7 +373,7 @@ int dist_halo_begin(DistCsr *d, const cplx *x) {
 
 int dist_halo_end(DistCsr *d) {
     Comm *c = d->comm;
-    if (c->is_rccl && !d->plan->peers.empty()) MGCR_HIP(hipStreamWaitEvent(ctx().stream, c->ev_done, 0));
+    if (c->is_rccl && halo_overlap() && !d->plan->peers.empty()) MGCR_HIP(hipStreamWaitEvent(ctx().stream, c->ev_done, 0));
     return MGCR_OK;
 }
 

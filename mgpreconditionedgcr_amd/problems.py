@@ -7,11 +7,13 @@ truncation), columns ascending within a row; complex values with zero imaginary 
 import numpy as np
 
 
-def poisson3d_csr(n, i0=0, i1=None):
-    """Rows of planes [i0, i1) of the n^3 Poisson matrix as (nrow, ncol, rowptr, col, val).
-    Column indices are global (0 .. n^3)."""
+def poisson3d_csr(n, i0=0, i1=None, ni=None):
+    """Rows of planes [i0, i1) of the (ni x n x n) Poisson matrix (ni = n by default) as
+    (nrow, ncol, rowptr, col, val).  Column indices are global (0 .. ni*n*n)."""
+    if ni is None:
+        ni = n
     if i1 is None:
-        i1 = n
+        i1 = ni
     i, j, k = np.meshgrid(np.arange(i0, i1, dtype=np.int64), np.arange(n, dtype=np.int64),
                           np.arange(n, dtype=np.int64), indexing="ij")
     i, j, k = i.ravel(), j.ravel(), k.ravel()
@@ -19,13 +21,13 @@ def poisson3d_csr(n, i0=0, i1=None):
     # candidate entries in ascending column order
     cand = [(i > 0, r - n * n, -1.0), (j > 0, r - n, -1.0), (k > 0, r - 1, -1.0),
             (np.ones_like(r, bool), r, 6.0),
-            (k < n - 1, r + 1, -1.0), (j < n - 1, r + n, -1.0), (i < n - 1, r + n * n, -1.0)]
+            (k < n - 1, r + 1, -1.0), (j < n - 1, r + n, -1.0), (i < ni - 1, r + n * n, -1.0)]
     mask = np.stack([c[0] for c in cand], axis=1)
     cols = np.stack([c[1] for c in cand], axis=1)
     vals = np.broadcast_to(np.array([c[2] for c in cand]), mask.shape)
     rowptr = np.zeros(r.size + 1, np.int64)
     np.cumsum(mask.sum(axis=1), out=rowptr[1:])
-    return r.size, n ** 3, rowptr, cols[mask], vals[mask].astype(np.complex128)
+    return r.size, ni * n * n, rowptr, cols[mask], vals[mask].astype(np.complex128)
 
 
 def rhs_grid(n, seed=0, offset=0):
