@@ -304,8 +304,8 @@ static bool halo_overlap() {
 }
 
 __global__ void __launch_bounds__(256) pack_kernel(int64_t n, const int32_t *__restrict__ idx, const cplx *__restrict__ x,
-                                                   cplx *__restrict__ out, const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                   cplx *__restrict__ out, const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = x[idx[i]];
 }
@@ -322,7 +322,7 @@ int dist_halo_begin(DistCsr *d, const cplx *x) {
         if (d->send_contig[(size_t)p] < 0 && d->send_cnt[(size_t)p]) {
             hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((d->send_cnt[(size_t)p] + 255) / 256)), dim3(256), 0, main,
                                d->send_cnt[(size_t)p], d->send_idx + d->send_off[(size_t)p], x, d->sendbuf + d->send_off[(size_t)p],
-                               get_apply_skip_flag());
+                               get_apply_skip().p, get_apply_skip().it);
             MGCR_HIP(hipGetLastError());
         }
     if (c->is_rccl) {

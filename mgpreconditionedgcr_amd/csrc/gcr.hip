@@ -23,6 +23,7 @@
 // Arithmetic follows the reference's order and conjugation (alpha = <r,Ap>/<Ap,Ap> with conj on
 // r, beta = <Ar,Aps_i>/<Aps_i,Aps_i> with conj on Ar: SURVEY.md §0 fact 2); the library is built
 // with -ffp-contract=off so element-wise results round like the reference's.
+#include <climits>
 #include <cmath>
 
 #include "internal.h"
@@ -33,9 +34,14 @@ namespace mgcr {
 constexpr int ND = 8;  // directions per multidot / build launch
 
 struct DevState {
-    int done;      // set on convergence; every later kernel of this solve is a no-op
+    // Iteration at which the solve ended (INT_MAX while running).  Every kernel of the solve gets the
+    // iteration number `it` it belongs to and returns at once when stop_at < it.  The bookkeeping of
+    // step k (inside build_kernel) writes stop_at = k, which is >= the `it` of every kernel of step
+    // k: no kernel ever acts on a value written by a concurrently running workgroup of itself.
+    int stop_at;
     int iter;      // global_count
-    int pad0, pad1;
+    int npend;     // x updates deferred so far in this restart cycle (see xr_update_kernel)
+    int pad1;
     double bnorm2; // |b|^2
     double rr;     // |r|^2 of the last finished step
     double tol2;
@@ -67,6 +73,7 @@ struct GcrState {
     double *dA = nullptr;   // [4]
     double *dRB = nullptr;  // [1 + 2 * dirs]: |r|^2, then the beta numerators
     double *dN = nullptr;   // [2]: |b|^2, |r0|^2
+    cplx *alphas = nullptr; // [storage]: alpha of the deferred x updates of the current restart cycle
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -75,9 +82,10 @@ struct GcrState {
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
-__global__ void reset_kernel(DevState *st, const int *inherit, double tol2) {
-    st->done = inherit ? *inherit : 0;
+__global__ void reset_kernel(DevState *st, const int *inherit, int inherit_it, double tol2) {
+    st->stop_at = (inherit && *inherit < inherit_it) ? -1 : INT_MAX;  // an outer solve that is over silences this one
     st->iter = 0;
+    st->npend = 0;
     st->bnorm2 = 0.;
     st->rr = 0.;
     st->tol2 = tol2;
@@ -85,16 +93,16 @@ __global__ void reset_kernel(DevState *st, const int *inherit, double tol2) {
 
 // r = b - t  (use_x0 extension)
 __global__ void __launch_bounds__(RED_THREADS) sub_kernel(cplx *__restrict__ out, const cplx *__restrict__ a,
-                                                          const cplx *__restrict__ b, int64_t n, const DevState *st) {
-    if (st->done) return;
+                                                          const cplx *__restrict__ b, int64_t n, const DevState *st, int it) {
+    if (st->stop_at < it) return;
     GRID_STRIDE(i, n) out[i] = csub(a[i], b[i]);
 }
 
 // partials of |a|^2 -> parts[blk]
 __global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *__restrict__ a, int64_t n,
-                                                                   double *__restrict__ parts, const DevState *st) {
+                                                                   double *__restrict__ parts, const DevState *st, int it) {
     __shared__ double lds[17];
-    if (st && st->done) return;
+    if (st && st->stop_at < it) return;
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
         cplx t = a[i];
@@ -106,9 +114,9 @@ __global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *
 
 // partials of <r,Ap> (conj on r) and <Ap,Ap>  ->  partsA[0..3][blk]
 __global__ void __launch_bounds__(RED_THREADS) dot2_partials_kernel(const cplx *__restrict__ r, const cplx *__restrict__ ap,
-                                                                   int64_t n, double *__restrict__ parts, const DevState *st) {
+                                                                   int64_t n, double *__restrict__ parts, const DevState *st, int it) {
     __shared__ double lds[4 * 17];
-    if (st->done) return;
+    if (st->stop_at < it) return;
     double v[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
         cplx a = ap[i];
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const d
                                                            int strideN, const double *__restrict__ partsR, int nblkR,
                                                            int strideR, double *__restrict__ hist) {
     __shared__ double lds[17];
-    if (st->done) return;
+    if (st->stop_at < 0) return;
     double b[1], r[1];
     fold_partials<1>(partsN, nblkN, strideN, b, lds);
     fold_partials<1>(partsR, nblkR, strideR, r, lds);
@@ -137,22 +145,33 @@ __global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const d
     }
 }
 
-// alpha = <r,Ap>/<Ap,Ap>;  x = x + p*alpha;  r = r - Ap*alpha  (src/GCR.h:230-233) + |r|^2 partials
-__global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *__restrict__ st, const double *__restrict__ partsA,
+// alpha = <r,Ap>/<Ap,Ap>;  x = x + p*alpha;  r = r - Ap*alpha  (src/GCR.h:230-233) + |r|^2 partials.
+// DEFER (restart mode): x is not touched here; alpha is parked in alphas[slot] and the pending
+// updates x += alpha_j p_j of a whole restart cycle are applied, in iteration order, by the
+// build_kernel that closes the cycle (which streams those p_j anyway) or by flush_x_kernel at the
+// end of the solve — 3 V less traffic per iteration, bit-identical x.
+template <bool DEFER>
+__global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsA,
                                                                 int nblkA, int strideA, const cplx *__restrict__ p,
                                                                 const cplx *__restrict__ ap, cplx *__restrict__ x,
                                                                 cplx *__restrict__ r, int64_t n, double *__restrict__ partsR,
-                                                                cplx *__restrict__ den_slot) {
+                                                                cplx *__restrict__ den_slot, cplx *__restrict__ alphas, int slot) {
     __shared__ double lds[4 * 17];
-    if (st->done) return;
+    if (st->stop_at < it) return;
     double s[4];
     fold_partials<4>(partsA, nblkA, strideA, s, lds);
     const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
     const cplx alpha = to_sgpr(cdiv(num, den));
-    if (blockIdx.x == 0 && threadIdx.x == 0) *den_slot = den;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *den_slot = den;
+        if (DEFER) {
+            alphas[slot] = alpha;
+            st->npend = slot + 1;
+        }
+    }
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
-        x[i] = cadd(x[i], cmul(alpha, p[i]));
+        if (!DEFER) x[i] = cadd(x[i], cmul(alpha, p[i]));
         cplx rn = csub(r[i], cmul(alpha, ap[i]));
         r[i] = rn;
         v[0] += rn.x * rn.x + rn.y * rn.y;
@@ -161,16 +180,29 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(const DevState *
     if (threadIdx.x == 0) partsR[blockIdx.x] = v[0];
 }
 
+// applies the x updates still pending when the solve ends (never skipped)
+__global__ void __launch_bounds__(RED_THREADS) flush_x_kernel(DevState *__restrict__ st, const cplx *__restrict__ alphas, DirPtrs d0,
+                                                              cplx *__restrict__ x, int64_t n) {
+    const int np = st->npend;
+    if (np <= 0) return;
+    GRID_STRIDE(i, n) {
+        cplx xv = x[i];
+        for (int j = 0; j < np && j < ND; j++) xv = cadd(xv, cmul(alphas[j], d0.ps[j][i]));
+        x[i] = xv;
+    }
+}
+__global__ void clear_pending_kernel(DevState *st) { st->npend = 0; }
+
 // <Ar, Aps[j]> for j < NDT (conj on Ar, src/GCR.h:258) -> partsB[(base+j)*2 + {0,1}][blk].
 // NDT is a template parameter so that the (1 + NDT) * U loads of one trip are issued back to back
 // with no branch between them: the kernel is latency-bound otherwise (a wave with a single 1-KiB
 // load in flight cannot cover HBM latency, even at 32 waves per CU).
 template <int NDT, int U>
-__global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *__restrict__ st, const cplx *__restrict__ ar,
+__global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *__restrict__ st, int it, const cplx *__restrict__ ar,
                                                                DirPtrs d, int base, int64_t n,
                                                                double *__restrict__ partsB) {
     __shared__ double lds[2 * NDT * 17];
-    if (st->done) return;
+    if (st->stop_at < it) return;
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
@@ -218,8 +250,10 @@ __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *_
 // the iteration counter, records the history entry and raises the convergence flag.  The flag only
 // takes effect from the next kernel on, so this step's directions are still built, as in the
 // reference.
-template <int NDT, bool FIRST, bool LAST, bool RDIR>
-__global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict__ st, const double *__restrict__ partsB,
+// XUPD (closing step of a restart cycle, NDT == restart): also applies the cycle's deferred
+// x += alpha_j ps_j, j ascending = iteration order.
+template <int NDT, bool FIRST, bool LAST, bool RDIR, bool XUPD>
+__global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
                                                             int nblkB, int strideB, int book,
                                                             const double *__restrict__ partsR, int nblkR, int strideR,
                                                             double *__restrict__ hist, int hist_cap,
@@ -227,22 +261,23 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
                                                             const cplx *__restrict__ dir, const cplx *__restrict__ r,
                                                             const cplx *__restrict__ ar, cplx *accp, cplx *accap,
                                                             cplx *p_out, cplx *ap_out, int64_t n,
-                                                            double *__restrict__ partsA) {
+                                                            double *__restrict__ partsA, cplx *__restrict__ x,
+                                                            const cplx *__restrict__ alphas) {
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT];
-    if (st->done) return;
+    if (st->stop_at < it) return;
     double s[2 * NDT];
     fold_partials<2 * NDT>(partsB + (size_t)(2 * base) * strideB, nblkB, strideB, s, lds);
     if (book && blockIdx.x == 0) {
         double rr[1];
         fold_partials<1>(partsR, nblkR, strideR, rr, lds);
         if (threadIdx.x == 0) {
-            int it = st->iter + 1;
-            st->iter = it;
+            st->iter = it;  // global_count
             st->rr = rr[0];
             if (it < hist_cap) hist[it] = sqrt(rr[0]) / sqrt(st->bnorm2);
             // continue while |r|^2/|b|^2 > tol^2 (src/GCR.h:288); NaN compares false -> stop, like the reference
-            if (!((rr[0] / st->bnorm2) > st->tol2)) st->done = 1;
+            if (!((rr[0] / st->bnorm2) > st->tol2)) st->stop_at = it;
+            if (XUPD) st->npend = 0;
         }
     }
     if (threadIdx.x < NDT) {
@@ -254,9 +289,12 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
         sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
     }
     __syncthreads();
-    cplx beta[NDT];
+    cplx beta[NDT], alf[NDT];
 #pragma unroll
-    for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
+    for (int j = 0; j < NDT; j++) {
+        beta[j] = to_sgpr(sbeta[j]);
+        alf[j] = XUPD ? to_sgpr(alphas[j]) : make_double2(0., 0.);
+    }
     double v[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
         // all loads of the trip first, no branches in between
@@ -273,6 +311,12 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
             dv = dir[i];
             av = ar[i];
             rv = RDIR ? r[i] : dv;
+        }
+        if (XUPD) {
+            cplx xv = x[i];
+#pragma unroll
+            for (int j = 0; j < NDT; j++) xv = cadd(xv, cmul(alf[j], pj[j]));
+            x[i] = xv;
         }
 #pragma unroll
         for (int j = 0; j < NDT; j++) {
@@ -346,9 +390,9 @@ static void gcr_free_vectors(GcrState *s) {
     for (cplx *p : s->aps) hipFree(p);
     s->ps.clear(); s->aps.clear();
     hipFree(s->r); hipFree(s->ar); hipFree(s->z); hipFree(s->tmp); hipFree(s->accp); hipFree(s->accap);
-    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB); hipFree(s->dRB);
+    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB); hipFree(s->dRB); hipFree(s->alphas);
     s->r = s->ar = s->z = s->tmp = s->accp = s->accap = nullptr;
-    s->den = nullptr; s->hist = nullptr; s->partsB = nullptr; s->dRB = nullptr;
+    s->den = nullptr; s->hist = nullptr; s->partsB = nullptr; s->dRB = nullptr; s->alphas = nullptr;
     s->alloc_slots = 0; s->n = 0; s->partsB_dirs = 0; s->hist_cap = 0;
 }
 
@@ -424,6 +468,7 @@ static int gcr_prepare(GcrState *s, int64_t n) {
         MGCR_TRY(dalloc(&s->r, (size_t)n));
         MGCR_TRY(dalloc(&s->ar, (size_t)n));
         MGCR_TRY(dalloc(&s->den, (size_t)storage));
+        MGCR_TRY(dalloc(&s->alphas, (size_t)storage));
         int cap = (p.max_iter > 0 ? p.max_iter : 1) + 1;
         MGCR_TRY(dalloc(&s->hist, (size_t)cap));
         s->hist_cap = cap;
@@ -454,13 +499,13 @@ static int gcr_prepare(GcrState *s, int64_t n) {
     } while (0)
 
 struct SkipGuard {
-    const int *prev;
-    explicit SkipGuard(const int *f) : prev(get_apply_skip_flag()) { set_apply_skip_flag(f); }
-    ~SkipGuard() { set_apply_skip_flag(prev); }
+    SkipRef prev;
+    explicit SkipGuard(SkipRef f) : prev(get_apply_skip()) { set_apply_skip(f); }
+    ~SkipGuard() { set_apply_skip(prev); }
 };
 
-static int launch_multidot(int g, int nd, const DevState *st, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB) {
-#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, ar, d, base, n, partsB)
+static int launch_multidot(int g, int nd, const DevState *st, int it, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB) {
+#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, partsB)
     switch (nd) {
         case 1: MD(1, 2); break;
         case 2: MD(2, 2); break;
@@ -480,34 +525,54 @@ struct RedRef {  // where a consumer finds a reduction: slab of per-workgroup pa
     int nblk, stride;
 };
 
+struct BuildArgs {
+    int g, nd;
+    bool first, last, rdir, xupd;
+    DevState *st;
+    int it;
+    RedRef B;
+    int book;
+    RedRef R;
+    double *hist;
+    int hist_cap;
+    const cplx *den;
+    DirPtrs d;
+    int base;
+    const cplx *dir, *r, *ar;
+    cplx *accp, *accap, *p_out, *ap_out;
+    int64_t n;
+    double *partsA;
+    cplx *x;
+    const cplx *alphas;
+};
+
 template <int NDT>
-static int launch_build_n(int g, bool first, bool last, bool rdir, DevState *st, RedRef B, int book, RedRef R, double *hist,
-                          int hist_cap, const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r,
-                          const cplx *ar, cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
-#define BK(F, L, R_) KLAUNCH((build_kernel<NDT, F, L, R_>), g, st, B.p, B.nblk, B.stride, book, R.p, R.nblk, R.stride, hist, hist_cap, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
-    if (first && last) { if (rdir) BK(true, true, true); else BK(true, true, false); }
-    else if (first) BK(true, false, false);
-    else if (last) { if (rdir) BK(false, true, true); else BK(false, true, false); }
-    else BK(false, false, false);
+static int launch_build_n(const BuildArgs &a) {
+    const int g = a.g;
+#define BK(F, L, R_, X_)                                                                                                       \
+    KLAUNCH((build_kernel<NDT, F, L, R_, X_>), g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.book, a.R.p, a.R.nblk, a.R.stride, \
+            a.hist, a.hist_cap, a.den, a.d, a.base, a.dir, a.r, a.ar, a.accp, a.accap, a.p_out, a.ap_out, a.n, a.partsA, a.x, a.alphas)
+    if (a.first && a.last) {
+        if (a.xupd) { if (a.rdir) BK(true, true, true, true); else BK(true, true, false, true); }
+        else { if (a.rdir) BK(true, true, true, false); else BK(true, true, false, false); }
+    } else if (a.first) BK(true, false, false, false);
+    else if (a.last) { if (a.rdir) BK(false, true, true, false); else BK(false, true, false, false); }
+    else BK(false, false, false, false);
 #undef BK
     return MGCR_OK;
 }
 
-static int launch_build(int g, int nd, bool first, bool last, bool rdir, DevState *st, RedRef B, int book, RedRef R, double *hist,
-                        int hist_cap, const cplx *den, const DirPtrs &d, int base, const cplx *dir, const cplx *r, const cplx *ar,
-                        cplx *accp, cplx *accap, cplx *p_out, cplx *ap_out, int64_t n, double *partsA) {
-#define LB(NDT) return launch_build_n<NDT>(g, first, last, rdir, st, B, book, R, hist, hist_cap, den, d, base, dir, r, ar, accp, accap, p_out, ap_out, n, partsA)
-    switch (nd) {
-        case 1: LB(1);
-        case 2: LB(2);
-        case 3: LB(3);
-        case 4: LB(4);
-        case 5: LB(5);
-        case 6: LB(6);
-        case 7: LB(7);
-        default: LB(8);
+static int launch_build(const BuildArgs &a) {
+    switch (a.nd) {
+        case 1: return launch_build_n<1>(a);
+        case 2: return launch_build_n<2>(a);
+        case 3: return launch_build_n<3>(a);
+        case 4: return launch_build_n<4>(a);
+        case 5: return launch_build_n<5>(a);
+        case 6: return launch_build_n<6>(a);
+        case 7: return launch_build_n<7>(a);
+        default: return launch_build_n<8>(a);
     }
-#undef LB
 }
 
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged) {
@@ -518,16 +583,16 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const mgcr_gcr_param &p = s->p;
     const int g = red_grid(n);
     const bool flex = p.flexible && p.right_precond;
-    const int *inherit = get_apply_skip_flag();  // outer solver's flag: if it is up, this solve is a no-op too
+    const SkipRef outer = get_apply_skip();  // outer solver's predicate: if that solve is over, this one is a no-op too
 
-    hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, c.stream, s->st, inherit, p.tol * p.tol);
+    hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, c.stream, s->st, outer.p, outer.it, p.tol * p.tol);
     MGCR_HIP(hipGetLastError());
-    SkipGuard guard(&s->st->done);
+    SkipGuard guard(SkipRef{&s->st->stop_at, 0});
 
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
         MGCR_TRY(op_apply_raw(s->A, x, s->ar, n));
-        KLAUNCH(sub_kernel, g, s->r, rhs, s->ar, n, s->st);
+        KLAUNCH(sub_kernel, g, s->r, rhs, s->ar, n, (const DevState *)s->st, 0);
     } else {
         MGCR_TRY(k_copy(s->r, rhs, n));
     }
@@ -550,9 +615,10 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool multi = comm_collectives(comm);
     MGCR_CHECK(!multi || (!p.left_precond && !p.right_precond), MGCR_ERR_UNSUPPORTED,
                "preconditioned GCR on a distributed operator is not available yet");
-    KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, s->st);
-    KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, s->st);
-    KLAUNCH(dot2_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, s->partsA, s->st);
+    const DevState *cst = s->st;
+    KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
+    KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, 0);
+    KLAUNCH(dot2_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, s->partsA, cst, 0);
     RedRef refA = {s->partsA, g, RED_MAX_BLOCKS}, refR = {s->partsR, g, RED_MAX_BLOCKS};
     if (multi) {
         MGCR_TRY(k_fold(s->partsN, g, 1, s->dN));
@@ -569,14 +635,22 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
     int check_every = p.check_every > 0 ? p.check_every : 10;
+    // restart mode with all slots handled by one build launch: defer the x updates of a cycle
+    const bool defer = p.restart != 0 && s->storage <= ND;
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     while (global < max_it && !done) {
         global++;
         iter_count++;
+        const int it = global;
+        set_apply_skip(SkipRef{&s->st->stop_at, it});
         // alpha, x, r
-        KLAUNCH(xr_update_kernel, g, (const DevState *)s->st, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
-                (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur);
+        if (defer)
+            KLAUNCH((xr_update_kernel<true>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
+                    (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur, s->alphas, cur);
+        else
+            KLAUNCH((xr_update_kernel<false>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
+                    (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur, s->alphas, cur);
         const cplx *dir = s->r;
         if (flex) {
             MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
@@ -585,7 +659,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n));
             std::swap(s->r, s->tmp);
             dir = s->r;
-            KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, s->st);
+            KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, it);
         }
         MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
         if (p.left_precond) {                         // src/GCR.h:245-247
@@ -606,7 +680,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 int sl = ch * ND + (j < nd ? j : 0);
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
-            MGCR_TRY(launch_multidot(g, nd, (const DevState *)s->st, (const cplx *)s->ar, d, ch * ND, n, s->partsB));
+            MGCR_TRY(launch_multidot(g, nd, cst, it, (const cplx *)s->ar, d, ch * ND, n, s->partsB));
         }
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
         if (multi) {  // one all-reduce for |r|^2 and all beta numerators of the step
@@ -616,15 +690,20 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             refB = {s->dRB + 1, 1, 1};
         }
         for (int ch = 0; ch < nchunk; ch++) {
-            DirPtrs d;
-            int nd = lim - ch * ND < ND ? lim - ch * ND : ND;
+            BuildArgs a;
+            a.g = g;
+            a.nd = lim - ch * ND < ND ? lim - ch * ND : ND;
             for (int j = 0; j < ND; j++) {
-                int sl = ch * ND + (j < nd ? j : 0);
-                d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
+                int sl = ch * ND + (j < a.nd ? j : 0);
+                a.d.ps[j] = s->ps[sl]; a.d.aps[j] = s->aps[sl]; a.d.slot[j] = sl;
             }
-            MGCR_TRY(launch_build(g, nd, ch == 0, ch == nchunk - 1, dir != s->r, s->st, refB, ch == nchunk - 1 ? 1 : 0, refR,
-                                  s->hist, s->hist_cap, (const cplx *)s->den, d, ch * ND, dir, (const cplx *)s->r,
-                                  (const cplx *)s->ar, s->accp, s->accap, s->ps[nxt], s->aps[nxt], n, s->partsA));
+            a.first = ch == 0; a.last = ch == nchunk - 1; a.rdir = dir != s->r;
+            // the step that closes a restart cycle streams every ps slot of the cycle: apply the deferred x updates there
+            a.xupd = defer && ic_next == 0;
+            a.st = s->st; a.it = it; a.B = refB; a.book = a.last ? 1 : 0; a.R = refR; a.hist = s->hist; a.hist_cap = s->hist_cap;
+            a.den = s->den; a.base = ch * ND; a.dir = dir; a.r = s->r; a.ar = s->ar; a.accp = s->accp; a.accap = s->accap;
+            a.p_out = s->ps[nxt]; a.ap_out = s->aps[nxt]; a.n = n; a.partsA = s->partsA; a.x = x; a.alphas = s->alphas;
+            MGCR_TRY(launch_build(a));
         }
         if (multi) {
             MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
@@ -636,8 +715,15 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
             MGCR_HIP(hipStreamSynchronize(c.stream));
             const DevState *hs = (const DevState *)c.h_mail;
-            if (hs->done) done = true;
+            if (hs->stop_at != INT_MAX) done = true;
         }
+    }
+    if (defer) {  // x updates still pending (solve ended inside a restart cycle); ps[0..npend) hold their directions
+        DirPtrs d0;
+        for (int j = 0; j < ND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
+        KLAUNCH(flush_x_kernel, g, s->st, (const cplx *)s->alphas, d0, x, n);
+        hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);
+        MGCR_HIP(hipGetLastError());
     }
     if (nested) return MGCR_OK;
 

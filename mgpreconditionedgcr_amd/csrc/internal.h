@@ -142,8 +142,14 @@ struct HostCsr {
     std::vector<double> val_ri;
 };
 int csr_download_host(const CsrDev &A, HostCsr *out);
-void set_apply_skip_flag(const int *flag);
-const int *get_apply_skip_flag();
+// Device-side "this solve is over" predicate consulted by operator-apply kernels that run inside a
+// solver iteration: they return at once when *stop_at < it (see gcr.hip: DevState::stop_at).
+struct SkipRef {
+    const int *p = nullptr;
+    int it = 0;
+};
+void set_apply_skip(SkipRef s);
+SkipRef get_apply_skip();
 
 // ---- comm.hip --------------------------------------------------------------------------------
 int dist_halo_begin(DistCsr *d, const cplx *x);

@@ -233,8 +233,8 @@ static void blocks_to_csr(const CoarseBlocks &B, int ne, int64_t nagg, HostCsr &
 __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const int32_t *__restrict__ aptr,
                                                        const int32_t *__restrict__ amem, const cplx *__restrict__ pv,
                                                        const cplx *__restrict__ x, cplx *__restrict__ xc,
-                                                       const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                       const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
     int64_t a = c / ne;
@@ -251,8 +251,8 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
 __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, const int32_t *__restrict__ agg,
                                                          const cplx *__restrict__ pv, const cplx *__restrict__ xc,
                                                          cplx *__restrict__ x, cplx damp, int add,
-                                                         const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                         const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const cplx *c = xc + (int64_t)agg[i] * ne;
@@ -263,8 +263,8 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
 
 // r = b - r   (r holds A x on entry)
 __global__ void __launch_bounds__(256) residual_kernel(int64_t n, const cplx *__restrict__ b, cplx *__restrict__ r,
-                                                       const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                       const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) r[i] = csub(b[i], r[i]);
 }
@@ -430,7 +430,7 @@ int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc) {
     MgLevel &L = m->lev[(size_t)l];
     int64_t nc = L.nagg * L.ne;
     hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, L.ne, L.d_aptr, L.d_amem, L.d_pv, x, xc,
-                       get_apply_skip_flag());
+                       get_apply_skip().p, get_apply_skip().it);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -438,7 +438,7 @@ int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc) {
 int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping) {
     MgLevel &L = m->lev[(size_t)l];
     hipLaunchKernelGGL(expand_add_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, L.ne, L.d_agg, L.d_pv, xc, x,
-                       make_double2(damping, 0.), add ? 1 : 0, get_apply_skip_flag());
+                       make_double2(damping, 0.), add ? 1 : 0, get_apply_skip().p, get_apply_skip().it);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -456,7 +456,7 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     MGCR_TRY(k_zero(x, L.n));
     MGCR_TRY(gcr_run(L.pre, b, x, true, nullptr, 0, nullptr, nullptr));
     MGCR_TRY(op_apply_raw(L.A, x, L.r, L.n));
-    hipLaunchKernelGGL(residual_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, b, L.r, get_apply_skip_flag());
+    hipLaunchKernelGGL(residual_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, b, L.r, get_apply_skip().p, get_apply_skip().it);
     MGCR_HIP(hipGetLastError());
     MgLevel &C = m->lev[(size_t)l + 1];
     MGCR_TRY(mg_restrict(m, l, L.r, C.b));

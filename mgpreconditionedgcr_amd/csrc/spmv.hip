@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
                                                           int64_t ntiles, const cplx *__restrict__ val,
                                                           const int32_t *__restrict__ col, const cplx *__restrict__ x,
                                                           const cplx *__restrict__ xh, int32_t n_own,
-                                                          cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                          cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
     int64_t rloc = tile * 256 + threadIdx.x;
@@ -274,8 +274,8 @@ template <int L, bool SHIFT>
 __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t row_count, int64_t npad, int32_t nchunk,
                                                       const cplx *__restrict__ val, const int32_t *__restrict__ col,
                                                       const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
-                                                      cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                      cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t rloc = t / L;
     int64_t row = row_begin + rloc;
@@ -304,8 +304,8 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
                                                        const int32_t *__restrict__ tail_col,
                                                        const cplx *__restrict__ tail_val, const cplx *__restrict__ x,
                                                        const cplx *__restrict__ xh, int32_t n_own,
-                                                       cplx *__restrict__ y, cplx k, const int *__restrict__ skip) {
-    if (skip && *skip) return;
+                                                       cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+    if (skip && *skip < skip_it) return;
     int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
     if (wave >= n_tail_rows) return;
@@ -320,9 +320,9 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
     }
 }
 
-static const int *g_skip_flag = nullptr;  // device flag consulted by apply kernels (set by the GCR driver)
-void set_apply_skip_flag(const int *flag) { g_skip_flag = flag; }
-const int *get_apply_skip_flag() { return g_skip_flag; }
+static SkipRef g_skip;  // consulted by apply kernels (set by the GCR driver around its operator applies)
+void set_apply_skip(SkipRef s) { g_skip = s; }
+SkipRef get_apply_skip() { return g_skip; }
 
 // rows [row_begin, row_begin + row_count) of the ELL part
 template <bool SHIFT>
@@ -335,7 +335,7 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
         unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
 #define RT(WT, X)                                                                                                        \
     hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, \
-                       A.W, ntiles, A.ell_val, A.ell_col, x, xh, n_own, y, k, g_skip_flag)
+                       A.W, ntiles, A.ell_val, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it)
         if (A.W == 7) { if (xcd) RT(7, true); else RT(7, false); }
         else { if (xcd) RT(0, true); else RT(0, false); }
 #undef RT
@@ -344,7 +344,7 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
         unsigned grid = (unsigned)((threads + 255) / 256);
 #define LN(LL)                                                                                                            \
     hipLaunchKernelGGL((ell_spmv_lanes<LL, SHIFT>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, A.nchunk, \
-                       A.ell_val, A.ell_col, x, xh, n_own, y, k, g_skip_flag)
+                       A.ell_val, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it)
         switch (A.L) {
             case 2: LN(2); break;
             case 4: LN(4); break;
@@ -379,7 +379,7 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
     if (A.n_tail_rows) {
         int64_t threads = A.n_tail_rows * 64;
         hipLaunchKernelGGL((csr_tail_kernel<SHIFT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream,
-                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, g_skip_flag);
+                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, g_skip.p, g_skip.it);
         MGCR_HIP(hipGetLastError());
     }
     return MGCR_OK;
@@ -400,10 +400,10 @@ int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistC
 __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
                                                        const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
                                                        const cplx *__restrict__ x, cplx *__restrict__ y,
-                                                       const int *__restrict__ skip) {
+                                                       const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
-    if (skip && *skip) return;
+    if (skip && *skip < skip_it) return;
     const int32_t brow = blockIdx.x;
     const int lane = threadIdx.x;
     const int32_t bs2 = bs * bs, ld = bs + 1;
@@ -468,7 +468,7 @@ int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y) {
     }
     MGCR_CHECK(lds <= 160 * 1024, MGCR_ERR_UNSUPPORTED, "block size %d needs more than 160 KiB of LDS", A.bs);
     hipLaunchKernelGGL(bcsr_wave_kernel, dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr,
-                       A.bcol, A.blocks, x, y, g_skip_flag);
+                       A.bcol, A.blocks, x, y, g_skip.p, g_skip.it);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
