@@ -114,6 +114,8 @@ typedef struct mgcr_gcr_param {
                             instead of the reference's literal r = M(r) (src/GCR.h:236-238) */
     int32_t check_every; /* host looks at the device-side convergence flag every this many
                             iterations (0 = library default); results do not depend on it */
+    int32_t profile_spmv; /* 1: bracket every operator apply of the loop with hipEvents on the
+                            library stream; read the result with mgcr_gcr_last_profile (bench.py) */
 } mgcr_gcr_param;
 
 /* GCR::solve(rhs, x) (src/GCR.h:158-302).  hist[0] is the step-0 entry, hist[k] the value
@@ -210,6 +212,9 @@ int mgcr_dcsr_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t n
 /* runs `reps` applies back to back on the library stream, bracketed by hipEvents there;
  * returns the average milliseconds per apply */
 int mgcr_bench_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y, int32_t reps, double *ms_avg);
+/* average in-loop duration of the operator apply (SpMV incl. halo exchange) of the last
+ * mgcr_gcr_solve that ran with profile_spmv = 1, and the number of applies it was averaged over */
+int mgcr_gcr_last_profile(double *spmv_ms_avg, int32_t *n_applies);
 /* opaque hipEvent-based stopwatch on the library stream */
 int mgcr_timer_start(void);
 int mgcr_timer_stop(double *ms);

@@ -24,7 +24,8 @@ class GcrParamC(C.Structure):
     _fields_ = [("truncation", C.c_int32), ("restart", C.c_int32), ("max_iter", C.c_int32),
                 ("tol", C.c_double), ("verbose", C.c_int32),
                 ("left_precond", C.c_void_p), ("right_precond", C.c_void_p),
-                ("use_x0", C.c_int32), ("flexible", C.c_int32), ("check_every", C.c_int32)]
+                ("use_x0", C.c_int32), ("flexible", C.c_int32), ("check_every", C.c_int32),
+                ("profile_spmv", C.c_int32)]
 
 
 class MgParamC(C.Structure):
@@ -99,6 +100,7 @@ _SIGS = {
     "mgcr_plan_halo_globals": (C.c_int, [_vp, _vp]),
     "mgcr_plan_destroy": (C.c_int, [_vp]),
     "mgcr_dcsr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "mgcr_gcr_last_profile": (C.c_int, [_dp, C.POINTER(C.c_int32)]),
     "mgcr_bench_op_apply": (C.c_int, [_vp, _vp, _vp, C.c_int32, _dp]),
     "mgcr_timer_start": (C.c_int, []),
     "mgcr_timer_stop": (C.c_int, [_dp]),

@@ -236,17 +236,18 @@ class GCR_Param:
     """GCR_Param(trunc, re, max_it, tau, verb, solver_l, solver_r) (src/SolverParam.h:21-35,85-99)."""
 
     def __init__(self, trunc=0, re=0, max_it=100, tau=1e-16, verb=True, solver_l=None, solver_r=None,
-                 use_x0=False, flexible=False, check_every=0):
+                 use_x0=False, flexible=False, check_every=0, profile_spmv=False):
         self.truncation, self.restart, self.max_iter, self.tol = int(trunc), int(re), int(max_it), float(tau)
         self.verbose = bool(verb)
         self.left_precond, self.right_precond = solver_l, solver_r
         self.use_x0, self.flexible, self.check_every = bool(use_x0), bool(flexible), int(check_every)
+        self.profile_spmv = bool(profile_spmv)
 
     def _c(self):
         return GcrParamC(self.truncation, self.restart, self.max_iter, self.tol, int(self.verbose),
                          self.left_precond.h if self.left_precond is not None else None,
                          self.right_precond.h if self.right_precond is not None else None,
-                         int(self.use_x0), int(self.flexible), self.check_every)
+                         int(self.use_x0), int(self.flexible), self.check_every, int(self.profile_spmv))
 
 
 class GCR(Operator):

@@ -126,7 +126,7 @@ int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width
     if (o->kind == OP_CSR) {
         const CsrDev &A = o->csr;
         int64_t slab = (int64_t)A.nchunk * A.npad * A.L;
-        if (matrix_bytes) *matrix_bytes = slab * 20 + A.tail_nnz * 20 + A.n_tail_rows * 8 + (A.n_tail_rows ? 4 : 0);
+        if (matrix_bytes) *matrix_bytes = slab * (A.ell_val_re ? 12 : 20) + A.tail_nnz * 20 + A.n_tail_rows * 8 + (A.n_tail_rows ? 4 : 0);
         if (ell_width) *ell_width = A.nchunk * A.L;
         if (tail_nnz) *tail_nnz = A.tail_nnz;
         return MGCR_OK;
@@ -198,6 +198,16 @@ int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0) {
     MGCR_CHECK(gcr && gcr->kind == OP_GCR, MGCR_ERR_INVALID, "mgcr_gcr_set_x0: not a GCR operator");
     LOCK();
     return gcr_state_set_x0(gcr->gcr, x0 ? x0->d : nullptr, x0 ? x0->n : 0);
+}
+
+int mgcr_gcr_last_profile(double *spmv_ms_avg, int32_t *n_applies) {
+    MGCR_CHECK(spmv_ms_avg && n_applies, MGCR_ERR_INVALID, "null argument");
+    double ms = 0.;
+    int n = 0;
+    gcr_last_profile(&ms, &n);
+    *spmv_ms_avg = ms;
+    *n_applies = n;
+    return MGCR_OK;
 }
 
 int mgcr_bench_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y, int32_t reps, double *ms_avg) {

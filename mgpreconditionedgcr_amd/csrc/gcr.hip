@@ -53,6 +53,10 @@ struct DirPtrs {
     int slot[ND];
 };
 
+static double g_prof_spmv_ms = 0.;
+static int g_prof_spmv_n = 0;
+void gcr_last_profile(double *ms, int *n) { *ms = g_prof_spmv_ms; *n = g_prof_spmv_n; }
+
 struct GcrState {
     Op *A = nullptr;
     mgcr_gcr_param p{};
@@ -639,6 +643,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool defer = p.restart != 0 && s->storage <= ND;
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
+    std::vector<hipEvent_t> prof_events;
     while (global < max_it && !done) {
         global++;
         iter_count++;
@@ -661,6 +666,16 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             dir = s->r;
             KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, it);
         }
+        if (p.profile_spmv && !nested) {
+            hipEvent_t e0, e1;
+            MGCR_HIP(hipEventCreate(&e0));
+            MGCR_HIP(hipEventCreate(&e1));
+            MGCR_HIP(hipEventRecord(e0, c.stream));
+            MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));
+            MGCR_HIP(hipEventRecord(e1, c.stream));
+            prof_events.push_back(e0);
+            prof_events.push_back(e1);
+        } else
         MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
         if (p.left_precond) {                         // src/GCR.h:245-247
             MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->ar, s->tmp, n));
@@ -729,6 +744,17 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 
     MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
     MGCR_HIP(hipStreamSynchronize(c.stream));
+    if (!prof_events.empty()) {
+        double tot = 0.;
+        for (size_t i = 0; i + 1 < prof_events.size(); i += 2) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]);
+            tot += ms;
+        }
+        g_prof_spmv_n = (int)(prof_events.size() / 2);
+        g_prof_spmv_ms = tot / g_prof_spmv_n;
+        for (hipEvent_t e : prof_events) hipEventDestroy(e);
+    }
     DevState hs = *(const DevState *)c.h_mail;
     int it = hs.iter;
     if (n_iter) *n_iter = it;

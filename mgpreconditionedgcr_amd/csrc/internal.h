@@ -79,7 +79,8 @@ struct CsrDev {
     int64_t nrow = 0, ncol = 0, nnz = 0;
     int32_t W = 0, L = 1, nchunk = 0;
     int64_t npad = 0;
-    cplx *ell_val = nullptr;
+    cplx *ell_val = nullptr;       // complex slab, or ...
+    double *ell_val_re = nullptr;  // ... real slab when every stored value has a zero imaginary part (12 B/nnz)
     int32_t *ell_col = nullptr;
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
@@ -176,6 +177,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             int *converged);
 void gcr_state_set_use_x0(GcrState *s, bool use_x0);
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);
+void gcr_last_profile(double *ms, int *n);
 
 }  // namespace mgcr
 

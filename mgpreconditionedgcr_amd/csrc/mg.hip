@@ -35,7 +35,12 @@ int csr_download_host(const CsrDev &A, HostCsr *out) {
     const size_t slab = (size_t)Wp * (size_t)A.npad;
     std::vector<hc> ev(slab);
     std::vector<int32_t> ec(slab);
-    if (slab) {
+    std::vector<double> evr;
+    if (slab && A.ell_val_re) {
+        evr.resize(slab);
+        MGCR_HIP(hipMemcpyAsync(evr.data(), A.ell_val_re, sizeof(double) * slab, hipMemcpyDeviceToHost, c.stream));
+        MGCR_HIP(hipMemcpyAsync(ec.data(), A.ell_col, sizeof(int32_t) * slab, hipMemcpyDeviceToHost, c.stream));
+    } else if (slab) {
         MGCR_HIP(hipMemcpyAsync(ev.data(), A.ell_val, sizeof(cplx) * slab, hipMemcpyDeviceToHost, c.stream));
         MGCR_HIP(hipMemcpyAsync(ec.data(), A.ell_col, sizeof(int32_t) * slab, hipMemcpyDeviceToHost, c.stream));
     }
@@ -48,6 +53,7 @@ int csr_download_host(const CsrDev &A, HostCsr *out) {
         MGCR_HIP(hipMemcpyAsync(tval.data(), A.tail_val, sizeof(cplx) * tval.size(), hipMemcpyDeviceToHost, c.stream));
     }
     MGCR_HIP(hipStreamSynchronize(c.stream));
+    for (size_t i = 0; i < evr.size(); i++) ev[i] = hc(evr[i], 0.);
     out->nrow = A.nrow;
     out->ncol = A.ncol;
     std::vector<int64_t> tail_of((size_t)A.nrow, -1);
