@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (not the driver's bench contract —
+that is bench.py).  One JSON line per workload on stdout.
+
+  python bench_extra.py --workload sample     config 1: data/sample_matrix format, DiracOp k=0.15, GCR restart 5
+  python bench_extra.py --workload poisson256 config 2 at 256^3: unpreconditioned GCR restart 5, 100 iterations
+  python bench_extra.py --workload mg256      config 3: Poisson 256^3, 3-level aggregation MG (2^3 aggregates,
+                                              piecewise-constant P, Galerkin), 2 GCR sweeps, flexible GCR restart 5
+  python bench_extra.py --workload bcsr       config 5 (single GPU): unstructured HierarchicalSparse, bs = 20,
+                                              skewed blocks/row, >= 2 GB of blocks: apply GB/s + GCR on it
+"""
+import argparse
+import ctypes
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def timed_solve(mg, gcr, rhs, x):
+    mg.lib().mgcr_synchronize()
+    t0 = time.perf_counter()
+    gcr.solve(rhs, x)
+    mg.lib().mgcr_synchronize()
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", required=True, choices=["sample", "poisson256", "mg256", "bcsr"])
+    ap.add_argument("--grid", dest="n", type=int, default=256)
+    ap.add_argument("--levels", type=int, default=2, help="number of coarse grids (2 = 3-level)")
+    args = ap.parse_args()
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import (DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MG, MG_Param, Mesh, Sparse,
+                                         problems, read_data)
+    mg.init(0)
+    out = {"workload": args.workload}
+    if args.workload == "sample":
+        d = tempfile.mkdtemp()
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "4x4parsed.txt.gz"), "rb") as fi, open(os.path.join(d, "4x4parsed.txt"), "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        D = read_data("4x4parsed.txt", directory=d)
+        dirac = DiracOp(D, 0.15)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "sample_4x4.npz"))
+        dims = (4, 4, 4, 4, 4, 3)
+        rhs = Field(dims, g["gcr_rhs"])
+        x = Field(dims).set_zero()
+        gcr = GCR(dirac, GCR_Param(0, 5, 4000, 1e-13, False, check_every=20))
+        timed_solve(mg, gcr, rhs, x)
+        x.set_zero()
+        dt = timed_solve(mg, gcr, rhs, x)
+        ref = g["g3_restart5_hist"]
+        out.update(iterations=gcr.last_iterations, seconds=dt, it_per_s=gcr.last_iterations / dt,
+                   final_rel_residual=float(gcr.last_history[-1]), reference_iterations=int(ref.size - 1),
+                   reference_final=float(ref[-1]),
+                   max_rel_dev_first_60_steps=float(np.max(np.abs(gcr.last_history[1:60] - ref[1:60]) / ref[1:60])),
+                   note="N = 3072: latency-bound (4 launches/iteration), the reference CPU path does ~1.7k it/s on this input")
+    elif args.workload in ("poisson256", "mg256"):
+        n = args.n
+        t0 = time.perf_counter()
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        nnz = int(rowptr[-1])
+        A = Sparse(N, ncol, rowptr, col, val)
+        del rowptr, col, val
+        out["setup_matrix_seconds"] = time.perf_counter() - t0
+        dims = (n, n, n)
+        rhs = Field(dims).fill_rhs(0)
+        x = Field(dims).set_zero()
+        V = 16 * N
+        stored = A.stored_bytes()
+        if args.workload == "poisson256":
+            iters = 100
+            gcr = GCR(A, GCR_Param(0, 5, 20, 0.0, False, check_every=20))
+            timed_solve(mg, gcr, rhs, x)
+            x.set_zero()
+            gcr = GCR(A, GCR_Param(0, 5, iters, 0.0, False, check_every=iters, profile_spmv=True))
+            dt = timed_solve(mg, gcr, rhs, x)
+            ms, na = ctypes.c_double(), ctypes.c_int32()
+            mg.lib().mgcr_gcr_last_profile(ctypes.byref(ms), ctypes.byref(na))
+            b_stored = stored["matrix_bytes"] + 2 * V
+            b_survey = nnz * 20 + (N + 1) * 4 + 2 * V
+            out.update(n=n, rows=N, nnz=nnz, iterations=iters, ms_per_iteration=dt * 1e3 / iters, it_per_s=iters / dt,
+                       spmv_ms_in_situ=ms.value, spmv_GBps_stored_layout=b_stored / ms.value / 1e6,
+                       spmv_frac_hbm_peak=b_stored / ms.value / 1e6 / HBM_PEAK_GBS,
+                       spmv_GBps_survey_formula=b_survey / ms.value / 1e6,
+                       iteration_bytes_survey=b_survey + 22 * V,
+                       iteration_GBps_survey=(b_survey + 22 * V) / dt * iters / 1e9,
+                       iteration_frac_hbm_peak_survey=(b_survey + 22 * V) / dt * iters / 1e9 / HBM_PEAK_GBS)
+        else:
+            t0 = time.perf_counter()
+            prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                           args.levels, None, None, null_vectors=np.ones((1, N), np.complex128))
+            M = MG(A, prm)
+            out["setup_mg_seconds_host"] = time.perf_counter() - t0
+            out["levels"] = [M.level_info(l) for l in range(args.levels + 1)]
+            # one V-cycle
+            y = Field(dims)
+            M(rhs, out=y)
+            mg.lib().mgcr_synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                M(rhs, out=y)
+            mg.lib().mgcr_synchronize()
+            out["vcycle_ms"] = (time.perf_counter() - t0) * 1e3 / reps
+            tol = 1e-8
+            outer = GCR(A, GCR_Param(0, 5, 200, tol, False, None, M, flexible=True, check_every=2))
+            dt = timed_solve(mg, outer, rhs, x)
+            r = rhs - A(x)
+            out.update(n=n, rows=N, nnz=nnz, tol=tol, outer_iterations=outer.last_iterations, converged=outer.last_converged,
+                       seconds_to_tol=dt, outer_it_per_s=outer.last_iterations / dt, history=[float(h) for h in outer.last_history],
+                       true_rel_residual=r.norm() / rhs.norm())
+            # unpreconditioned, same tolerance, for comparison (bounded)
+            x.set_zero()
+            plain = GCR(A, GCR_Param(0, 5, 3000, tol, False, check_every=50))
+            dtp = timed_solve(mg, plain, rhs, x)
+            out.update(plain_iterations=plain.last_iterations, plain_converged=plain.last_converged, plain_seconds=dtp,
+                       plain_final=float(plain.last_history[-1]))
+    else:
+        rng = np.random.default_rng(5)
+        bs = 20
+        nb = 36000  # block rows; ~9.6 blocks/row on average -> ~2.2 GB of blocks
+        per_row = np.where(rng.random(nb) < 0.8, rng.integers(5, 10, nb), rng.integers(10, 65, nb))
+        rows = np.repeat(np.arange(nb, dtype=np.int32), per_row)
+        cols = rng.integers(0, nb, rows.size).astype(np.int32)
+        # first block of every row is the diagonal block
+        first = np.concatenate([[0], np.cumsum(per_row)[:-1]])
+        cols[first] = np.arange(nb, dtype=np.int32)
+        nblk = rows.size
+        blocks = np.empty((nblk, bs, bs), np.complex128)
+        chunk = 20000
+        for s in range(0, nblk, chunk):
+            e = min(nblk, s + chunk)
+            blocks[s:e] = (rng.uniform(-1, 1, (e - s, bs, bs)) + 1j * rng.uniform(-1, 1, (e - s, bs, bs))) * (0.5 / bs)
+        # diagonally dominant: diag block = I * (1 + sum of off-diagonal block norms)  
+        offsum = np.bincount(rows, weights=np.abs(blocks).sum(axis=(1, 2)) / bs, minlength=nb)
+        blocks[first] = np.eye(bs)[None] * (1.0 + offsum)[:, None, None]
+        H = HierarchicalSparse(nb, nb, rows, cols, blocks)
+        del blocks
+        n = nb * bs
+        xf = Field((n,)).fill_rhs(1)
+        yf = Field((n,))
+        ms = H.bench_apply(xf, yf, reps=20)
+        b_alg = nblk * (bs * bs * 16 + 4) + (nb + 1) * 4 + 2 * n * 16
+        out.update(block_rows=nb, bs=bs, blocks=int(nblk), blocks_per_row_min=int(per_row.min()), blocks_per_row_max=int(per_row.max()),
+                   matrix_GB=nblk * bs * bs * 16 / 1e9, apply_ms=ms, algorithmic_bytes=b_alg, GBps=b_alg / ms / 1e6,
+                   frac_hbm_peak=b_alg / ms / 1e6 / HBM_PEAK_GBS)
+        rhs = Field((n,)).fill_rhs(2)
+        x = Field((n,)).set_zero()
+        gcr = GCR(H, GCR_Param(0, 5, 200, 1e-10, False, check_every=5))
+        dt = timed_solve(mg, gcr, rhs, x)
+        r = rhs - H(x)
+        out.update(gcr_iterations=gcr.last_iterations, gcr_converged=gcr.last_converged, gcr_seconds=dt,
+                   gcr_it_per_s=gcr.last_iterations / dt, true_rel_residual=r.norm() / rhs.norm())
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
