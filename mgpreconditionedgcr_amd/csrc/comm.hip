@@ -385,6 +385,39 @@ void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *in
 
 Comm *dist_comm(DistCsr *d) { return d->comm; }
 
+void dist_sizes(DistCsr *d, int64_t *nloc, int64_t *nh, int64_t *row0, int64_t *n_global, int *rank, int *nranks) {
+    if (nloc) *nloc = d->plan->nloc;
+    if (nh) *nh = (int64_t)d->plan->halo_gid.size();
+    if (row0) *row0 = d->plan->row0;
+    if (n_global) *n_global = d->plan->n_global;
+    if (rank) *rank = d->comm->rank;
+    if (nranks) *nranks = d->comm->nranks;
+}
+
+int comm_allreduce_host_pub(Comm *c, double *buf, int64_t count) { return comm_allreduce_host(c, buf, count); }
+
+// host-level halo exchange of w doubles per row (set-up data: aggregate ids, prolongator rows):
+// own[nloc*w] -> halo[nh*w], same lists as the SpMV halo
+int dist_exchange_rows_host(DistCsr *d, const double *own, int w, double *halo) {
+    Plan *P = d->plan;
+    const int np = (int)P->peers.size();
+    std::vector<std::vector<double>> sb((size_t)np);
+    std::vector<const double *> sp((size_t)np);
+    std::vector<double *> rp((size_t)np);
+    std::vector<int64_t> sc((size_t)np), rc((size_t)np);
+    for (int p = 0; p < np; p++) {
+        const std::vector<int64_t> &rows = P->send_rows[(size_t)p];
+        sb[(size_t)p].resize(rows.size() * (size_t)w);
+        for (size_t i = 0; i < rows.size(); i++)
+            memcpy(sb[(size_t)p].data() + i * (size_t)w, own + (size_t)rows[i] * (size_t)w, sizeof(double) * (size_t)w);
+        sp[(size_t)p] = sb[(size_t)p].data();
+        sc[(size_t)p] = (int64_t)rows.size() * w;
+        rp[(size_t)p] = halo + (size_t)P->recv_off[(size_t)p] * (size_t)w;
+        rc[(size_t)p] = P->recv_count[(size_t)p] * w;
+    }
+    return comm_exchange_host(d->comm, np, P->peers.data(), sp.data(), sc.data(), rp.data(), rc.data());
+}
+
 void dist_free(DistCsr *d) {
     if (!d) return;
     hipFree(d->xh); hipFree(d->sendbuf); hipFree(d->send_idx);

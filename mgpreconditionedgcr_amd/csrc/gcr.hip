@@ -617,8 +617,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     // compute stream, and consumers read the global scalars (stride 1, one "partial").
     Comm *comm = s->A->kind == OP_DIRAC ? s->A->base->comm : s->A->comm;
     const bool multi = comm_collectives(comm);
-    MGCR_CHECK(!multi || (!p.left_precond && !p.right_precond), MGCR_ERR_UNSUPPORTED,
-               "preconditioned GCR on a distributed operator is not available yet");
+    MGCR_CHECK(!multi || (!p.left_precond && (!p.right_precond || flex)), MGCR_ERR_UNSUPPORTED,
+               "on a distributed operator only flexible right preconditioning is available (set flexible = 1)");
     const DevState *cst = s->st;
     KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
     KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, 0);

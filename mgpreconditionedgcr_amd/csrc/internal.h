@@ -157,6 +157,12 @@ int dist_halo_begin(DistCsr *d, const cplx *x);
 int dist_halo_end(DistCsr *d);
 void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *interior_end);
 void dist_free(DistCsr *d);
+Comm *dist_comm(DistCsr *d);
+void dist_sizes(DistCsr *d, int64_t *nloc, int64_t *nh, int64_t *row0, int64_t *n_global, int *rank, int *nranks);
+int comm_allreduce_host_pub(Comm *c, double *buf, int64_t count);
+int dist_exchange_rows_host(DistCsr *d, const double *own, int w, double *halo);
+int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col,
+                    const double *val_ri, Op *op);
 int comm_nranks(Comm *c);
 bool comm_collectives(Comm *c);
 int comm_allreduce_dev(Comm *c, double *dbuf, int count);

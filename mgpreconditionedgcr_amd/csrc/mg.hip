@@ -161,10 +161,12 @@ struct CoarseBlocks {
 // Galerkin blocks P_{a'}^H (A P_a) for every coupled pair of aggregates (src/MG.h:216-274), with the
 // reference's evaluation order: row sum over the columns of aggregate a in CSR order, optional Dirac
 // shift y = x - k*sum, then the dot over the rows of a' ascending.
-static void galerkin(const HostCsr &A, bool shift, hc kshift, int ne, int64_t nagg, const std::vector<int32_t> &agg,
+// Multi-GPU: rows are this rank's aggregates (nagg of them); `agg` and `pv` cover the owned rows AND the
+// halo columns, halo aggregates carrying ids >= nagg (nagg_cols in total).
+static void galerkin(const HostCsr &A, bool shift, hc kshift, int ne, int64_t nagg, int64_t nagg_cols, const std::vector<int32_t> &agg,
                      const std::vector<int32_t> &ptr, const std::vector<int32_t> &mem, const std::vector<hc> &pv, CoarseBlocks &out) {
     const hc *val = reinterpret_cast<const hc *>(A.val_ri.data());
-    std::vector<int32_t> mark((size_t)nagg, -1), nbr;
+    std::vector<int32_t> mark((size_t)nagg_cols, -1), nbr;
     std::vector<hc> t((size_t)ne);
     out.browptr.assign((size_t)nagg + 1, 0);
     out.bcol.clear();
@@ -316,7 +318,7 @@ void mg_destroy(MgState *m) {
         hipFree(L.x); hipFree(L.b); hipFree(L.r);
         gcr_state_destroy(L.pre); gcr_state_destroy(L.post); gcr_state_destroy(L.coarse);
         if (L.owns_A && L.A) {
-            if (L.A->kind == OP_CSR) csr_free(&L.A->csr);
+            if (L.A->kind == OP_CSR) { csr_free(&L.A->csr); dist_free(L.A->dist); }
             if (L.A->kind == OP_BCSR) bcsr_free(&L.A->bcsr);
             delete static_cast<mgcr_op_s *>(L.A);
         }
@@ -329,12 +331,15 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
                "mgcr_mg_create: the fine operator must be a Sparse or a DiracOp");
     MGCR_CHECK(p->ndim >= 1 && p->ndim <= 8 && p->n_vec >= 1 && p->vecs_ri && p->n_level >= 1 && p->n_level <= 6,
                MGCR_ERR_INVALID, "mgcr_mg_create: bad parameters");
-    const CsrDev &A0 = A->kind == OP_DIRAC ? A->base->csr : A->csr;
-    MGCR_CHECK(A0.nrow == A0.ncol, MGCR_ERR_INVALID, "mgcr_mg_create: operator must be square");
+    Op *base0 = A->kind == OP_DIRAC ? A->base : A;
+    const CsrDev &A0 = base0->csr;
+    const bool distributed = base0->dist != nullptr;
+    MGCR_CHECK(distributed || A0.nrow == A0.ncol, MGCR_ERR_INVALID, "mgcr_mg_create: operator must be square");
     int64_t n = 1;
     int nblocked = 0;
     for (int d = 0; d < p->ndim; d++) { n *= p->dims[d]; nblocked += p->blocked[d] ? 1 : 0; }
-    MGCR_CHECK(n == A0.nrow, MGCR_ERR_INVALID, "mgcr_mg_create: mesh has %lld points, operator has %lld rows", (long long)n, (long long)A0.nrow);
+    // distributed operator: the mesh describes THIS RANK's row block (e.g. its slab of planes)
+    MGCR_CHECK(n == A0.nrow, MGCR_ERR_INVALID, "mgcr_mg_create: mesh has %lld points, operator has %lld (local) rows", (long long)n, (long long)A0.nrow);
     MGCR_CHECK(nblocked >= 1 && nblocked <= 4, MGCR_ERR_INVALID, "mgcr_mg_create: 1..4 dimensions can be blocked");
 
     MgState *m = new MgState();
@@ -353,6 +358,7 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
     memcpy((void *)vecs.data(), p->vecs_ri, sizeof(hc) * (size_t)ne * n);
     m->lev[0].A = A;
     m->lev[0].n = n;
+    DistCsr *dist = base0->dist;  // distribution of the current level's operator
     for (int l = 0; rc == MGCR_OK && l + 1 < nlev; l++) {
         MgLevel &L = m->lev[(size_t)l];
         L.ne = ne;
@@ -365,8 +371,50 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
         std::vector<int32_t> ptr, mem;
         member_lists(L.n, L.nagg, L.h_agg, ptr, mem);
         build_prolongator(L.n, ne, L.nagg, ptr, mem, vecs.data(), L.h_pv);
+        // aggregate ids / prolongator rows of the columns the Galerkin product sees
+        int64_t nh = 0, agg_off = 0, nagg_glob = L.nagg, nagg_cols = L.nagg;
+        std::vector<int32_t> agg_ext;                 // owned rows, then halo slots (ids >= L.nagg)
+        std::vector<hc> pv_ext;
+        std::vector<int64_t> ext_gid;                 // global id of extended aggregate L.nagg + k
+        const std::vector<int32_t> *aggp = &L.h_agg;
+        const std::vector<hc> *pvp = &L.h_pv;
+        Comm *comm = nullptr;
+        if (dist) {
+            int rank = 0, nranks = 1;
+            dist_sizes(dist, nullptr, &nh, nullptr, nullptr, &rank, &nranks);
+            comm = dist_comm(dist);
+            std::vector<double> cnt((size_t)nranks, 0.);
+            cnt[(size_t)rank] = (double)L.nagg;
+            rc = comm_allreduce_host_pub(comm, cnt.data(), nranks);
+            if (rc != MGCR_OK) break;
+            nagg_glob = 0;
+            for (int r = 0; r < nranks; r++) { if (r == rank) agg_off = nagg_glob; nagg_glob += (int64_t)cnt[(size_t)r]; }
+            const int w = 1 + 2 * ne;
+            std::vector<double> own((size_t)L.n * w), halo((size_t)nh * w);
+            for (int64_t i = 0; i < L.n; i++) {
+                own[(size_t)i * w] = (double)(agg_off + L.h_agg[(size_t)i]);
+                memcpy(&own[(size_t)i * w + 1], &L.h_pv[(size_t)i * ne], sizeof(hc) * (size_t)ne);
+            }
+            rc = dist_exchange_rows_host(dist, own.data(), w, halo.data());
+            if (rc != MGCR_OK) break;
+            for (int64_t h = 0; h < nh; h++) ext_gid.push_back((int64_t)halo[(size_t)h * w]);
+            std::sort(ext_gid.begin(), ext_gid.end());
+            ext_gid.erase(std::unique(ext_gid.begin(), ext_gid.end()), ext_gid.end());
+            nagg_cols = L.nagg + (int64_t)ext_gid.size();
+            agg_ext = L.h_agg;
+            pv_ext = L.h_pv;
+            agg_ext.resize((size_t)(L.n + nh));
+            pv_ext.resize((size_t)(L.n + nh) * ne);
+            for (int64_t h = 0; h < nh; h++) {
+                int64_t g = (int64_t)halo[(size_t)h * w];
+                agg_ext[(size_t)(L.n + h)] = (int32_t)(L.nagg + (std::lower_bound(ext_gid.begin(), ext_gid.end(), g) - ext_gid.begin()));
+                memcpy(&pv_ext[(size_t)(L.n + h) * ne], &halo[(size_t)h * w + 1], sizeof(hc) * (size_t)ne);
+            }
+            aggp = &agg_ext;
+            pvp = &pv_ext;
+        }
         CoarseBlocks cb;
-        galerkin(hA, shift, kshift, ne, L.nagg, L.h_agg, ptr, mem, L.h_pv, cb);
+        galerkin(hA, shift, kshift, ne, L.nagg, nagg_cols, *aggp, ptr, mem, *pvp, cb);
         rc = up(&L.d_agg, L.h_agg.data(), (size_t)L.n);
         if (rc == MGCR_OK) rc = up(&L.d_aptr, ptr.data(), ptr.size());
         if (rc == MGCR_OK) rc = up(&L.d_amem, mem.data(), mem.size());
@@ -376,16 +424,30 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
         // coarse operator on the device
         MgLevel &C = m->lev[(size_t)l + 1];
         C.n = L.nagg * ne;
-        blocks_to_csr(cb, ne, L.nagg, hNext);
         Op *Ac = new mgcr_op_s();
         Ac->dim = Ac->nrow = C.n;
-        if (ne == 1) {
+        if (dist) {
+            // row block [agg_off*ne, (agg_off + nagg)*ne) of the global coarse matrix, global columns
+            HostCsr g;
+            blocks_to_csr(cb, ne, L.nagg, g);   // columns in extended local aggregate numbering
+            for (int64_t &cidx : g.col) {
+                int64_t a = cidx / ne, k = cidx % ne;
+                int64_t gid = a < L.nagg ? agg_off + a : ext_gid[(size_t)(a - L.nagg)];
+                cidx = gid * ne + k;
+            }
             Ac->kind = OP_CSR;
-            rc = csr_build_device(C.n, C.n, hNext.rowptr.data(), hNext.col.data(), hNext.val_ri.data(), &Ac->csr);
+            rc = dist_csr_create(comm, nagg_glob * ne, agg_off * ne, C.n, g.rowptr.data(), g.col.data(), g.val_ri.data(), Ac);
+            if (rc == MGCR_OK) rc = csr_download_host(Ac->csr, &hNext);  // local numbering incl. halo slots, for the next level
         } else {
-            Ac->kind = OP_BCSR;
-            rc = bcsr_build_device((int32_t)L.nagg, (int32_t)L.nagg, ne, cb.browptr.data(), cb.bcol.data(),
-                                   reinterpret_cast<const double *>(cb.blocks.data()), &Ac->bcsr);
+            blocks_to_csr(cb, ne, L.nagg, hNext);
+            if (ne == 1) {
+                Ac->kind = OP_CSR;
+                rc = csr_build_device(C.n, C.n, hNext.rowptr.data(), hNext.col.data(), hNext.val_ri.data(), &Ac->csr);
+            } else {
+                Ac->kind = OP_BCSR;
+                rc = bcsr_build_device((int32_t)L.nagg, (int32_t)L.nagg, ne, cb.browptr.data(), cb.bcol.data(),
+                                       reinterpret_cast<const double *>(cb.blocks.data()), &Ac->bcsr);
+            }
         }
         C.A = Ac;
         C.owns_A = true;
@@ -395,7 +457,7 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
         if (rc != MGCR_OK) break;
         // smoothers of this level
         mgcr_gcr_param sp = p->smoother;
-        sp.verbose = 0; sp.left_precond = sp.right_precond = nullptr; sp.flexible = 0;
+        sp.verbose = 0; sp.left_precond = sp.right_precond = nullptr; sp.flexible = 0; sp.profile_spmv = 0;
         sp.use_x0 = 0;
         rc = gcr_state_create(L.A, &sp, 1, &L.pre);
         sp.use_x0 = 1;
@@ -417,12 +479,13 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
             ndim = (int)dims.size();
             std::swap(hA, hNext);
             shift = false;
+            dist = Ac->dist;
         }
     }
     if (rc == MGCR_OK) {
         MgLevel &Z = m->lev[(size_t)nlev - 1];
         mgcr_gcr_param cp = p->coarse;
-        cp.verbose = 0; cp.left_precond = cp.right_precond = nullptr; cp.flexible = 0; cp.use_x0 = 0;
+        cp.verbose = 0; cp.left_precond = cp.right_precond = nullptr; cp.flexible = 0; cp.use_x0 = 0; cp.profile_spmv = 0;
         rc = gcr_state_create(Z.A, &cp, 1, &Z.coarse);
     }
     if (rc != MGCR_OK) { mg_destroy(m); return rc; }

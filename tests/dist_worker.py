@@ -58,6 +58,29 @@ def main():
     from mgpreconditionedgcr_amd import Comm, Plan, problems
     comm = Comm.host(dist)
     results = {}
+    if mode == "mg":
+        # distributed 3-level aggregation MG as flexible right preconditioner (BASELINE config 4 shape, small)
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistSparse, Field, GCR, GCR_Param, MG, MG_Param, Mesh
+        mg.init(0)
+        n, planes = 8, 8                      # every rank owns 8 planes of an (8*world) x 8 x 8 grid
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n, rank * planes, (rank + 1) * planes, ni=world * planes)
+        A = DistSparse(comm, ncol, rank * N, rowptr, col, val)
+        dims = (planes, n, n)                 # LOCAL mesh of this rank's row block
+        prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                       2, None, None, null_vectors=np.ones((1, N), np.complex128))
+        M = MG(A, prm)
+        b = problems.rhs_grid(ncol, 3)[rank * N:(rank + 1) * N]
+        y = M(Field(dims, b)).to_numpy()
+        outer = GCR(A, GCR_Param(0, 5, 60, 1e-9, False, None, M, flexible=True, check_every=3))
+        x = Field(dims).set_zero()
+        outer.solve(Field(dims, b), x)
+        results["mg"] = dict(y=y, x=x.to_numpy(), hist=outer.last_history, its=outer.last_iterations,
+                             conv=outer.last_converged, levels=[M.level_info(l) for l in range(3)])
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for kind in ("poisson", "random"):
         N, rowptr, col, val, gran = problem(kind)
         offs = split_rows(N // gran, world)

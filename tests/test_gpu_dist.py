@@ -82,3 +82,37 @@ print("RCCL_OK")
     from tests.test_dist_cpu import free_port
     p = subprocess.run([sys.executable, "-c", code, str(free_port())], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_mg_gcr_matches_single_process(tmp_path, world):
+    """BASELINE config 4 in miniature: slab-partitioned Poisson, 3-level aggregation MG built
+    collectively (Galerkin across the slab boundaries, distributed coarse operators), flexible
+    outer GCR — against the single-process MG-GCR of the same global problem."""
+    from mgpreconditionedgcr_amd import MG, MG_Param, Mesh
+    mg.init()
+    res = run_workers("mg", world, tmp_path, timeout=500)
+    n, planes = 8, 8
+    ni = world * planes
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, 0, ni, ni=ni)
+    A = Sparse(N, ncol, rowptr, col, val)
+    dims = (ni, n, n)
+    prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   2, None, None, null_vectors=np.ones((1, N), np.complex128))
+    M = MG(A, prm)
+    b = problems.rhs_grid(N, 3)
+    y = M(Field(dims, b)).to_numpy()
+    yd = np.concatenate([res[r]["mg"]["y"] for r in range(world)])
+    for l in range(3):
+        assert sum(res[r]["mg"]["levels"][l]["dim"] for r in range(world)) == M.level_info(l)["dim"]
+    assert np.abs(yd - y).max() <= 1e-9 * np.abs(y).max()        # one V-cycle
+    outer = GCR(A, GCR_Param(0, 5, 60, 1e-9, False, None, M, flexible=True))
+    x = Field(dims).set_zero()
+    outer.solve(Field(dims, b), x)
+    for r in range(world):
+        assert res[r]["mg"]["conv"] and abs(res[r]["mg"]["its"] - outer.last_iterations) <= 1
+        m_ = min(res[r]["mg"]["hist"].size, outer.last_history.size)
+        assert np.allclose(res[r]["mg"]["hist"][1:m_], outer.last_history[1:m_], rtol=1e-5, atol=1e-15)
+    xd = np.concatenate([res[r]["mg"]["x"] for r in range(world)])
+    rr = Field(dims, b) - A(Field(dims, xd))
+    assert rr.norm() / np.linalg.norm(b) <= 2e-9
