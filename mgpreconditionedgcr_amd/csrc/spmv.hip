@@ -492,6 +492,70 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs
     if (lane + 64 < bs) y[(int64_t)brow * bs + lane + 64] = acc1;
 }
 
+// Same algorithm with the block's bs*bs entries held in registers: TT = ceil(bs*bs/64) (rounded up to
+// 1, 2, 4, 8, 16) matrix loads and x gathers per lane are ISSUED TOGETHER for every block, instead of
+// one dependent load per loop trip — the generic kernel above keeps a single 1-KiB load in flight per
+// wave and is latency-bound.  The (row, column) of each lane's entries does not depend on the block
+// and is computed once.  PREFETCH additionally keeps the NEXT block's loads in flight during the LDS
+// phase; measured on MI355X (bs = 20, 3 GB of blocks) it loses to the plain form (5.08 vs 5.28 TB/s:
+// 164 VGPRs cost a third of the resident waves), so it is compiled but not dispatched.
+template <int TT, bool PREFETCH>
+__global__ void __launch_bounds__(64) bcsr_wave_kernel_t(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
+                                                         const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
+                                                         const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                         const int *__restrict__ skip, int skip_it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
+    if (skip && *skip < skip_it) return;
+    const int32_t brow = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int32_t bs2 = bs * bs, ld = bs + 1;
+    const int32_t beg = browptr[brow], end = browptr[brow + 1];
+    int32_t ecol[TT], elds[TT];
+    bool live[TT];
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+        int32_t e = lane + 64 * t;
+        live[t] = e < bs2;
+        int32_t r = live[t] ? e / bs : 0;
+        ecol[t] = live[t] ? e - r * bs : 0;
+        elds[t] = r * ld + ecol[t];
+    }
+    cplx acc = make_double2(0., 0.);
+    cplx mv[TT], xv[TT], mn[TT], xn[TT];
+    auto fetch = [&](int32_t l, cplx (&mo)[TT], cplx (&xo)[TT]) {
+        const cplx *m = blocks + (int64_t)l * bs2;
+        const cplx *xb = x + (int64_t)bcol[l] * bs;
+#pragma unroll
+        for (int t = 0; t < TT; t++) {
+            mo[t] = live[t] ? m[lane + 64 * t] : make_double2(0., 0.);
+            xo[t] = xb[ecol[t]];
+        }
+    };
+    if (beg < end) fetch(beg, mv, xv);
+    for (int32_t l = beg; l < end; l++) {
+        // the next block's loads are in flight while this block goes through LDS
+        if (PREFETCH && l + 1 < end) fetch(l + 1, mn, xn);
+#pragma unroll
+        for (int t = 0; t < TT; t++)
+            if (live[t]) prod[elds[t]] = cmul(mv[t], xv[t]);
+        __syncthreads();
+        if (lane < bs) {
+            cplx o = make_double2(0., 0.);
+            for (int32_t cc = 0; cc < bs; cc++) o = cadd(o, prod[lane * ld + cc]);
+            acc = cadd(acc, o);
+        }
+        __syncthreads();
+        if (PREFETCH) {
+#pragma unroll
+            for (int t = 0; t < TT; t++) { mv[t] = mn[t]; xv[t] = xn[t]; }
+        } else if (l + 1 < end) {
+            fetch(l + 1, mv, xv);
+        }
+    }
+    if (lane < bs) y[(int64_t)brow * bs + lane] = acc;
+}
+
 void bcsr_free(BcsrDev *b) {
     hipFree(b->browptr); hipFree(b->bcol); hipFree(b->blocks);
     *b = BcsrDev();
@@ -525,8 +589,19 @@ int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y) {
         attr_set = true;
     }
     MGCR_CHECK(lds <= 160 * 1024, MGCR_ERR_UNSUPPORTED, "block size %d needs more than 160 KiB of LDS", A.bs);
-    hipLaunchKernelGGL(bcsr_wave_kernel, dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr,
-                       A.bcol, A.blocks, x, y, g_skip.p, g_skip.it);
+    const int tt = (A.bs * A.bs + 63) / 64;
+#define BT(T_)                                                                                                              \
+    hipLaunchKernelGGL((bcsr_wave_kernel_t<T_, false>), dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr, \
+                       A.bcol, A.blocks, x, y, g_skip.p, g_skip.it)
+    if (A.bs > 64 || tt > 16)  // rows beyond lane 63 / too many registers: generic kernel
+        hipLaunchKernelGGL(bcsr_wave_kernel, dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr,
+                           A.bcol, A.blocks, x, y, g_skip.p, g_skip.it);
+    else if (tt <= 1) BT(1);
+    else if (tt <= 2) BT(2);
+    else if (tt <= 4) BT(4);
+    else if (tt <= 8) BT(8);
+    else BT(16);
+#undef BT
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
