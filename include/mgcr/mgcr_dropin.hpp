@@ -689,4 +689,28 @@ inline Sparse<long> read_data(const std::string &filename) {
     return output;
 }
 
+// parse_data — src/Parse.cpp:9-61: MatrixMarket `complex coordinate` -> text CSR ("parsed.txt" next to the
+// sample data; $MGCR_SAMPLE_DIR overrides the directory).  Duplicates are summed by the triplet constructor.
+inline void parse_data(const std::string &file_loc) {
+    std::ifstream file(file_loc);
+    if (file) std::printf("File read is successful.\n");
+    else { std::printf("File read is unsuccessful!\n"); return; }
+    while (file.peek() == '%') file.ignore(1 << 20, '\n');
+    long rows = 0, cols = 0, elements = 0;
+    file >> rows >> cols >> elements;
+    std::vector<std::pair<std::complex<double>, std::pair<long, long>>> trip((size_t)elements);
+    for (long l = 0; l < elements; l++) {
+        long r, c;
+        double re, im;
+        file >> r >> c >> re >> im;
+        trip[(size_t)l] = {std::complex<double>(re, im), {r - 1, c - 1}};
+    }
+    Sparse<long> sparse(rows, cols, trip.data(), elements);
+    const char *pre = std::getenv("MGCR_SAMPLE_DIR");
+    std::ofstream out((pre ? std::string(pre) + "/" : std::string("../../data/sample_matrix/")) + "parsed.txt");
+    out << sparse.get_nrow() << " " << sparse.get_dim() << " " << sparse.get_nnz() << "\n";
+    for (long i = 0; i < sparse.get_nrow(); i++) out << sparse.get_ROW(i) << " ";
+    for (long j = 0; j < sparse.get_nnz(); j++) out << "\n" << sparse.get_COL(j) << " " << sparse.val_at(j);
+}
+
 #endif  // MGCR_DROPIN_HPP

@@ -9,6 +9,7 @@ from .api import (DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MG, MG_Par
                   Operator, Sparse, gamma5, read_data, vec_double)
 from . import problems  # noqa: F401
 from .distributed import Comm, DistSparse, Plan  # noqa: F401
+from . import experiments  # noqa: F401
 
 __all__ = ["init", "finalize", "lib", "MgcrError", "Field", "Operator", "Sparse", "DiracOp",
            "HierarchicalSparse", "GCR_Param", "GCR", "MG_Param", "MG", "Mesh", "gamma5", "vec_double", "read_data", "problems", "Comm", "Plan", "DistSparse"]
