@@ -123,6 +123,11 @@ typedef struct mgcr_gcr_param {
  * *n_iter = iterations performed (global_count); *converged = 0 iff n_iter == max_iter. */
 int mgcr_gcr_solve(mgcr_op_t A, const mgcr_gcr_param *param, mgcr_vec_t rhs, mgcr_vec_t x,
                    double *hist, int32_t hist_cap, int32_t *n_iter, int32_t *converged);
+/* Unpreconditioned solves on a single-GPU Sparse / DiracOp with at most `rows` unknowns (default
+ * 1024, $MGCR_SMALL_SOLVE_ROWS; and at most 16*rows stored entries) and <= 8 stored directions run
+ * as ONE launch of one workgroup (latency regime: coarsest multigrid levels); 0 disables that path.
+ * Same arithmetic, dot products summed in a different fixed order. */
+int mgcr_set_small_solve_rows(int64_t rows);
 /* GCR as an Operator (src/GCR.h:19-50,62-68): apply(f) solves A x = f.  A may be NULL and be
  * supplied later with mgcr_gcr_set_operator (GCR(GCR_Param*) + initialise(), src/GCR.h:30-31).
  * x0_mode 0: x0 = the vector given with mgcr_gcr_set_x0 (the reference seeds x0 with

@@ -200,6 +200,12 @@ int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0) {
     return gcr_state_set_x0(gcr->gcr, x0 ? x0->d : nullptr, x0 ? x0->n : 0);
 }
 
+int mgcr_set_small_solve_rows(int64_t rows) {
+    MGCR_CHECK(rows >= 0, MGCR_ERR_INVALID, "rows must be >= 0");
+    gcr_small_set_limit(rows);
+    return MGCR_OK;
+}
+
 int mgcr_gcr_last_profile(double *spmv_ms_avg, int32_t *n_applies) {
     MGCR_CHECK(spmv_ms_avg && n_applies, MGCR_ERR_INVALID, "null argument");
     double ms = 0.;

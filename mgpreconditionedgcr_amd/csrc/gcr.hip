@@ -579,6 +579,30 @@ static int launch_build(const BuildArgs &a) {
     }
 }
 
+// read back iteration count / history once the solve has been enqueued (not for nested solves)
+static int gcr_finish(GcrState *s, double *hist, int hist_cap, int *n_iter, int *converged) {
+    Context &c = ctx();
+    const mgcr_gcr_param &p = s->p;
+    MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
+    MGCR_HIP(hipStreamSynchronize(c.stream));
+    DevState hs = *(const DevState *)c.h_mail;
+    int it = hs.iter;
+    if (n_iter) *n_iter = it;
+    if (converged) *converged = (it == p.max_iter) ? 0 : 1;  // src/GCR.h:294-298
+    std::vector<double> hh((size_t)it + 1);
+    MGCR_HIP(hipMemcpy(hh.data(), s->hist, sizeof(double) * ((size_t)it + 1), hipMemcpyDeviceToHost));
+    if (hist)
+        for (int i = 0; i <= it && i < hist_cap; i++) hist[i] = hh[i];
+    if (p.verbose) {  // src/GCR.h:213-216,270-274,293-300
+        for (int i = 0; i <= it; i++) printf("Step %d residual norm = %.10e\n", i, hh[i]);
+        if (it == p.max_iter)
+            printf("GCR did not converge after %d steps! Residual norm = %.10e\n", p.max_iter, hh[it]);
+        else
+            printf("GCR converged after %d steps. Residual norm=%.10e\n", it, hh[it]);
+    }
+    return MGCR_OK;
+}
+
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged) {
     Context &c = ctx();
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
@@ -588,6 +612,15 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const int g = red_grid(n);
     const bool flex = p.flexible && p.right_precond;
     const SkipRef outer = get_apply_skip();  // outer solver's predicate: if that solve is over, this one is a no-op too
+
+    // small systems: the whole solve in one launch of one workgroup (gcr_small.hip)
+    if (gcr_small_eligible(s->A, p, s->storage, n)) {
+        MGCR_TRY(ensure_slot(s, s->storage - 1));
+        MGCR_TRY(gcr_small_run(s->A, p, s->storage, s->restart, rhs, x, s->r, s->ar, s->ps.data(), s->aps.data(), s->hist,
+                               s->hist_cap, &s->st->stop_at));
+        if (nested) return MGCR_OK;
+        return gcr_finish(s, hist, hist_cap, n_iter, converged);
+    }
 
     hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, c.stream, s->st, outer.p, outer.it, p.tol * p.tol);
     MGCR_HIP(hipGetLastError());
@@ -741,10 +774,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         MGCR_HIP(hipGetLastError());
     }
     if (nested) return MGCR_OK;
-
-    MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
-    MGCR_HIP(hipStreamSynchronize(c.stream));
     if (!prof_events.empty()) {
+        MGCR_HIP(hipStreamSynchronize(c.stream));
         double tot = 0.;
         for (size_t i = 0; i + 1 < prof_events.size(); i += 2) {
             float ms = 0.f;
@@ -755,22 +786,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         g_prof_spmv_ms = tot / g_prof_spmv_n;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
-    DevState hs = *(const DevState *)c.h_mail;
-    int it = hs.iter;
-    if (n_iter) *n_iter = it;
-    if (converged) *converged = (it == p.max_iter) ? 0 : 1;  // src/GCR.h:294-298
-    std::vector<double> hh((size_t)it + 1);
-    MGCR_HIP(hipMemcpy(hh.data(), s->hist, sizeof(double) * ((size_t)it + 1), hipMemcpyDeviceToHost));
-    if (hist)
-        for (int i = 0; i <= it && i < hist_cap; i++) hist[i] = hh[i];
-    if (p.verbose) {  // src/GCR.h:213-216,270-274,293-300
-        for (int i = 0; i <= it; i++) printf("Step %d residual norm = %.10e\n", i, hh[i]);
-        if (it == p.max_iter)
-            printf("GCR did not converge after %d steps! Residual norm = %.10e\n", p.max_iter, hh[it]);
-        else
-            printf("GCR converged after %d steps. Residual norm=%.10e\n", it, hh[it]);
-    }
-    return MGCR_OK;
+    return gcr_finish(s, hist, hist_cap, n_iter, converged);
 }
 
 // x = init_rand(2) in the reference (src/GCR.h:63-68); here the caller-provided x0 or zero

@@ -185,6 +185,12 @@ void gcr_state_set_use_x0(GcrState *s, bool use_x0);
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);
 void gcr_last_profile(double *ms, int *n);
 
+// ---- gcr_small.hip ---------------------------------------------------------------------------
+void gcr_small_set_limit(int64_t rows);
+bool gcr_small_eligible(const Op *A, const mgcr_gcr_param &p, int storage, int64_t n);
+int gcr_small_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, const cplx *rhs, cplx *x, cplx *r, cplx *ar,
+                  cplx *const *ps, cplx *const *aps, double *hist, int hist_cap, int *state);
+
 }  // namespace mgcr
 
 struct mgcr_vec_s : mgcr::Vec {};

@@ -33,11 +33,21 @@ def _init():
     yield
 
 
+@pytest.fixture(params=["multi-kernel", "one-workgroup"], autouse=True)
+def solver_path(request):
+    """Every test runs twice: with the one-workgroup small-system solver (gcr_small.hip) switched
+    off, so that small test systems exercise the fused multi-kernel loop that large systems use, and
+    with it forced on for systems up to 16384 rows (default: 1024)."""
+    mg.lib().mgcr_set_small_solve_rows(0 if request.param == "multi-kernel" else 16384)
+    yield request.param
+    mg.lib().mgcr_set_small_solve_rows(1024)
+
+
 def its_close(it, it_ref, its_range=None):
     """Iterations to convergence: +-1, widened by the spread the reference algorithm itself shows
     under re-association of its dot products (see module docstring)."""
     lo, hi = (it_ref, it_ref) if its_range is None else its_range
-    slack = max(1, hi - lo)
+    slack = max(1, 3 * (hi - lo))  # two alternative orders only sample the spread: allow three times what they show
     return lo - slack <= it <= hi + slack
 
 
