@@ -32,6 +32,10 @@
 namespace mgcr {
 
 constexpr int ND = 8;  // directions per multidot / build launch
+#ifndef MGCR_NT_SLOTS
+#define MGCR_NT_SLOTS 1
+#endif
+constexpr bool NTS = MGCR_NT_SLOTS != 0;  // non-temporal access to the old direction slots
 
 struct DevState {
     // Iteration at which the solve ended (INT_MAX while running).  Every kernel of the solve gets the
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *_
             if (i < n) {
                 a[u] = ar[i];
 #pragma unroll
-                for (int j = 0; j < NDT; j++) b[u][j] = d.aps[j][i];
+                for (int j = 0; j < NDT; j++) b[u][j] = ld_stream<NTS>(d.aps[j] + i);
             } else {
                 a[u] = make_double2(0., 0.);
 #pragma unroll
@@ -305,8 +309,8 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
         cplx pj[NDT], aj[NDT];
 #pragma unroll
         for (int j = 0; j < NDT; j++) {
-            pj[j] = d.ps[j][i];
-            aj[j] = d.aps[j][i];
+            pj[j] = ld_stream<NTS>(d.ps[j] + i);
+            aj[j] = ld_stream<NTS>(d.aps[j] + i);
         }
         cplx pc = FIRST ? make_double2(0., 0.) : accp[i];
         cplx ac = FIRST ? make_double2(0., 0.) : accap[i];
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
         if (LAST) {
             cplx pn = cadd(dv, pc);
             cplx an = cadd(av, ac);
-            p_out[i] = pn;
+            st_stream<NTS>(p_out + i, pn);  // p is next read as an "old slot"; Ap' is read by the very next kernel
             ap_out[i] = an;
             cplx t = cconj_mul(rv, an);
             v[0] += t.x; v[1] += t.y;

@@ -27,6 +27,24 @@ __device__ __forceinline__ cplx cdiv(cplx n, cplx d) {
     }
 }
 
+// Non-temporal access to streams that are touched once per solver iteration (old direction slots):
+// they then do not displace the vectors that ARE re-used within the iteration (r, Ar, the newest Ap)
+// from L2 / the 256 MiB Infinity Cache.
+template <bool NT>
+__device__ __forceinline__ cplx ld_stream(const cplx *p) {
+    if (NT) return make_double2(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y));
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(cplx *p, cplx v) {
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+    } else {
+        *p = v;
+    }
+}
+
 // Re-materialise a wave-uniform double in scalar registers (frees 2 VGPRs per value)
 __device__ __forceinline__ double to_sgpr(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));

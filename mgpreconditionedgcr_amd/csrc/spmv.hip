@@ -272,16 +272,29 @@ __device__ __forceinline__ cplx gather_x(const cplx *__restrict__ x, const cplx 
 }
 
 // one stored value times an x entry; REALV: the value is a real fp64
-template <bool REALV>
+// NT: the matrix stream is read exactly once per SpMV — load it non-temporally so that it does not
+// displace the vectors (x, and the solver's r / Ar / direction slots) from L2 and the Infinity Cache.
+template <bool REALV, bool NT = false>
 __device__ __forceinline__ cplx vmul(const void *__restrict__ val, int64_t idx, cplx xv) {
     if (REALV) {
-        double v = reinterpret_cast<const double *>(val)[idx];
+        const double *p = reinterpret_cast<const double *>(val) + idx;
+        double v = NT ? __builtin_nontemporal_load(p) : *p;
         return make_double2(v * xv.x, v * xv.y);
     }
-    return cmul(reinterpret_cast<const cplx *>(val)[idx], xv);
+    const cplx *p = reinterpret_cast<const cplx *>(val) + idx;
+    cplx v;
+    if (NT) {
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+    } else {
+        v = *p;
+    }
+    return cmul(v, xv);
 }
+template <bool NT>
+__device__ __forceinline__ int32_t ldcol(const int32_t *__restrict__ p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 
-template <int WT, bool SHIFT, bool XCD, bool REALV>
+template <int WT, bool SHIFT, bool XCD, bool REALV, bool NT>
 __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int64_t row_count, int64_t npad, int32_t Wrt,
                                                           int64_t ntiles, const void *__restrict__ val,
                                                           const int32_t *__restrict__ col, const cplx *__restrict__ x,
@@ -299,16 +312,16 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
         int32_t j[WT ? WT : 1];
         cplx xv[WT ? WT : 1];
 #pragma unroll
-        for (int32_t c = 0; c < W; c++) j[c] = col[(int64_t)c * npad + row];
+        for (int32_t c = 0; c < W; c++) j[c] = ldcol<NT>(col + (int64_t)c * npad + row);
 #pragma unroll
         for (int32_t c = 0; c < W; c++) xv[c] = gather_x(x, xh, n_own, j[c]);
 #pragma unroll
-        for (int32_t c = 0; c < W; c++) sum = cadd(sum, vmul<REALV>(val, (int64_t)c * npad + row, xv[c]));
+        for (int32_t c = 0; c < W; c++) sum = cadd(sum, vmul<REALV, NT>(val, (int64_t)c * npad + row, xv[c]));
     } else {
 #pragma unroll 4
         for (int32_t c = 0; c < W; c++) {
-            int32_t j = col[(int64_t)c * npad + row];
-            sum = cadd(sum, vmul<REALV>(val, (int64_t)c * npad + row, gather_x(x, xh, n_own, j)));
+            int32_t j = ldcol<NT>(col + (int64_t)c * npad + row);
+            sum = cadd(sum, vmul<REALV, NT>(val, (int64_t)c * npad + row, gather_x(x, xh, n_own, j)));
         }
     }
     y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
@@ -379,9 +392,17 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
         bool xcd = ntiles >= 64;
         unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
         const void *vals = A.ell_val_re ? (const void *)A.ell_val_re : (const void *)A.ell_val;
-#define RT(WT, X, RV)                                                                                                        \
-    hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X, RV>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, \
-                       A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it)
+        // on by default (+3 % GCR iterations/s at 128^3, measured); MGCR_SPMV_NT=0 turns it off
+        static const bool nt = !(getenv("MGCR_SPMV_NT") && atoi(getenv("MGCR_SPMV_NT")) == 0);
+#define RT(WT, X, RV)                                                                                                            \
+    do {                                                                                                                         \
+        if (nt)                                                                                                                  \
+            hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X, RV, true>), dim3(grid), dim3(256), 0, c.stream, row_begin,      \
+                               row_count, A.npad, A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it);        \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X, RV, false>), dim3(grid), dim3(256), 0, c.stream, row_begin,     \
+                               row_count, A.npad, A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it);        \
+    } while (0)
         if (A.ell_val_re) {
             if (A.W == 7) { if (xcd) RT(7, true, true); else RT(7, false, true); }
             else { if (xcd) RT(0, true, true); else RT(0, false, true); }
