@@ -10,10 +10,12 @@
 //   m_coarse = HierarchicalSparse src/MG.h:281          block-CSR (ne > 1) or ELL/CSR (ne == 1)
 //   MG::solve                    src/MG.h:405-430       corrected V-cycle, see mg_cycle()
 //
-// Round-1 split: the set-up (aggregates, Gram-Schmidt, Galerkin) runs on the host from a copy of
-// the operator pulled back from HBM — it is SURVEY §8(f) rank 1 ("next"); everything the solve
-// touches per iteration (restrict, prolong+add, residual, smoothers, coarse solve) is HIP and is
-// enqueued on the library stream without host round trips.
+// The set-up (aggregates, Gram-Schmidt, Galerkin) exists twice with identical arithmetic: on the
+// device (mg_setup.hip, the default for single-GPU operators) and on the host from a copy of the
+// operator pulled back from HBM (this file; used for distributed operators, whose halo rows travel
+// through host-level exchanges, and by the tests as the cross-check).  Everything the solve touches
+// per iteration (restrict, prolong+add, residual, smoothers, coarse solve) is HIP and is enqueued
+// on the library stream without host round trips.
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -326,7 +328,7 @@ void mg_destroy(MgState *m) {
     delete m;
 }
 
-int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
+static int mg_create_host(Op *A, const mgcr_mg_param *p, MgState **out) {
     MGCR_CHECK(A && (A->kind == OP_CSR || A->kind == OP_DIRAC), MGCR_ERR_UNSUPPORTED,
                "mgcr_mg_create: the fine operator must be a Sparse or a DiracOp");
     MGCR_CHECK(p->ndim >= 1 && p->ndim <= 8 && p->n_vec >= 1 && p->vecs_ri && p->n_level >= 1 && p->n_level <= 6,
@@ -493,7 +495,97 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
     return MGCR_OK;
 }
 
+int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *blocked, int64_t sub, int ne, const cplx *d_vecs,
+                          int64_t *nagg_out, int32_t **d_agg, int32_t **d_aptr, int32_t **d_amem, cplx **d_pv, Op **coarse,
+                          bool want_next, cplx **d_vecs_next);
+
+// Hierarchy built on the device (mg_setup.hip): single-GPU operators.
+static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
+    const CsrDev &A0 = (A->kind == OP_DIRAC ? A->base : A)->csr;
+    MGCR_CHECK(A0.nrow == A0.ncol, MGCR_ERR_INVALID, "mgcr_mg_create: operator must be square");
+    int64_t n = 1;
+    int nblocked = 0;
+    for (int d = 0; d < p->ndim; d++) { n *= p->dims[d]; nblocked += p->blocked[d] ? 1 : 0; }
+    MGCR_CHECK(n == A0.nrow, MGCR_ERR_INVALID, "mgcr_mg_create: mesh has %lld points, operator has %lld rows", (long long)n, (long long)A0.nrow);
+    MGCR_CHECK(nblocked >= 1 && nblocked <= 4, MGCR_ERR_INVALID, "mgcr_mg_create: 1..4 dimensions can be blocked");
+    MgState *m = new MgState();
+    m->damping = p->damping;
+    const int nlev = p->n_level + 1;
+    m->lev.resize((size_t)nlev);
+    int ndim = p->ndim, ne = p->n_vec;
+    std::vector<int64_t> dims(p->dims, p->dims + ndim);
+    std::vector<int32_t> blocked(p->blocked, p->blocked + ndim);
+    m->lev[0].A = A;
+    m->lev[0].n = n;
+    cplx *d_vecs = nullptr;
+    int rc = up(&d_vecs, reinterpret_cast<const cplx *>(p->vecs_ri), (size_t)ne * n);
+    for (int l = 0; rc == MGCR_OK && l + 1 < nlev; l++) {
+        MgLevel &L = m->lev[(size_t)l];
+        MgLevel &C = m->lev[(size_t)l + 1];
+        L.ne = ne;
+        Op *Ac = nullptr;
+        cplx *d_next = nullptr;
+        rc = mg_level_setup_device(L.A, ndim, dims.data(), blocked.data(), p->subblock_dim, ne, d_vecs, &L.nagg, &L.d_agg, &L.d_aptr,
+                                   &L.d_amem, &L.d_pv, &Ac, l + 2 < nlev, &d_next);
+        if (rc != MGCR_OK) break;
+        C.A = Ac;
+        C.owns_A = true;
+        C.n = L.nagg * ne;
+        rc = up<cplx>(&L.r, nullptr, (size_t)L.n);
+        if (rc == MGCR_OK) rc = up<cplx>(&C.x, nullptr, (size_t)C.n);
+        if (rc == MGCR_OK) rc = up<cplx>(&C.b, nullptr, (size_t)C.n);
+        if (rc != MGCR_OK) break;
+        mgcr_gcr_param sp = p->smoother;
+        sp.verbose = 0; sp.left_precond = sp.right_precond = nullptr; sp.flexible = 0; sp.profile_spmv = 0;
+        sp.use_x0 = 0;
+        rc = gcr_state_create(L.A, &sp, 1, &L.pre);
+        sp.use_x0 = 1;
+        if (rc == MGCR_OK) rc = gcr_state_create(L.A, &sp, 1, &L.post);
+        if (rc != MGCR_OK) break;
+        hipFree(d_vecs);
+        d_vecs = d_next;
+        std::vector<int64_t> d2;
+        std::vector<int32_t> b2;
+        for (int d = 0; d < ndim; d++)
+            if (blocked[(size_t)d]) { d2.push_back(dims[(size_t)d] / p->subblock_dim); b2.push_back(1); }
+        d2.push_back(ne);
+        b2.push_back(0);
+        dims.swap(d2);
+        blocked.swap(b2);
+        ndim = (int)dims.size();
+    }
+    hipFree(d_vecs);
+    if (rc == MGCR_OK) {
+        MgLevel &Z = m->lev[(size_t)nlev - 1];
+        mgcr_gcr_param cp = p->coarse;
+        cp.verbose = 0; cp.left_precond = cp.right_precond = nullptr; cp.flexible = 0; cp.use_x0 = 0; cp.profile_spmv = 0;
+        rc = gcr_state_create(Z.A, &cp, 1, &Z.coarse);
+    }
+    if (rc != MGCR_OK) { mg_destroy(m); return rc; }
+    *out = m;
+    return MGCR_OK;
+}
+
+// MGCR_MG_HOST_SETUP=1 forces the host set-up (used by the tests to compare the two);
+// distributed operators always take it (their halo rows travel through host-level exchanges)
+int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
+    MGCR_CHECK(A && (A->kind == OP_CSR || A->kind == OP_DIRAC), MGCR_ERR_UNSUPPORTED,
+               "mgcr_mg_create: the fine operator must be a Sparse or a DiracOp");
+    MGCR_CHECK(p->ndim >= 1 && p->ndim <= 8 && p->n_vec >= 1 && p->vecs_ri && p->n_level >= 1 && p->n_level <= 6,
+               MGCR_ERR_INVALID, "mgcr_mg_create: bad parameters");
+    const bool distributed = (A->kind == OP_DIRAC ? A->base : A)->dist != nullptr;
+    const bool host = getenv("MGCR_MG_HOST_SETUP") && atoi(getenv("MGCR_MG_HOST_SETUP")) != 0;
+    if (distributed || host) return mg_create_host(A, p, out);
+    return mg_create_device(A, p, out);
+}
+
 static unsigned g256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+int mg_restrict_raw(int64_t nc, int ne, const int32_t *aptr, const int32_t *amem, const cplx *pv, const cplx *x, cplx *xc) {
+    hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, ne, aptr, amem, pv, x, xc, (const int *)nullptr, 0);
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
 
 int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc) {
     MgLevel &L = m->lev[(size_t)l];
@@ -603,8 +695,10 @@ int mgcr_mg_download_prolongator(mgcr_op_t mg, int32_t level, double *pv_ri, int
     MGCR_CHECK(mg && mg->kind == OP_MG, MGCR_ERR_INVALID, "not an MG operator");
     MGCR_CHECK(level >= 0 && level + 1 < (int32_t)mg->mg->lev.size(), MGCR_ERR_INVALID, "level %d out of range", level);
     const MgLevel &L = mg->mg->lev[(size_t)level];
-    if (pv_ri) memcpy(pv_ri, L.h_pv.data(), sizeof(hc) * L.h_pv.size());
-    if (agg) memcpy(agg, L.h_agg.data(), sizeof(int32_t) * L.h_agg.size());
+    LOCK();
+    if (ctx().ready) hipStreamSynchronize(ctx().stream);
+    if (pv_ri) MGCR_HIP(hipMemcpy(pv_ri, L.d_pv, sizeof(cplx) * (size_t)L.n * L.ne, hipMemcpyDeviceToHost));
+    if (agg) MGCR_HIP(hipMemcpy(agg, L.d_agg, sizeof(int32_t) * (size_t)L.n, hipMemcpyDeviceToHost));
     return MGCR_OK;
 }
 

@@ -221,6 +221,12 @@ static int ell_from_device_csr(int64_t nrow, int64_t ncol, const int64_t *h_rowp
     return MGCR_OK;
 }
 
+// device-resident CSR (int64 indices) -> ELL + tail; h_rowptr is the host copy of the row pointers
+int csr_build_from_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *d_rowptr, const int64_t *d_col,
+                          const cplx *d_val, CsrDev *out) {
+    return ell_from_device_csr(nrow, ncol, h_rowptr, d_rowptr, d_col, d_val, out);
+}
+
 int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *h_col, const double *h_val_ri,
                      CsrDev *out) {
     Context &c = ctx();

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-kernel achieved-HBM-rate table from a rocprofv3 --kernel-trace --stats CSV of `bench.py`
+(Poisson n^3, restart 5).  Bytes are the models of DESIGN.md section 3 for the stored layout.
+
+    python tools/roofline_table.py profiles/r01_bench_kernel_stats_v3.csv [n]
+"""
+import csv
+import re
+import sys
+
+path = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+N = n ** 3
+nnz = 7 * N - 6 * n * n
+V = 16 * N
+slab = 7 * ((N + 63) // 64 * 64)
+B_spmv = slab * 12 + 2 * V          # real-valued slab (8 B) + int32 column + x + y
+rows = list(csv.DictReader(open(path)))
+print("| kernel | calls | avg µs | bytes / launch (model) | GB/s | of 8 TB/s |")
+print("|---|---|---|---|---|---|")
+for r in rows:
+    name = r["Name"].split("(")[0].replace("void mgcr::", "").replace("mgcr::", "")
+    us = float(r["AverageNs"]) / 1e3
+    b = None
+    m = re.match(r"multidot_kernel<(\d+)", name)
+    if m:
+        b = (1 + int(m.group(1))) * V
+    m = re.match(r"build_kernel<(\d+), true, true, (true|false), (true|false)>", name)
+    if m:
+        lim = int(m.group(1))
+        b = (4 + 2 * lim) * V + (2 * V if m.group(3) == "true" else 0)   # + x read/write on the cycle-closing step
+    if name.startswith("xr_update_kernel<true>"):
+        b = 3 * V
+    if name.startswith("xr_update_kernel<false>"):
+        b = 6 * V
+    if name.startswith("ell_spmv_rowthread"):
+        b = B_spmv
+    if name.startswith("copy_kernel"):
+        b = 2 * V
+    if b is None or int(r["Calls"]) < 4:
+        continue
+    gbs = b / us / 1e3
+    print("| `%s` | %s | %.1f | %.1f MB | %.0f | %.2f |" % (name, r["Calls"], us, b / 1e6, gbs, gbs / 8000))
