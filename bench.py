@@ -126,9 +126,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # one solver object for all runs: its work vectors are allocated by the warm-up solve and re-used
+    # (GCR_Param is re-read at every solve, like the reference's GCR does with its GCR_Param*)
+    gparam = GCR_Param(0, args.restart, 1, 0.0, False)
+    gcr = GCR(A, gparam)
+
     def run(iters, profile=False):
         x.set_zero()
-        gcr = GCR(A, GCR_Param(0, args.restart, iters, 0.0, False, check_every=max(iters, 1), profile_spmv=profile))
+        gparam.max_iter, gparam.check_every, gparam.profile_spmv = iters, max(iters, 1), profile
         torch.cuda.synchronize()
         mg.lib().mgcr_synchronize()
         barrier()
@@ -145,8 +150,7 @@ def main():
         assert gcr.last_iterations == iters, (gcr.last_iterations, iters)
         return dt, gcr
 
-    if args.warmup > 0:
-        run(args.warmup)
+    run(max(args.warmup, 1))  # at least one untimed solve: it allocates the solver's work vectors
     dt, gcr = run(args.steps)
     hist = gcr.last_history
     ms_per_step = dt * 1e3 / args.steps
@@ -219,10 +223,17 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # orderly teardown: solver state and operator first, then the communicator, then the process group
+    del gcr, x, rhs, y
+    del A
     if dist is not None:
         dist.barrier()
-        del A, gcr
+        lib = mg.lib()
+        lib.mgcr_synchronize()
+        lib.mgcr_comm_destroy(comm.h)
+        comm.h = None
         dist.destroy_process_group()
+    mg.finalize()
 
 
 if __name__ == "__main__":

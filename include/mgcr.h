@@ -135,6 +135,13 @@ int mgcr_set_small_solve_rows(int64_t rows);
  * host round-trips: the device-side convergence flag turns the remaining iterations into no-ops. */
 int mgcr_gcr_create(mgcr_op_t A, const mgcr_gcr_param *param, int32_t x0_mode, mgcr_op_t *out);
 int mgcr_gcr_set_operator(mgcr_op_t gcr, mgcr_op_t A);
+/* GCR::solve(rhs, x) on a GCR object made with mgcr_gcr_create: same as mgcr_gcr_solve, but the
+ * work vectors (r, Ar, the direction slots, reduction slabs) live in the object and are re-used
+ * from solve to solve instead of being allocated and freed around every call.  The reference's GCR
+ * reads its GCR_Param* at solve time (src/GCR.h:171-185); mgcr_gcr_set_param is that refresh. */
+int mgcr_gcr_set_param(mgcr_op_t gcr, const mgcr_gcr_param *param);
+int mgcr_gcr_solve_op(mgcr_op_t gcr, mgcr_vec_t rhs, mgcr_vec_t x, double *hist, int32_t hist_cap,
+                      int32_t *n_iter, int32_t *converged);
 int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0);
 
 /* ---- MG: src/MG.h, src/Mesh.h, src/SolverParam.h:38-59 ------------------------------------ */

@@ -516,11 +516,14 @@ public:
         if (rhs.field_size() != this->dim) { std::fprintf(stderr, "Field dimension does not match with Operator!\n"); std::abort(); }
         if (x.field_size() != this->dim) { std::fprintf(stderr, "x dimension does not match with Operator!\n"); std::abort(); }
         if (param->truncation == 0 && param->restart == 0 && param->verbose) std::printf("WARNING: Full GCR solve could incur high memory usage!\n");
-        mgcr_gcr_param p = cparam();
+        mgcr_gcr_param p = cparam();  // GCR_Param is read at solve time, the work vectors live in the handle
         int cap = (param->max_iter > 0 ? param->max_iter : 1) + 1;
         history.assign((size_t)cap, 0.);
         int32_t it = 0, conv = 0;
-        mgcr_detail::ok(mgcr_gcr_solve(need_handle(A_operator), &p, rhs.device(), x.device(), history.data(), cap, &it, &conv), "GCR::solve");
+        mgcr_op_t self = handle();
+        mgcr_detail::ok(mgcr_gcr_set_operator(self, need_handle(A_operator)), "GCR::solve");
+        mgcr_detail::ok(mgcr_gcr_set_param(self, &p), "GCR::solve");
+        mgcr_detail::ok(mgcr_gcr_solve_op(self, rhs.device(), x.device(), history.data(), cap, &it, &conv), "GCR::solve");
         x.device_written();
         history.resize((size_t)it + 1);
         iterations = it; converged = conv != 0;

@@ -82,6 +82,8 @@ _SIGS = {
     "mgcr_gcr_create": (C.c_int, [_vp, C.POINTER(GcrParamC), C.c_int32, C.POINTER(_vp)]),
     "mgcr_gcr_set_operator": (C.c_int, [_vp, _vp]),
     "mgcr_gcr_set_x0": (C.c_int, [_vp, _vp]),
+    "mgcr_gcr_set_param": (C.c_int, [_vp, C.POINTER(GcrParamC)]),
+    "mgcr_gcr_solve_op": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mgcr_mg_create": (C.c_int, [_vp, C.POINTER(MgParamC), C.POINTER(_vp)]),
     "mgcr_mg_level_info": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "mgcr_mg_restrict": (C.c_int, [_vp, C.c_int32, _vp, _vp]),

@@ -283,9 +283,9 @@ class GCR(Operator):
         cap = max(self.param.max_iter, 1) + 1
         hist = np.zeros(cap, np.float64)
         it, conv = C.c_int32(), C.c_int32()
-        pc = self.param._c()
-        check(_lib.lib().mgcr_gcr_solve(self.A.h, C.byref(pc), rhs.h, x.h, hist.ctypes.data, cap,
-                                        C.byref(it), C.byref(conv)))
+        pc = self.param._c()  # the reference reads its GCR_Param* at solve time: refresh, keep the work vectors
+        check(_lib.lib().mgcr_gcr_set_param(self.h, C.byref(pc)))
+        check(_lib.lib().mgcr_gcr_solve_op(self.h, rhs.h, x.h, hist.ctypes.data, cap, C.byref(it), C.byref(conv)))
         self.last_iterations = it.value
         self.last_converged = bool(conv.value)
         self.last_history = hist[: it.value + 1].copy()

@@ -193,6 +193,27 @@ int mgcr_gcr_set_operator(mgcr_op_t gcr, mgcr_op_t A) {
     return gcr_state_set_operator(gcr->gcr, A);
 }
 
+int mgcr_gcr_set_param(mgcr_op_t gcr, const mgcr_gcr_param *param) {
+    MGCR_CHECK(gcr && param && gcr->kind == OP_GCR, MGCR_ERR_INVALID, "mgcr_gcr_set_param: not a GCR operator");
+    LOCK();
+    return gcr_state_set_param(gcr->gcr, param);
+}
+
+int mgcr_gcr_solve_op(mgcr_op_t gcr, mgcr_vec_t rhs, mgcr_vec_t x, double *hist, int32_t hist_cap, int32_t *n_iter,
+                      int32_t *converged) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(gcr && rhs && x && gcr->kind == OP_GCR, MGCR_ERR_INVALID, "mgcr_gcr_solve_op: bad argument");
+    MGCR_CHECK(rhs->n == gcr->dim, MGCR_ERR_INVALID, "Field dimension does not match with Operator!");
+    MGCR_CHECK(x->n == gcr->dim, MGCR_ERR_INVALID, "x dimension does not match with Operator!");
+    MGCR_CHECK(rhs->d != x->d, MGCR_ERR_INVALID, "rhs and x must be different Fields");
+    LOCK();
+    int it = 0, conv = 0;
+    int rc = gcr_run(gcr->gcr, rhs->d, x->d, false, hist, hist_cap, &it, &conv);
+    if (n_iter) *n_iter = it;
+    if (converged) *converged = conv;
+    return rc;
+}
+
 int mgcr_gcr_set_x0(mgcr_op_t gcr, mgcr_vec_t x0) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(gcr && gcr->kind == OP_GCR, MGCR_ERR_INVALID, "mgcr_gcr_set_x0: not a GCR operator");

@@ -435,6 +435,13 @@ int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out
 
 void gcr_state_set_use_x0(GcrState *s, bool use_x0) { s->p.use_x0 = use_x0 ? 1 : 0; }
 
+int gcr_state_set_param(GcrState *s, const mgcr_gcr_param *p) {
+    MGCR_CHECK(p->truncation == 0 || p->restart == 0, MGCR_ERR_INVALID, "Do not support concurrent restarting and truncation.");
+    MGCR_CHECK(p->truncation >= 0 && p->restart >= 0 && p->max_iter >= 0, MGCR_ERR_INVALID, "negative GCR parameter");
+    s->p = *p;
+    return MGCR_OK;
+}
+
 int gcr_state_set_operator(GcrState *s, Op *A) {
     s->A = A;
     return MGCR_OK;
@@ -477,9 +484,6 @@ static int gcr_prepare(GcrState *s, int64_t n) {
         MGCR_TRY(dalloc(&s->ar, (size_t)n));
         MGCR_TRY(dalloc(&s->den, (size_t)storage));
         MGCR_TRY(dalloc(&s->alphas, (size_t)storage));
-        int cap = (p.max_iter > 0 ? p.max_iter : 1) + 1;
-        MGCR_TRY(dalloc(&s->hist, (size_t)cap));
-        s->hist_cap = cap;
         int bd = storage < ND ? ND : (storage + ND - 1) / ND * ND;
         MGCR_TRY(dalloc(&s->partsB, (size_t)2 * bd * RED_MAX_BLOCKS));
         MGCR_HIP(hipMemsetAsync(s->partsB, 0, sizeof(double) * (size_t)2 * bd * RED_MAX_BLOCKS, ctx().stream));
@@ -488,6 +492,14 @@ static int gcr_prepare(GcrState *s, int64_t n) {
         MGCR_HIP(hipMemsetAsync(s->dRB, 0, sizeof(double) * ((size_t)1 + 2 * bd), ctx().stream));
     }
     s->restart = restart;
+    {   // history buffer: grows with max_iter, everything else is kept across solves
+        int cap = (p.max_iter > 0 ? p.max_iter : 1) + 1;
+        if (cap > s->hist_cap) {
+            if (s->hist) { hipStreamSynchronize(ctx().stream); hipFree(s->hist); s->hist = nullptr; }
+            MGCR_TRY(dalloc(&s->hist, (size_t)cap));
+            s->hist_cap = cap;
+        }
+    }
     if (precond && !s->tmp) MGCR_TRY(dalloc(&s->tmp, (size_t)n));
     if (p.flexible && p.right_precond && !s->z) MGCR_TRY(dalloc(&s->z, (size_t)n));
     if (storage > ND && !s->accp) {

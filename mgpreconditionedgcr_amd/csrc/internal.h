@@ -182,6 +182,7 @@ int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n);
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter,
             int *converged);
 void gcr_state_set_use_x0(GcrState *s, bool use_x0);
+int gcr_state_set_param(GcrState *s, const mgcr_gcr_param *p);
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);
 void gcr_last_profile(double *ms, int *n);
 

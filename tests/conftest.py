@@ -14,6 +14,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # the shared objects are git-ignored build artefacts: build whatever is missing (hipcc cross-compiles
+    # gfx950 without a GPU; on the GPU box the prebuilt files travel with the snapshot)
+    lib = os.path.join(ROOT, "mgpreconditionedgcr_amd", "libmgcr_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(ROOT, "mgpreconditionedgcr_amd", "csrc")],
+                       check=True, capture_output=True)
 
 
 @pytest.fixture(scope="session")
