@@ -261,7 +261,6 @@ static int plan_build(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, con
     }
     // local column numbering and the interior row range
     P->col_local.resize((size_t)P->nnz);
-    int64_t first_b = nloc, last_b = -1;
     std::vector<char> touches((size_t)nloc, 0);
     for (int64_t r = 0; r < nloc; r++)
         for (int64_t l = rowptr[r]; l < rowptr[r + 1]; l++) {
@@ -277,7 +276,6 @@ static int plan_build(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, con
             cur_b = r + 1;
         }
     }
-    (void)first_b; (void)last_b;
     P->interior_begin = best_b;
     P->interior_end = best_e;
     *out = P;
@@ -489,7 +487,7 @@ int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const
         set_error("dist_csr_create: device allocation failed: %s", hipGetErrorString(e));
         return MGCR_ERR_ALLOC;
     }
-    if (c->is_rccl || true) rc = comm_device_ready(c);
+    rc = comm_device_ready(c);
     if (rc != MGCR_OK) { csr_free(&op->csr); dist_free(d); return rc; }
     op->dist = d;
     op->comm = c;

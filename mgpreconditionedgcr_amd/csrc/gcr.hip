@@ -5,18 +5,23 @@
 //     vectors but the ring slot that was written last (the reference copies them, :286-287);
 //   * per iteration three fused BLAS-1 kernels + one SpMV instead of ~90 vector passes
 //     (SURVEY.md §8(a) A3):
-//        xr_update   x += a p, r -= a Ap, |r|^2 partials                         6 V
+//        xr_update   x += a p, r -= a Ap, |r|^2 partials                         6 V  (3 V when the
+//                    x update is deferred to the end of the restart cycle, see xr_update_kernel)
 //        SpMV        Ar = A r                                                     B_spmv
 //        multidot    <Ar, Aps[i]> partials for all stored i in one pass           (1+lim) V
 //        build       p' = r - sum b_i ps[i], Ap' = Ar - sum b_i Aps[i] written straight into the
-//                    ring slot, plus <r,Ap'> and <Ap',Ap'> partials               (4+2 lim) V
+//                    ring slot, plus <r,Ap'> and <Ap',Ap'> partials and the step's bookkeeping
+//                    (history entry, convergence predicate)                        (4+2 lim) V
 //     = B_spmv + (11 + 3 lim) V of HBM traffic per iteration;
 //   * all scalars (alpha, beta_i, norms, the iteration counter, the convergence flag and the
 //     residual history) stay on the device.  Reductions are two-stage and deterministic: producers
 //     write per-workgroup partials, consumers fold them in a fixed order (reduce.h), so the
-//     history is reproducible run to run.  The host only looks at the flag every `check_every`
-//     iterations; once the flag is up every later kernel returns immediately, so x, r and the
-//     history are exactly those of the converged step;
+//     history is reproducible run to run.  The host only looks at the device-side stop predicate
+//     every `check_every` iterations; once it is set every later kernel returns immediately, so x, r
+//     and the history are exactly those of the converged step;
+//   * the work vectors belong to the solver object and are re-used from solve to solve;
+//   * streams touched once per iteration (old direction slots; the matrix in spmv.hip) are accessed
+//     non-temporally so that r, Ar and the newest Ap survive in L2 / Infinity Cache between kernels;
 //   * used as an Operator (smoother / coarse solver / preconditioner, src/GCR.h:62-68) a solve
 //     is enqueued without any host round trip.
 //
@@ -67,7 +72,6 @@ struct GcrState {
     int x0_mode = 1;
     int64_t n = 0;
     int storage = 0, restart = 0;
-    int alloc_slots = 0;
     std::vector<cplx *> ps, aps;
     cplx *r = nullptr, *ar = nullptr, *z = nullptr, *tmp = nullptr, *accp = nullptr, *accap = nullptr;
     cplx *x0 = nullptr;
@@ -401,7 +405,7 @@ static void gcr_free_vectors(GcrState *s) {
     hipFree(s->den); hipFree(s->hist); hipFree(s->partsB); hipFree(s->dRB); hipFree(s->alphas);
     s->r = s->ar = s->z = s->tmp = s->accp = s->accap = nullptr;
     s->den = nullptr; s->hist = nullptr; s->partsB = nullptr; s->dRB = nullptr; s->alphas = nullptr;
-    s->alloc_slots = 0; s->n = 0; s->partsB_dirs = 0; s->hist_cap = 0;
+    s->n = 0; s->partsB_dirs = 0; s->hist_cap = 0;
 }
 
 void gcr_state_destroy(GcrState *s) {

@@ -45,7 +45,6 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // extra "finalise" launch is needed and results are reproducible run to run.
 constexpr int RED_THREADS = 1024;
 constexpr int RED_MAX_BLOCKS = 512;
-constexpr int MAX_DIRS = 32;  // max stored directions handled by one multi-dot / build launch
 
 struct Context {
     bool ready = false;

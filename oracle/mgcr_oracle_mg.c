@@ -64,11 +64,10 @@ int64_t orc_mg_aggregates(int ndim, const int64_t *dims, const int32_t *blocked,
         }
     }
     for (int64_t i = 0; i < n; i++) {
-        int64_t rem = i, b = 0, stride = 1;
+        int64_t rem = i, b = 0;
         /* decompose from the fastest dimension; accumulate the block index from the slowest */
         int64_t idx[16];
         for (int d = ndim - 1; d >= 0; d--) { idx[d] = rem % dims[d]; rem /= dims[d]; }
-        (void)stride;
         for (int d = 0; d < ndim; d++)
             if (blocked[d]) b = b * (dims[d] / sub) + idx[d] / sub;
         agg[i] = (int32_t)b;

@@ -121,7 +121,6 @@ def test_mg_dirac_sample_two_level(sample_matrix_path, mg_gold):
     prm = MG_Param(Mesh(DIMS), 2, 2, GCR_Param(0, 10, 10, 1e-8, False), GCR(GCR_Param(0, 10, 50, 1e-2, False)),
                    GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1, None, None)
     M = MG(dirac, prm)
-    vecs = None
     # rebuild the same hierarchy in the oracle from the vectors the GPU set-up used
     pv, agg = M.prolongator(0)
     nrow, ncol, rowptr, col, val = orc.read_text_csr(sample_matrix_path)

@@ -390,8 +390,6 @@ def test_use_x0_extension():
 def test_linearity_and_row_sums_full_size():
     """Size-independent checks at BASELINE config 3's matrix size (256^3, 117 M nnz)."""
     n = 256
-    slabs = []
-    # build on the host slab by slab to bound memory, then one CSR
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
     A = Sparse(N, ncol, rowptr, col, val)
     del rowptr, col, val
@@ -402,7 +400,7 @@ def test_linearity_and_row_sums_full_size():
     edge = ((idx == 0) | (idx == n - 1)).astype(np.float64)
     expect = edge[:, None, None] + edge[None, :, None] + edge[None, None, :]
     assert np.array_equal(y.real, expect) and not y.imag.any()
-    del y, slabs
+    del y
     a, b = Field((n, n, n)).fill_rhs(1), Field((n, n, n)).fill_rhs(2)
     alpha = 0.5 - 0.25j  # exactly representable: A(a + alpha b) == A a + alpha A b up to rounding
     lhs = A(a.add_scaled(alpha, b))
