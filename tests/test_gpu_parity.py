@@ -418,3 +418,88 @@ def test_error_paths(sample):
         GCR(sample, GCR_Param(3, 3, 10, 1e-8, False))  # Do not support concurrent restarting and truncation.
     with pytest.raises(MgcrError):
         Sparse(2, 2, [0, 1, 2], [0, 5], [1.0, 1.0])  # column out of range
+
+
+# ------------------------------------------------------------------ edge cases
+def test_degenerate_matrices():
+    # no entries at all: y = 0
+    A = Sparse(5, 7, np.zeros(6, np.int64), np.zeros(0, np.int64), np.zeros(0, np.complex128))
+    y = A(Field((7,), problems.rhs_grid(7, 1))).to_numpy()
+    assert y.shape == (5,) and not y.any()
+    # 1 x 1
+    A = Sparse(1, 1, [0, 1], [0], [2.5 - 1j])
+    assert A(Field((1,), [1 + 1j])).to_numpy()[0] == (2.5 - 1j) * (1 + 1j)
+    # only empty rows except the last one
+    rowptr = np.zeros(1001, np.int64)
+    rowptr[-1] = 3
+    A = Sparse(1000, 1000, rowptr, [0, 500, 999], [1.0, 2.0, 3.0])
+    x = problems.rhs_grid(1000, 2)
+    y = A(Field((1000,), x)).to_numpy()
+    assert not y[:-1].any() and y[-1] == 1.0 * x[0] + 2.0 * x[500] + 3.0 * x[999]
+    # block-CSR with an empty block row and 1x1 blocks
+    H = HierarchicalSparse(4, 4, [0, 2, 3, 3], [1, 2, 0, 3], np.array([2.0, 3.0, 4.0, 5.0]).reshape(4, 1, 1))
+    x4 = np.array([1, 2, 3, 4], np.complex128)
+    assert np.array_equal(H(Field((4,), x4)).to_numpy(), np.array([4, 0, 9, 24], np.complex128))
+
+
+@pytest.mark.parametrize("kw_o,kw_g", [
+    (dict(restart=1, max_iter=40, tol=1e-10), dict(re=1, max_it=40, tau=1e-10)),          # steepest-descent-like
+    (dict(truncation=1, max_iter=40, tol=1e-10), dict(trunc=1, max_it=40, tau=1e-10)),
+    (dict(restart=50, max_iter=7, tol=1e-30), dict(re=50, max_it=7, tau=1e-30)),           # restart never reached
+    (dict(restart=3, max_iter=1, tol=1e-30), dict(re=3, max_it=1, tau=1e-30)),
+    (dict(truncation=20, max_iter=30, tol=1e-30), dict(trunc=20, max_it=30, tau=1e-30)),   # > 8 directions: chunked kernels
+])
+def test_gcr_corner_parameters_vs_oracle(kw_o, kw_g):
+    n = 9
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    val = val * (1.0 + 0.1j)
+    b = problems.rhs_grid(N, 4)
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    xo, ho, ito, co = orc.gcr_solve(Ao, orc.gcr_param(**kw_o), b)
+    _, sens, rng = orc.gcr_reorder_sensitivity(Ao, orc.gcr_param(**kw_o), b)
+    A = Sparse(N, ncol, rowptr, col, val)
+    x = Field((N,)).set_zero()
+    gcr = GCR(A, GCR_Param(verb=False, **kw_g))
+    fb = Field((N,), b)
+    gcr.solve(fb, x)
+    assert its_close(gcr.last_iterations, ito, rng) and gcr.last_converged == co
+    hist_close(gcr.last_history, ho, str(kw_g), sens)
+    x_close(x, A, fb, gcr, xo if gcr.last_iterations == ito else None, sens)
+
+
+def test_zero_rhs_behaves_like_the_reference():
+    """b = 0: |r|^2/|b|^2 is NaN, the reference's `while (NaN > tol^2 && ...)` is false: one iteration,
+    reported as converged (global_count != max_iter), NaN in the history (no breakdown guard)."""
+    n = 6
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    x = Field((N,)).set_zero()
+    gcr = GCR(A, GCR_Param(0, 5, 50, 1e-10, False))
+    gcr.solve(Field((N,)).set_zero(), x)
+    xo, ho, ito, co = orc.gcr_solve(orc.csr(N, ncol, rowptr, col, val), orc.gcr_param(restart=5, max_iter=50, tol=1e-10), np.zeros(N, np.complex128))
+    assert gcr.last_iterations == ito == 1 and gcr.last_converged == co
+    assert np.isnan(gcr.last_history[1]) and np.isnan(ho[1])
+
+
+def test_solver_object_is_reusable_and_reads_params_at_solve_time():
+    n = 10
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    b = Field((N,), problems.rhs_grid(N, 1))
+    prm = GCR_Param(0, 5, 30, 1e-30, False)
+    gcr = GCR(A, prm)
+    x1 = Field((N,)).set_zero()
+    gcr.solve(b, x1)
+    h1 = gcr.last_history.copy()
+    prm.restart, prm.max_iter = 3, 12      # GCR_Param is held by pointer in the reference and read per solve
+    x2 = Field((N,)).set_zero()
+    gcr.solve(b, x2)
+    assert gcr.last_iterations == 12
+    fresh = GCR(A, GCR_Param(0, 3, 12, 1e-30, False))
+    x3 = Field((N,)).set_zero()
+    fresh.solve(b, x3)
+    assert np.array_equal(gcr.last_history, fresh.last_history) and np.array_equal(x2.to_numpy(), x3.to_numpy())
+    prm.restart, prm.max_iter = 5, 30
+    x4 = Field((N,)).set_zero()
+    gcr.solve(b, x4)
+    assert np.array_equal(gcr.last_history, h1) and np.array_equal(x4.to_numpy(), x1.to_numpy())  # run-to-run reproducible
