@@ -303,7 +303,7 @@ static bool halo_overlap() {
 
 __global__ void __launch_bounds__(256) pack_kernel(int64_t n, const int32_t *__restrict__ idx, const cplx *__restrict__ x,
                                                    cplx *__restrict__ out, const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = x[idx[i]];
 }

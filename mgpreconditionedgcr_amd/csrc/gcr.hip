@@ -48,9 +48,12 @@ struct DevState {
     // step k (inside build_kernel) writes stop_at = k, which is >= the `it` of every kernel of step
     // k: no kernel ever acts on a value written by a concurrently running workgroup of itself.
     int stop_at;
+    // Iteration numbers reach the kernels as base + it: `it` is a launch argument counted from the last
+    // advance_kernel, `base` lives here.  Eager launches never advance (base = 0, it = global count);
+    // a captured restart cycle (hipGraph) is replayed with it = 1..R and followed by base += R.
+    int base;
     int iter;      // global_count
     int npend;     // x updates deferred so far in this restart cycle (see xr_update_kernel)
-    int pad1;
     double bnorm2; // |b|^2
     double rr;     // |r|^2 of the last finished step
     double tol2;
@@ -86,7 +89,19 @@ struct GcrState {
     double *dRB = nullptr;  // [1 + 2 * dirs]: |r|^2, then the beta numerators
     double *dN = nullptr;   // [2]: |b|^2, |r0|^2
     cplx *alphas = nullptr; // [storage]: alpha of the deferred x updates of the current restart cycle
+    // captured restart cycle (see gcr_run)
+    hipGraphExec_t graph_exec = nullptr;
+    const cplx *graph_x = nullptr;
+    int graph_R = 0;
+    int64_t graph_n = 0;
 };
+
+constexpr int64_t GRAPH_MAX_ROWS = 1 << 18;
+
+static bool graphs_enabled() {
+    static const bool on = !(getenv("MGCR_GRAPH") && atoi(getenv("MGCR_GRAPH")) == 0);
+    return on;
+}
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -95,7 +110,8 @@ struct GcrState {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
 __global__ void reset_kernel(DevState *st, const int *inherit, int inherit_it, double tol2) {
-    st->stop_at = (inherit && *inherit < inherit_it) ? -1 : INT_MAX;  // an outer solve that is over silences this one
+    st->stop_at = (inherit && inherit[0] < inherit[1] + inherit_it) ? -1 : INT_MAX;  // an outer solve that is over silences this one
+    st->base = 0;
     st->iter = 0;
     st->npend = 0;
     st->bnorm2 = 0.;
@@ -106,7 +122,7 @@ __global__ void reset_kernel(DevState *st, const int *inherit, int inherit_it, d
 // r = b - t  (use_x0 extension)
 __global__ void __launch_bounds__(RED_THREADS) sub_kernel(cplx *__restrict__ out, const cplx *__restrict__ a,
                                                           const cplx *__restrict__ b, int64_t n, const DevState *st, int it) {
-    if (st->stop_at < it) return;
+    if (st->stop_at < st->base + it) return;
     GRID_STRIDE(i, n) out[i] = csub(a[i], b[i]);
 }
 
@@ -114,7 +130,7 @@ __global__ void __launch_bounds__(RED_THREADS) sub_kernel(cplx *__restrict__ out
 __global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *__restrict__ a, int64_t n,
                                                                    double *__restrict__ parts, const DevState *st, int it) {
     __shared__ double lds[17];
-    if (st && st->stop_at < it) return;
+    if (st && st->stop_at < st->base + it) return;
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
         cplx t = a[i];
@@ -128,7 +144,7 @@ __global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *
 __global__ void __launch_bounds__(RED_THREADS) dot2_partials_kernel(const cplx *__restrict__ r, const cplx *__restrict__ ap,
                                                                    int64_t n, double *__restrict__ parts, const DevState *st, int it) {
     __shared__ double lds[4 * 17];
-    if (st->stop_at < it) return;
+    if (st->stop_at < st->base + it) return;
     double v[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
         cplx a = ap[i];
@@ -169,7 +185,7 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
                                                                 cplx *__restrict__ r, int64_t n, double *__restrict__ partsR,
                                                                 cplx *__restrict__ den_slot, cplx *__restrict__ alphas, int slot) {
     __shared__ double lds[4 * 17];
-    if (st->stop_at < it) return;
+    if (st->stop_at < st->base + it) return;
     double s[4];
     fold_partials<4>(partsA, nblkA, strideA, s, lds);
     const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
@@ -204,6 +220,7 @@ __global__ void __launch_bounds__(RED_THREADS) flush_x_kernel(DevState *__restri
     }
 }
 __global__ void clear_pending_kernel(DevState *st) { st->npend = 0; }
+__global__ void advance_kernel(DevState *st, int by) { st->base += by; }
 
 // <Ar, Aps[j]> for j < NDT (conj on Ar, src/GCR.h:258) -> partsB[(base+j)*2 + {0,1}][blk].
 // NDT is a template parameter so that the (1 + NDT) * U loads of one trip are issued back to back
@@ -214,7 +231,7 @@ __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *_
                                                                DirPtrs d, int base, int64_t n,
                                                                double *__restrict__ partsB) {
     __shared__ double lds[2 * NDT * 17];
-    if (st->stop_at < it) return;
+    if (st->stop_at < st->base + it) return;
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
@@ -277,18 +294,19 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
                                                             const cplx *__restrict__ alphas) {
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT];
-    if (st->stop_at < it) return;
+    if (st->stop_at < st->base + it) return;
     double s[2 * NDT];
     fold_partials<2 * NDT>(partsB + (size_t)(2 * base) * strideB, nblkB, strideB, s, lds);
     if (book && blockIdx.x == 0) {
         double rr[1];
         fold_partials<1>(partsR, nblkR, strideR, rr, lds);
         if (threadIdx.x == 0) {
-            st->iter = it;  // global_count
+            const int git = st->base + it;  // global_count
+            st->iter = git;
             st->rr = rr[0];
-            if (it < hist_cap) hist[it] = sqrt(rr[0]) / sqrt(st->bnorm2);
+            if (git < hist_cap) hist[git] = sqrt(rr[0]) / sqrt(st->bnorm2);
             // continue while |r|^2/|b|^2 > tol^2 (src/GCR.h:288); NaN compares false -> stop, like the reference
-            if (!((rr[0] / st->bnorm2) > st->tol2)) st->stop_at = it;
+            if (!((rr[0] / st->bnorm2) > st->tol2)) st->stop_at = git;
             if (XUPD) st->npend = 0;
         }
     }
@@ -398,6 +416,7 @@ int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n) {
 }
 
 static void gcr_free_vectors(GcrState *s) {
+    if (s->graph_exec) { hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     for (cplx *p : s->ps) hipFree(p);
     for (cplx *p : s->aps) hipFree(p);
     s->ps.clear(); s->aps.clear();
@@ -697,10 +716,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;
-    while (global < max_it && !done) {
-        global++;
+    // one iteration, enqueued on the library stream; `it` = iteration number relative to DevState::base
+    auto one_iteration = [&](int it) -> int {
         iter_count++;
-        const int it = global;
         set_apply_skip(SkipRef{&s->st->stop_at, it});
         // alpha, x, r
         if (defer)
@@ -779,7 +797,48 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         }
         iter_count = ic_next;
         cur = nxt;
-        if (!nested && (global % check_every == 0 || global == max_it)) {
+        return MGCR_OK;
+    };
+
+    // hipGraph: in restart mode every cycle of R iterations is the same launch sequence with the same
+    // arguments (iteration numbers are base-relative, base lives on the device), so one cycle is
+    // captured once and replayed.  Measured on MI355X: +11 % iterations/s on the 3072-row sample
+    // (launch-bound: 4 kernels of a few microseconds per iteration), -1.8 % at 128^3 where the eager
+    // launches are already hidden behind 15-100 us kernels — hence the size gate.
+    const int R = s->restart;
+    bool use_graph = graphs_enabled() && n <= GRAPH_MAX_ROWS && defer && !multi && !p.left_precond && !p.right_precond &&
+                     !p.profile_spmv && max_it >= 2 * R && R <= s->storage;
+    if (use_graph && (s->graph_exec == nullptr || s->graph_x != x || s->graph_R != R || s->graph_n != n)) {
+        if (s->graph_exec) { hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        MGCR_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
+        int rc = MGCR_OK;
+        for (int i = 1; i <= R && rc == MGCR_OK; i++) rc = one_iteration(i);
+        if (rc == MGCR_OK) {
+            hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c.stream, s->st, R);
+        }
+        hipError_t e = hipStreamEndCapture(c.stream, &graph);
+        if (rc != MGCR_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        MGCR_HIP(e);
+        e = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        MGCR_HIP(e);
+        s->graph_x = x; s->graph_R = R; s->graph_n = n;
+        // the capture pass walked the host-side cycle state through one full cycle: back at its start
+    }
+    int rel = 0;  // iterations enqueued eagerly since the last advance of DevState::base
+    int last_check = 0;
+    while (global < max_it && !done) {
+        if (use_graph && iter_count == 0 && rel == 0 && max_it - global >= R) {
+            MGCR_HIP(hipGraphLaunch(s->graph_exec, c.stream));
+            global += R;
+        } else {
+            global++;
+            rel++;
+            MGCR_TRY(one_iteration(rel));
+        }
+        if (!nested && (global / check_every != last_check || global == max_it)) {
+            last_check = global / check_every;
             MGCR_HIP(hipMemcpyAsync(c.h_mail, s->st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
             MGCR_HIP(hipStreamSynchronize(c.stream));
             const DevState *hs = (const DevState *)c.h_mail;

@@ -48,7 +48,7 @@ struct SmallArgs {
     cplx *ps[SMALL_MAX_DIRS], *aps[SMALL_MAX_DIRS];
     double *hist;
     int hist_cap;
-    int *state;  // [0] stop_at-style flag (INT_MAX while running / iteration it ended), [1] iterations done
+    int *state;  // DevState prefix of gcr.hip: [0] stop_at (INT_MAX while running / iteration it ended), [1] base, [2] iterations done
     const int *outer_skip;
     int outer_it;
 };
@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gcr_small_kernel(SmallArgs a) {
     __shared__ double lds[2 * (SMALL_MAX_DIRS + 2) * 17];
     const int tid = threadIdx.x;
     const int64_t n = a.n;
-    if (a.outer_skip && *a.outer_skip < a.outer_it) {  // an outer solve that is already over silences this one
-        if (tid == 0) { a.state[0] = -1; a.state[1] = 0; }
+    if (a.outer_skip && a.outer_skip[0] < a.outer_skip[1] + a.outer_it) {  // an outer solve that is already over silences this one
+        if (tid == 0) { a.state[0] = -1; a.state[1] = 0; a.state[2] = 0; }
         return;
     }
     // ---- set-up (src/GCR.h:189-216): r = rhs (or rhs - A x0); p = r; Ap = A p; slot 0 <- (p, Ap)
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) gcr_small_kernel(SmallArgs a) {
         cur = nxt;
         if (stop != INT_MAX) break;
     }
-    if (tid == 0) { a.state[0] = stop; a.state[1] = global; }
+    if (tid == 0) { a.state[0] = stop; a.state[1] = 0; a.state[2] = global; }
 }
 
 static int64_t g_small_limit = -1;

@@ -143,7 +143,8 @@ struct HostCsr {
 };
 int csr_download_host(const CsrDev &A, HostCsr *out);
 // Device-side "this solve is over" predicate consulted by operator-apply kernels that run inside a
-// solver iteration: they return at once when *stop_at < it (see gcr.hip: DevState::stop_at).
+// solver iteration: p points at {stop_at, base} of the solver's DevState (gcr.hip) and the kernel
+// returns at once when stop_at < base + it.
 struct SkipRef {
     const int *p = nullptr;
     int it = 0;

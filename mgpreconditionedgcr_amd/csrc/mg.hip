@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
                                                        const int32_t *__restrict__ amem, const cplx *__restrict__ pv,
                                                        const cplx *__restrict__ x, cplx *__restrict__ xc,
                                                        const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
     int64_t a = c / ne;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
                                                          const cplx *__restrict__ pv, const cplx *__restrict__ xc,
                                                          cplx *__restrict__ x, cplx damp, int add,
                                                          const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const cplx *c = xc + (int64_t)agg[i] * ne;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
 // r = b - r   (r holds A x on entry)
 __global__ void __launch_bounds__(256) residual_kernel(int64_t n, const cplx *__restrict__ b, cplx *__restrict__ r,
                                                        const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) r[i] = csub(b[i], r[i]);
 }

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
                                                           const int32_t *__restrict__ col, const cplx *__restrict__ x,
                                                           const cplx *__restrict__ xh, int32_t n_own,
                                                           cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
     int64_t rloc = tile * 256 + threadIdx.x;
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t
                                                       const void *__restrict__ val, const int32_t *__restrict__ col,
                                                       const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
                                                       cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t rloc = t / L;
     int64_t row = row_begin + rloc;
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
                                                        const cplx *__restrict__ tail_val, const cplx *__restrict__ x,
                                                        const cplx *__restrict__ xh, int32_t n_own,
                                                        cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
     if (wave >= n_tail_rows) return;
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs
                                                        const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     const int32_t brow = blockIdx.x;
     const int lane = threadIdx.x;
     const int32_t bs2 = bs * bs, ld = bs + 1;
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel_t(int32_t nbrow, int32_t 
                                                          const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
-    if (skip && *skip < skip_it) return;
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     const int32_t brow = blockIdx.x;
     const int lane = threadIdx.x;
     const int32_t bs2 = bs * bs, ld = bs + 1;
