@@ -135,13 +135,6 @@ int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h
 void bcsr_free(BcsrDev *b);
 int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y);
 
-// reconstructs a host CSR (int64 indices; padding entries appear as explicit zeros) from the device layout
-struct HostCsr {
-    int64_t nrow = 0, ncol = 0;
-    std::vector<int64_t> rowptr, col;
-    std::vector<double> val_ri;
-};
-int csr_download_host(const CsrDev &A, HostCsr *out);
 // Device-side "this solve is over" predicate consulted by operator-apply kernels that run inside a
 // solver iteration: p points at {stop_at, base} of the solver's DevState (gcr.hip) and the kernel
 // returns at once when stop_at < base + it.

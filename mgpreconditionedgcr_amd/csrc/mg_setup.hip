@@ -4,8 +4,14 @@
 // vectors for the next level — without pulling the operator back to the host.
 //
 // Every kernel keeps the reference's evaluation order (src/MG.h:171-198,216-274), one thread per
-// aggregate / per coarse block, so the hierarchy is bit-identical to the host path of mg.hip and to
-// the oracle (tests/test_gpu_mg.py::test_device_setup_equals_host_setup).
+// aggregate / per coarse block, so the hierarchy is bit-identical to the oracle's
+// (tests/test_gpu_mg.py::test_device_setup_bit_identical_to_oracle) and, through it, pinned to the
+// reference's golden G9.
+//
+// Distributed operators (row blocks): aggregates are formed inside the local block; the aggregate
+// ids and prolongator rows of the halo columns are fetched once over the SpMV's halo lists
+// (set-up-time host-level exchange), the Galerkin kernels then see owned + halo columns, and the
+// resulting row block of the coarse operator (global column ids) becomes a distributed Sparse.
 #include <algorithm>
 
 #include "internal.h"
@@ -230,6 +236,7 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     hipStream_t st = ctx().stream;
     const Op *base = A->kind == OP_DIRAC ? A->base : A;
     const bool shift = A->kind == OP_DIRAC;
+    DistCsr *dist = base->kind == OP_CSR ? base->dist : nullptr;
     MeshDesc m;
     m.ndim = ndim; m.sub = sub;
     int64_t n = 1, nagg = 1, S = 1;
@@ -254,6 +261,53 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     hipLaunchKernelGGL(pv_init_kernel, dim3(g256(n)), dim3(256), 0, st, n, ne, d_vecs, *d_pv);
     hipLaunchKernelGGL(gs_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, ne, (const int32_t *)*d_aptr, (const int32_t *)*d_amem, *d_pv);
     MGCR_HIP(hipGetLastError());
+    // columns the Galerkin product sees: the owned rows, plus (distributed) the halo slots
+    const int32_t *g_agg = *d_agg;
+    const cplx *g_pv = *d_pv;
+    int32_t *d_agg_ext = nullptr;
+    cplx *d_pv_ext = nullptr;
+    int64_t agg_off = 0, nagg_glob = nagg;
+    std::vector<int64_t> ext_gid;  // global id of the extended-local aggregate nagg + k
+    Comm *comm = nullptr;
+    if (dist) {
+        int64_t nh = 0;
+        int rank = 0, nranks = 1;
+        dist_sizes(dist, nullptr, &nh, nullptr, nullptr, &rank, &nranks);
+        comm = dist_comm(dist);
+        std::vector<double> cnt((size_t)nranks, 0.);
+        cnt[(size_t)rank] = (double)nagg;
+        MGCR_TRY(comm_allreduce_host_pub(comm, cnt.data(), nranks));
+        nagg_glob = 0;
+        for (int r = 0; r < nranks; r++) { if (r == rank) agg_off = nagg_glob; nagg_glob += (int64_t)cnt[(size_t)r]; }
+        std::vector<int32_t> h_agg((size_t)n);
+        std::vector<double> h_pv((size_t)n * ne * 2);
+        MGCR_HIP(hipMemcpyAsync(h_agg.data(), *d_agg, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        MGCR_HIP(hipMemcpyAsync(h_pv.data(), *d_pv, sizeof(cplx) * (size_t)n * ne, hipMemcpyDeviceToHost, st));
+        MGCR_HIP(hipStreamSynchronize(st));
+        const int w = 1 + 2 * ne;
+        std::vector<double> own((size_t)n * w), halo((size_t)nh * w);
+        for (int64_t i = 0; i < n; i++) {
+            own[(size_t)i * w] = (double)(agg_off + h_agg[(size_t)i]);
+            memcpy(&own[(size_t)i * w + 1], &h_pv[(size_t)i * ne * 2], sizeof(double) * 2 * (size_t)ne);
+        }
+        MGCR_TRY(dist_exchange_rows_host(dist, own.data(), w, halo.data()));
+        for (int64_t h = 0; h < nh; h++) ext_gid.push_back((int64_t)halo[(size_t)h * w]);
+        std::sort(ext_gid.begin(), ext_gid.end());
+        ext_gid.erase(std::unique(ext_gid.begin(), ext_gid.end()), ext_gid.end());
+        h_agg.resize((size_t)(n + nh));
+        h_pv.resize((size_t)(n + nh) * ne * 2);
+        for (int64_t h = 0; h < nh; h++) {
+            int64_t gid = (int64_t)halo[(size_t)h * w];
+            h_agg[(size_t)(n + h)] = (int32_t)(nagg + (std::lower_bound(ext_gid.begin(), ext_gid.end(), gid) - ext_gid.begin()));
+            memcpy(&h_pv[(size_t)(n + h) * ne * 2], &halo[(size_t)h * w + 1], sizeof(double) * 2 * (size_t)ne);
+        }
+        MGCR_TRY(dmalloc(&d_agg_ext, (size_t)(n + nh)));
+        MGCR_TRY(dmalloc(&d_pv_ext, (size_t)(n + nh) * ne));
+        MGCR_HIP(hipMemcpy(d_agg_ext, h_agg.data(), sizeof(int32_t) * (size_t)(n + nh), hipMemcpyHostToDevice));
+        MGCR_HIP(hipMemcpy(d_pv_ext, h_pv.data(), sizeof(cplx) * (size_t)(n + nh) * ne, hipMemcpyHostToDevice));
+        g_agg = d_agg_ext;
+        g_pv = d_pv_ext;
+    }
     // Galerkin: symbolic
     RowSrc src = row_source(base);
     int32_t *d_cnt = nullptr, *d_nbr = nullptr;
@@ -262,7 +316,7 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     MGCR_TRY(dmalloc(&d_nbr, (size_t)nagg * MAXNB));
     MGCR_TRY(dmalloc(&d_over, 1));
     MGCR_HIP(hipMemsetAsync(d_over, 0, sizeof(int), st));
-    hipLaunchKernelGGL(gal_count_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, src, shift ? 1 : 0, (const int32_t *)*d_agg,
+    hipLaunchKernelGGL(gal_count_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, src, shift ? 1 : 0, g_agg,
                        (const int32_t *)*d_aptr, (const int32_t *)*d_amem, d_cnt, d_nbr, d_over);
     MGCR_HIP(hipGetLastError());
     std::vector<int32_t> cnt((size_t)nagg);
@@ -290,18 +344,46 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     MGCR_HIP(hipMemcpyAsync(d_browptr, browptr.data(), sizeof(int32_t) * ((size_t)nagg + 1), hipMemcpyHostToDevice, st));
     MGCR_HIP(hipMemsetAsync(d_blocks, 0, sizeof(cplx) * (size_t)nblk * ne * ne, st));
     hipLaunchKernelGGL(gal_index_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, (const int32_t *)d_browptr, (const int32_t *)d_nbr, d_brow, d_bcol);
-    hipLaunchKernelGGL(gal_fill_kernel, dim3(g256(nblk)), dim3(256), 0, st, nblk, src, shift ? 1 : 0, A->k, ne, (const int32_t *)*d_agg,
-                       (const int32_t *)*d_aptr, (const int32_t *)*d_amem, (const cplx *)*d_pv, (const int32_t *)d_brow,
+    hipLaunchKernelGGL(gal_fill_kernel, dim3(g256(nblk)), dim3(256), 0, st, nblk, src, shift ? 1 : 0, A->k, ne, g_agg,
+                       (const int32_t *)*d_aptr, (const int32_t *)*d_amem, g_pv, (const int32_t *)d_brow,
                        (const int32_t *)d_bcol, d_blocks, d_t);
     MGCR_HIP(hipGetLastError());
     MGCR_HIP(hipStreamSynchronize(st));
-    hipFree(d_nbr); hipFree(d_brow); hipFree(d_t);
+    hipFree(d_nbr); hipFree(d_brow); hipFree(d_t); hipFree(d_agg_ext); hipFree(d_pv_ext);
     // coarse operator
     mgcr_op_s *Ac = new mgcr_op_s();
     const int64_t nc = nagg * ne;
     Ac->dim = Ac->nrow = nc;
     int rc = MGCR_OK;
-    if (ne == 1) {
+    if (dist) {
+        // this rank's row block [agg_off*ne, (agg_off+nagg)*ne) of the coarse operator, GLOBAL columns;
+        // the partition plan of the new distributed Sparse is host logic, so the blocks make one trip back
+        std::vector<int32_t> h_bcol((size_t)nblk);
+        std::vector<double> h_blk((size_t)nblk * ne * ne * 2);
+        MGCR_HIP(hipMemcpy(h_bcol.data(), d_bcol, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
+        MGCR_HIP(hipMemcpy(h_blk.data(), d_blocks, sizeof(cplx) * (size_t)nblk * ne * ne, hipMemcpyDeviceToHost));
+        hipFree(d_browptr); hipFree(d_bcol); hipFree(d_blocks);
+        std::vector<int64_t> rp((size_t)nc + 1, 0), ci;
+        std::vector<double> va;
+        ci.reserve((size_t)nblk * ne * ne);
+        va.reserve((size_t)nblk * ne * ne * 2);
+        for (int64_t a = 0; a < nagg; a++)
+            for (int kp = 0; kp < ne; kp++) {
+                for (int32_t b = browptr[(size_t)a]; b < browptr[(size_t)a + 1]; b++) {
+                    int64_t ca = h_bcol[(size_t)b];
+                    int64_t gid = ca < nagg ? agg_off + ca : ext_gid[(size_t)(ca - nagg)];
+                    for (int k = 0; k < ne; k++) {
+                        ci.push_back(gid * ne + k);
+                        size_t e = ((size_t)b * ne * ne + (size_t)kp * ne + k) * 2;
+                        va.push_back(h_blk[e]);
+                        va.push_back(h_blk[e + 1]);
+                    }
+                }
+                rp[(size_t)(a * ne + kp) + 1] = (int64_t)ci.size();
+            }
+        Ac->kind = OP_CSR;
+        rc = dist_csr_create(comm, nagg_glob * ne, agg_off * ne, nc, rp.data(), ci.data(), va.data(), Ac);
+    } else if (ne == 1) {
         Ac->kind = OP_CSR;
         std::vector<int64_t> rp64(browptr.begin(), browptr.end());
         int64_t *d_rp = nullptr, *d_ci = nullptr;

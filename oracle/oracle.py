@@ -89,6 +89,10 @@ def lib():
         L.orc_mg_level_ne.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_level_nagg.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_level_nagg.restype = C.c_int64
+        L.orc_mg_level_pv.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_pv.restype = C.POINTER(C.c_double)
+        L.orc_mg_level_agg.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_agg.restype = C.POINTER(C.c_int32)
         L.orc_mg_level_op.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_level_op.restype = C.c_void_p
         L.orc_mg_level_restrict.argtypes = [C.c_void_p, C.c_int, _cp, _cp]
@@ -356,6 +360,13 @@ class MG(Op):
 
     def level_op(self, l):
         return Op(lib().orc_mg_level_op(self.mg, l), keep=(self,))
+
+    def prolongator(self, l):
+        """(pv[n][ne], agg[n]) of level l -> l+1."""
+        n, ne = self.level_dim(l), lib().orc_mg_level_ne(self.mg, l)
+        pv = np.ctypeslib.as_array(lib().orc_mg_level_pv(self.mg, l), shape=(n * ne * 2,)).copy().view(c128).reshape(n, ne)
+        agg = np.ctypeslib.as_array(lib().orc_mg_level_agg(self.mg, l), shape=(n,)).copy()
+        return pv, agg
 
     def restrict(self, l, x):
         xc = np.empty(self.level_dim(l + 1), c128)

@@ -148,48 +148,50 @@ def test_mg_dirac_sample_two_level(sample_matrix_path, mg_gold):
     assert r.norm() / np.linalg.norm(b) <= 2e-10
 
 
-def _build_mg(kind, sample_matrix_path, mg_gold):
-    if kind == "poisson":
-        n = 16
-        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
-        A = Sparse(N, ncol, rowptr, col, val)
-        dims = (n, n, n)
-        prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
-                       2, None, None, null_vectors=np.ones((1, N), np.complex128))
-        return A, dims, prm, [A]
-    D = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path))
-    dirac = DiracOp(D, 0.1)
-    vecs = vec_double([mg_gold["eigvec0"], mg_gold["eigvec1"]], DIMS, 4)
-    prm = MG_Param(Mesh(DIMS), 2, 2, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
-                   1, None, None, null_vectors=vecs)
-    return dirac, DIMS, prm, [D, dirac]
+def _dense(op, n, wrap):
+    out = np.empty((n, n), np.complex128)
+    for c in range(n):
+        e = np.zeros(n, np.complex128)
+        e[c] = 1.0
+        out[:, c] = wrap(op, e)
+    return out
 
 
 @pytest.mark.parametrize("kind", ["poisson", "dirac"])
-def test_device_setup_equals_host_setup(kind, sample_matrix_path, mg_gold):
-    """The hierarchy built by the device kernels (mg_setup.hip) is bit-identical to the host set-up
-    (which the tests above pin to the reference's golden G9 and to the oracle)."""
-    out = []
-    for host in ("1", "0"):
-        os.environ["MGCR_MG_HOST_SETUP"] = host
-        try:
-            A, dims, prm, keep = _build_mg(kind, sample_matrix_path, mg_gold)
-            M = MG(A, prm)
-        finally:
-            os.environ.pop("MGCR_MG_HOST_SETUP", None)
-        lv = [M.level_info(l) for l in range(prm.n_level + 1)]
-        pvs = [M.prolongator(l) for l in range(prm.n_level)]
-        b = problems.rhs_grid(int(np.prod(dims)), 6)
-        y = M(Field(dims, b)).to_numpy()
-        coarse = []
-        for l in range(1, prm.n_level + 1):
-            nc = lv[l]["dim"]
-            coarse.append(M.level_operator(l)(Field((nc,), problems.rhs_grid(nc, 2))).to_numpy())
-        out.append((lv, pvs, y, coarse))
-    (lv0, pv0, y0, c0), (lv1, pv1, y1, c1) = out
-    assert lv0 == lv1
-    for (p0, a0), (p1, a1) in zip(pv0, pv1):
-        assert np.array_equal(a0, a1) and np.array_equal(p0, p1)
-    for u, v in zip(c0, c1):
-        assert np.array_equal(u, v)
-    assert np.array_equal(y0, y1)
+def test_device_setup_bit_identical_to_oracle(kind, sample_matrix_path, mg_gold):
+    """The hierarchy the device kernels build (mg_setup.hip) — aggregates, Gram-Schmidt'ed
+    prolongator, every entry of every Galerkin coarse operator, the restricted near-null vectors
+    feeding the next level — has the same bits as the oracle's (which test_oracle_golden.py pins
+    to the reference's golden G9): same evaluation order, no contraction."""
+    smo = orc.gcr_param(restart=10, max_iter=2, tol=1e-30)
+    coo = orc.gcr_param(restart=10, max_iter=50, tol=1e-2)
+    sm, co = GCR(GCR_Param(0, 10, 2, 1e-30, False)), GCR(GCR_Param(0, 10, 50, 1e-2, False))
+    if kind == "poisson":
+        n = 16
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        dims, nlevel = (n, n, n), 2
+        vecs = np.ones((1, N), np.complex128)
+        A = Sparse(N, ncol, rowptr, col, val)
+        M = MG(A, MG_Param(Mesh(dims), 2, 1, None, co, sm, nlevel, None, None, null_vectors=vecs))
+        Mo = orc.MG(orc.csr(N, ncol, rowptr, col, val), rowptr, col, val, dims, (1, 1, 1), 2, vecs, nlevel + 1, smo, coo)
+    else:
+        nrow, ncol, rowptr, col, val = orc.read_text_csr(sample_matrix_path)
+        D = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path))
+        dims, nlevel, k = DIMS, 1, 0.1
+        vecs = vec_double([mg_gold["eigvec0"], mg_gold["eigvec1"]], DIMS, 4)
+        A = DiracOp(D, k)
+        M = MG(A, MG_Param(Mesh(DIMS), 2, 2, None, co, sm, nlevel, None, None, null_vectors=vecs))
+        Mo = orc.MG(orc.dirac(orc.csr(nrow, ncol, rowptr, col, val), k), rowptr, col, val, DIMS, (1, 1, 1, 1, 0, 0), 2,
+                    np.asarray(vecs), nlevel + 1, smo, coo, shift=k)
+    for l in range(nlevel):
+        pv, agg = M.prolongator(l)
+        pvo, aggo = Mo.prolongator(l)
+        assert np.array_equal(agg, aggo)
+        assert np.array_equal(pv, pvo)
+    for l in range(1, nlevel + 1):
+        nc = M.level_info(l)["dim"]
+        assert nc == Mo.level_dim(l)
+        Ac = M.level_operator(l)
+        dense = _dense(Ac, nc, lambda op, e: op(Field((nc,), e)).to_numpy())
+        dense_o = _dense(Mo.level_op(l), nc, lambda op, e: op(e))
+        assert np.array_equal(dense, dense_o)
