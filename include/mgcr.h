@@ -97,6 +97,18 @@ int64_t mgcr_op_nnz(mgcr_op_t op);
 int mgcr_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y);
 /* bytes the device layout of `op` occupies / streams per apply (for roofline accounting) */
 int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width, int64_t *tail_nnz);
+/* storage a Sparse ended up with: *format = 0 plain ELL slab (+ CSR tail), 1 row-pattern dictionary
+ * holding column offsets and values, 2 row-pattern dictionary for the columns + value slab;
+ * *n_patterns = dictionary size (0 for format 0) */
+int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
+/* Implementation switches (all default on; each also has an environment variable read at first use).
+ * They select between code paths that compute the same thing; tests use them to compare the paths.
+ *   "pattern_storage" ($MGCR_PATTERNS): try the row-pattern dictionary for every Sparse of >= 2^15 rows
+ *                      created while it is on;
+ *   "lean_cycles"     ($MGCR_LEAN): restart-mode GCR keeps residuals instead of search directions inside
+ *                      a restart cycle (same r, Ap and scalars; x differs by rounding).
+ * *previous (may be NULL) receives the old value. */
+int mgcr_set_option(const char *name, int value, int *previous);
 
 /* ---- GCR: src/GCR.h, src/SolverParam.h ---------------------------------------------------- */
 typedef struct mgcr_gcr_param {

@@ -21,6 +21,13 @@ def _ri(z):
     return (C.c_double * 2)(z.real, z.imag)
 
 
+def set_option(name, value):
+    """mgcr_set_option: switch between equivalent code paths ("pattern_storage", "lean_cycles"); returns the old value."""
+    prev = C.c_int()
+    check(_lib.lib().mgcr_set_option(name.encode(), int(value), C.byref(prev)))
+    return prev.value
+
+
 class Field:
     """Field<num_type> (src/Fields.h:29-71): complex-fp64 vector tagged with mesh dimensions."""
 
@@ -162,6 +169,12 @@ class Operator:
         b, w, t = C.c_int64(), C.c_int32(), C.c_int64()
         check(_lib.lib().mgcr_op_stored_bytes(self.h, C.byref(b), C.byref(w), C.byref(t)))
         return dict(matrix_bytes=b.value, ell_width=w.value, tail_nnz=t.value)
+
+    def storage_format(self):
+        """(format, n_patterns): 0 ELL slab, 1 row-pattern dictionary (columns + values), 2 (columns only)."""
+        f, n = C.c_int32(), C.c_int32()
+        check(_lib.lib().mgcr_op_storage_format(self.h, C.byref(f), C.byref(n)))
+        return f.value, n.value
 
     def bench_apply(self, x, y, reps=20):
         ms = C.c_double()

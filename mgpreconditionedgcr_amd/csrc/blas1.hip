@@ -22,6 +22,17 @@ __global__ void __launch_bounds__(RED_THREADS) copy_kernel(cplx *__restrict__ ds
 __global__ void __launch_bounds__(RED_THREADS) set_kernel(cplx *__restrict__ dst, cplx c, int64_t n) {
     GRID_STRIDE(i, n) dst[i] = c;
 }
+// same, as part of an operator apply enqueued by a solver: no-ops once that solve is over (SkipRef)
+__global__ void __launch_bounds__(RED_THREADS) copy_skip_kernel(cplx *__restrict__ dst, const cplx *__restrict__ src, int64_t n,
+                                                                const int *__restrict__ skip, int skip_it) {
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    GRID_STRIDE(i, n) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(RED_THREADS) set_skip_kernel(cplx *__restrict__ dst, cplx c, int64_t n,
+                                                               const int *__restrict__ skip, int skip_it) {
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    GRID_STRIDE(i, n) dst[i] = c;
+}
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -83,6 +94,20 @@ int k_copy(cplx *dst, const cplx *src, int64_t n) {
     return MGCR_OK;
 }
 int k_zero(cplx *dst, int64_t n) { return k_set_constant(dst, make_double2(0., 0.), n); }
+// Inside an operator apply (GCR / MG used as preconditioner): the output vector may be live storage of
+// the calling solver (a direction slot), so even the initialisation must respect its stop predicate.
+int k_copy_apply(cplx *dst, const cplx *src, int64_t n) {
+    if (n == 0 || dst == src) return MGCR_OK;
+    SkipRef sk = get_apply_skip();
+    LAUNCH(copy_skip_kernel, red_grid(n), dst, src, n, sk.p, sk.it);
+    return MGCR_OK;
+}
+int k_zero_apply(cplx *dst, int64_t n) {
+    if (n == 0) return MGCR_OK;
+    SkipRef sk = get_apply_skip();
+    LAUNCH(set_skip_kernel, red_grid(n), dst, make_double2(0., 0.), n, sk.p, sk.it);
+    return MGCR_OK;
+}
 int k_set_constant(cplx *dst, cplx c, int64_t n) {
     if (n == 0) return MGCR_OK;
     LAUNCH(set_kernel, red_grid(n), dst, c, n);

@@ -13,6 +13,16 @@
 //                    ring slot, plus <r,Ap'> and <Ap',Ap'> partials and the step's bookkeeping
 //                    (history entry, convergence predicate)                        (4+2 lim) V
 //     = B_spmv + (11 + 3 lim) V of HBM traffic per iteration;
+//   * restart mode without the literal preconditioner hooks runs LEAN: inside a restart cycle the
+//     directions p_k are never formed.  Only x needs them, and x is updated once per cycle, so the
+//     solver keeps what p_k is a combination of — the cycle's first direction P0 and the residuals
+//     (or M r, flexible mode) D_1..D_k the later directions were started from — plus the small
+//     triangular table of coefficients p_k = t_k P0 + sum_m T_km D_m on the device.  The residual ring
+//     costs nothing (xr_update writes r into the slot instead of in place), build shrinks from
+//     (4+2 lim) V to (3+lim) V, and the step that closes the cycle applies x += sum_k alpha_k p_k and
+//     forms the next P0 from the same streams the classic closing step reads.  r, Ap and every scalar
+//     follow the same recurrences with the same bits; x differs by rounding only (MGCR_LEAN=0 selects
+//     the classic kernels);
 //   * all scalars (alpha, beta_i, norms, the iteration counter, the convergence flag and the
 //     residual history) stay on the device.  Reductions are two-stage and deterministic: producers
 //     write per-workgroup partials, consumers fold them in a fixed order (reduce.h), so the
@@ -65,6 +75,24 @@ struct DirPtrs {
     int slot[ND];
 };
 
+// lean restart cycles: p_k = t[k] P0 + sum_{1<=m<=k} T[k][m] D_m;  cx = coefficients of the pending x update
+struct LeanCoef {
+    cplx T[ND * ND];
+    cplx t[ND];
+    cplx cx[ND];
+};
+
+static int g_lean = -1;
+static bool lean_enabled() {
+    if (g_lean < 0) g_lean = !(getenv("MGCR_LEAN") && atoi(getenv("MGCR_LEAN")) == 0);
+    return g_lean != 0;
+}
+bool set_lean_enabled(bool on) {
+    bool prev = lean_enabled();
+    g_lean = on ? 1 : 0;
+    return prev;
+}
+
 static double g_prof_spmv_ms = 0.;
 static int g_prof_spmv_n = 0;
 void gcr_last_profile(double *ms, int *n) { *ms = g_prof_spmv_ms; *n = g_prof_spmv_n; }
@@ -89,6 +117,7 @@ struct GcrState {
     double *dRB = nullptr;  // [1 + 2 * dirs]: |r|^2, then the beta numerators
     double *dN = nullptr;   // [2]: |b|^2, |r0|^2
     cplx *alphas = nullptr; // [storage]: alpha of the deferred x updates of the current restart cycle
+    LeanCoef *lc = nullptr;
     // captured restart cycle (see gcr_run)
     hipGraphExec_t graph_exec = nullptr;
     const cplx *graph_x = nullptr;
@@ -178,12 +207,13 @@ __global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const d
 // updates x += alpha_j p_j of a whole restart cycle are applied, in iteration order, by the
 // build_kernel that closes the cycle (which streams those p_j anyway) or by flush_x_kernel at the
 // end of the solve — 3 V less traffic per iteration, bit-identical x.
-template <bool DEFER>
+template <bool DEFER, bool LEAN>
 __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsA,
                                                                 int nblkA, int strideA, const cplx *__restrict__ p,
                                                                 const cplx *__restrict__ ap, cplx *__restrict__ x,
-                                                                cplx *__restrict__ r, int64_t n, double *__restrict__ partsR,
-                                                                cplx *__restrict__ den_slot, cplx *__restrict__ alphas, int slot) {
+                                                                const cplx *r_in, cplx *r_out, int64_t n, double *__restrict__ partsR,
+                                                                cplx *__restrict__ den_slot, cplx *__restrict__ alphas, int slot,
+                                                                LeanCoef *__restrict__ lc) {
     __shared__ double lds[4 * 17];
     if (st->stop_at < st->base + it) return;
     double s[4];
@@ -193,15 +223,26 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *den_slot = den;
         if (DEFER) {
-            alphas[slot] = alpha;
             st->npend = slot + 1;
+            if (LEAN) {
+                // x += alpha p_slot, in terms of P0 and D_1..D_slot
+                if (slot == 0) {
+                    lc->cx[0] = alpha;
+                    for (int m = 1; m < ND; m++) lc->cx[m] = make_double2(0., 0.);
+                } else {
+                    lc->cx[0] = cadd(lc->cx[0], cmul(alpha, lc->t[slot]));
+                    for (int m = 1; m <= slot; m++) lc->cx[m] = cadd(lc->cx[m], cmul(alpha, lc->T[slot * ND + m]));
+                }
+            } else {
+                alphas[slot] = alpha;
+            }
         }
     }
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
         if (!DEFER) x[i] = cadd(x[i], cmul(alpha, p[i]));
-        cplx rn = csub(r[i], cmul(alpha, ap[i]));
-        r[i] = rn;
+        cplx rn = csub(r_in[i], cmul(alpha, ap[i]));
+        r_out[i] = rn;  // LEAN: the residual ring (r_out != r_in inside a cycle); else in place
         v[0] += rn.x * rn.x + rn.y * rn.y;
     }
     block_sum_bcast<1>(v, lds);
@@ -376,6 +417,169 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
     }
 }
 
+// step bookkeeping shared by the build kernels (src/GCR.h:270-274,288)
+__device__ __forceinline__ void close_step(DevState *st, int it, double rr, double *hist, int hist_cap, bool clear_pending) {
+    const int git = st->base + it;  // global_count
+    st->iter = git;
+    st->rr = rr;
+    if (git < hist_cap) hist[git] = sqrt(rr) / sqrt(st->bnorm2);
+    // continue while |r|^2/|b|^2 > tol^2 (src/GCR.h:288); NaN compares false -> stop, like the reference
+    if (!((rr / st->bnorm2) > st->tol2)) st->stop_at = git;
+    if (clear_pending) st->npend = 0;
+}
+
+// LEAN, inside a restart cycle: direction k = NDT is started from D_k (the residual, or M r) and only
+// its image is formed:  Ap_k = Ar - sum_{j<k} beta_j Ap_j  (same order as build_kernel), with the
+// <r,Ap_k>, <Ap_k,Ap_k> partials; workgroup 0 extends the coefficient table by row k:
+//   p_k = D_k - sum_j beta_j p_j   =>   t_k = -sum_j beta_j t_j ,  T_km = -sum_{j>=m} beta_j T_jm ,  T_kk = 1.
+template <int NDT>
+__global__ void __launch_bounds__(RED_THREADS) build_lean_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
+                                                                 int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
+                                                                 int strideR, double *__restrict__ hist, int hist_cap,
+                                                                 const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ r,
+                                                                 const cplx *__restrict__ ar, cplx *__restrict__ ap_out, int64_t n,
+                                                                 double *__restrict__ partsA, LeanCoef *__restrict__ lc) {
+    __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
+    __shared__ cplx sbeta[NDT];
+    if (st->stop_at < st->base + it) return;
+    double s[2 * NDT];
+    fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
+    if (blockIdx.x == 0) {
+        double rr[1];
+        fold_partials<1>(partsR, nblkR, strideR, rr, lds);
+        if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, false);
+    }
+    if (threadIdx.x < NDT) {
+        cplx num = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++)
+            if (j == (int)threadIdx.x) num = make_double2(s[2 * j], s[2 * j + 1]);
+        sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        constexpr int k = NDT;
+        cplx tk = make_double2(0., 0.);
+        for (int j = 0; j < k; j++) tk = csub(tk, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
+        lc->t[k] = tk;
+        for (int m = 1; m < k; m++) {
+            cplx a = make_double2(0., 0.);
+            for (int j = m; j < k; j++) a = csub(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * ND + m]));
+            lc->T[k * ND + m] = a;
+        }
+        lc->T[k * ND + k] = make_double2(1., 0.);
+    }
+    cplx beta[NDT];
+#pragma unroll
+    for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
+    double v[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n) {
+        cplx aj[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) aj[j] = ld_stream<NTS>(d.aps[j] + i);
+        const cplx av = ar[i], rv = r[i];
+        cplx ac = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++) ac = csub(ac, cmul(beta[j], aj[j]));
+        const cplx an = cadd(av, ac);
+        ap_out[i] = an;
+        cplx t = cconj_mul(rv, an);
+        v[0] += t.x; v[1] += t.y;
+        cplx u = cconj_mul(an, an);
+        v[2] += u.x; v[3] += u.y;
+    }
+    block_sum_bcast<4>(v, lds);
+    if (threadIdx.x < 4) {
+        double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
+        partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
+    }
+}
+
+// LEAN, the step that closes a restart cycle (NDT = restart = lim).  d.ps[0] is P0, d.ps[m] the D_m;
+// `dir` is D_R, what the new direction is started from.  In one pass:
+//   x    += cx_0 P0 + sum_m cx_m D_m                        (the cycle's x updates, = sum_k alpha_k p_k)
+//   P0'   = dir - cp_0 P0 - sum_m cp_m D_m                   (= dir - sum_j beta_j p_j, src/GCR.h:257-266)
+//   Ap_0' = Ar - sum_j beta_j Ap_j                           with cp_m = sum_{j>=m} beta_j T_jm, cp_0 = sum_j beta_j t_j
+// written in place over slot 0, plus the <r,Ap'>, <Ap',Ap'> partials and the step's bookkeeping.
+template <int NDT, bool RDIR>
+__global__ void __launch_bounds__(RED_THREADS) build_close_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
+                                                                  int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
+                                                                  int strideR, double *__restrict__ hist, int hist_cap,
+                                                                  const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ dir,
+                                                                  const cplx *__restrict__ r, const cplx *__restrict__ ar, cplx *p_out,
+                                                                  cplx *ap_out, int64_t n, double *__restrict__ partsA,
+                                                                  cplx *__restrict__ x, const LeanCoef *__restrict__ lc) {
+    __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
+    __shared__ cplx sbeta[NDT], scp[NDT];
+    if (st->stop_at < st->base + it) return;
+    double s[2 * NDT];
+    fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
+    if (blockIdx.x == 0) {
+        double rr[1];
+        fold_partials<1>(partsR, nblkR, strideR, rr, lds);
+        if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, true);
+    }
+    if (threadIdx.x < NDT) {
+        cplx num = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++)
+            if (j == (int)threadIdx.x) num = make_double2(s[2 * j], s[2 * j + 1]);
+        sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NDT) {
+        const int m = threadIdx.x;
+        cplx a = make_double2(0., 0.);
+        if (m == 0) {
+            for (int j = 0; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
+        } else {
+            for (int j = m; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * ND + m]));
+        }
+        scp[m] = a;
+    }
+    __syncthreads();
+    cplx beta[NDT], cp[NDT], cx[NDT];
+#pragma unroll
+    for (int j = 0; j < NDT; j++) {
+        beta[j] = to_sgpr(sbeta[j]);
+        cp[j] = to_sgpr(scp[j]);
+        cx[j] = to_sgpr(lc->cx[j]);
+    }
+    double v[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n) {
+        cplx pj[NDT], aj[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) {
+            pj[j] = ld_stream<NTS>(d.ps[j] + i);
+            aj[j] = ld_stream<NTS>(d.aps[j] + i);
+        }
+        const cplx dv = dir[i], av = ar[i];
+        const cplx rv = RDIR ? r[i] : dv;
+        cplx xv = x[i];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) xv = cadd(xv, cmul(cx[j], pj[j]));
+        x[i] = xv;
+        cplx pc = make_double2(0., 0.), ac = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++) {
+            pc = csub(pc, cmul(cp[j], pj[j]));
+            ac = csub(ac, cmul(beta[j], aj[j]));
+        }
+        const cplx pn = cadd(dv, pc), an = cadd(av, ac);
+        st_stream<NTS>(p_out + i, pn);
+        ap_out[i] = an;
+        cplx t = cconj_mul(rv, an);
+        v[0] += t.x; v[1] += t.y;
+        cplx u = cconj_mul(an, an);
+        v[2] += u.x; v[3] += u.y;
+    }
+    block_sum_bcast<4>(v, lds);
+    if (threadIdx.x < 4) {
+        double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
+        partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +636,7 @@ void gcr_state_destroy(GcrState *s) {
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     gcr_free_vectors(s);
     hipFree(s->x0); hipFree(s->st); hipFree(s->partsA); hipFree(s->partsR); hipFree(s->partsN);
-    hipFree(s->dA); hipFree(s->dN);
+    hipFree(s->dA); hipFree(s->dN); hipFree(s->lc);
     delete s;
 }
 
@@ -451,6 +655,7 @@ int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out
     if (rc == MGCR_OK) rc = dalloc(&s->partsN, RED_MAX_BLOCKS);
     if (rc == MGCR_OK) rc = dalloc(&s->dA, 4);
     if (rc == MGCR_OK) rc = dalloc(&s->dN, 2);
+    if (rc == MGCR_OK) rc = dalloc(&s->lc, 1);
     if (rc != MGCR_OK) { gcr_state_destroy(s); return rc; }
     *out = s;
     return MGCR_OK;
@@ -618,6 +823,67 @@ static int launch_build(const BuildArgs &a) {
     }
 }
 
+struct LeanArgs {
+    int g, nd;
+    bool rdir;
+    DevState *st;
+    int it;
+    RedRef B, R;
+    double *hist;
+    int hist_cap;
+    const cplx *den;
+    DirPtrs d;
+    const cplx *dir, *r, *ar;
+    cplx *p_out, *ap_out;
+    int64_t n;
+    double *partsA;
+    cplx *x;
+    LeanCoef *lc;
+};
+
+static int launch_build_lean(const LeanArgs &a) {
+#define BL(NDT)                                                                                                               \
+    KLAUNCH((build_lean_kernel<NDT>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk, a.R.stride, a.hist,      \
+            a.hist_cap, a.den, a.d, a.r, a.ar, a.ap_out, a.n, a.partsA, a.lc)
+    switch (a.nd) {
+        case 1: BL(1); break;
+        case 2: BL(2); break;
+        case 3: BL(3); break;
+        case 4: BL(4); break;
+        case 5: BL(5); break;
+        case 6: BL(6); break;
+        default: BL(7); break;  // a cycle of ND slots has at most ND - 1 in-cycle builds
+    }
+#undef BL
+    return MGCR_OK;
+}
+
+static int launch_build_close(const LeanArgs &a) {
+#define BC(NDT)                                                                                                               \
+    do {                                                                                                                      \
+        if (a.rdir)                                                                                                           \
+            KLAUNCH((build_close_kernel<NDT, true>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk,           \
+                    a.R.stride, a.hist, a.hist_cap, a.den, a.d, a.dir, a.r, a.ar, a.p_out, a.ap_out, a.n, a.partsA, a.x,      \
+                    (const LeanCoef *)a.lc);                                                                                  \
+        else                                                                                                                  \
+            KLAUNCH((build_close_kernel<NDT, false>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk,          \
+                    a.R.stride, a.hist, a.hist_cap, a.den, a.d, a.dir, a.r, a.ar, a.p_out, a.ap_out, a.n, a.partsA, a.x,      \
+                    (const LeanCoef *)a.lc);                                                                                  \
+    } while (0)
+    switch (a.nd) {
+        case 1: BC(1); break;
+        case 2: BC(2); break;
+        case 3: BC(3); break;
+        case 4: BC(4); break;
+        case 5: BC(5); break;
+        case 6: BC(6); break;
+        case 7: BC(7); break;
+        default: BC(8); break;
+    }
+#undef BC
+    return MGCR_OK;
+}
+
 // read back iteration count / history once the solve has been enqueued (not for nested solves)
 static int gcr_finish(GcrState *s, double *hist, int hist_cap, int *n_iter, int *converged) {
     Context &c = ctx();
@@ -713,6 +979,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     int check_every = p.check_every > 0 ? p.check_every : 10;
     // restart mode with all slots handled by one build launch: defer the x updates of a cycle
     const bool defer = p.restart != 0 && s->storage <= ND;
+    // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
+    const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
+    const cplx *rcur = s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;
@@ -720,14 +989,35 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     auto one_iteration = [&](int it) -> int {
         iter_count++;
         set_apply_skip(SkipRef{&s->st->stop_at, it});
+        // slot the new direction goes to (src/GCR.h:277-287)
+        const int lim = s->storage < iter_count ? s->storage : iter_count;  // src/GCR.h:251
+        int ic_next = iter_count;
+        if (iter_count % s->restart == 0) ic_next = 0;
+        const int nxt = ic_next % s->storage;
+        MGCR_TRY(ensure_slot(s, nxt));
         // alpha, x, r
+        const cplx *dir;
+        if (lean) {
+            // D_nxt, what direction nxt is started from, lands in the p slot of that direction (nxt >= 1);
+            // the step that closes the cycle only needs it for its own build
+            cplx *dslot = nxt >= 1 ? s->ps[nxt] : (flex ? s->z : s->r);
+            cplx *r_out = flex ? s->r : dslot;
+            KLAUNCH((xr_update_kernel<true, true>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)nullptr,
+                    (const cplx *)s->aps[cur], x, rcur, r_out, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
+            rcur = r_out;
+            dir = r_out;
+            if (flex) {
+                MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, dslot, n));
+                dir = dslot;
+            }
+        } else {
         if (defer)
-            KLAUNCH((xr_update_kernel<true>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
-                    (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur, s->alphas, cur);
+            KLAUNCH((xr_update_kernel<true, false>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
+                    (const cplx *)s->aps[cur], x, (const cplx *)s->r, s->r, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
         else
-            KLAUNCH((xr_update_kernel<false>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
-                    (const cplx *)s->aps[cur], x, s->r, n, s->partsR, s->den + cur, s->alphas, cur);
-        const cplx *dir = s->r;
+            KLAUNCH((xr_update_kernel<false, false>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
+                    (const cplx *)s->aps[cur], x, (const cplx *)s->r, s->r, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
+        dir = s->r;
         if (flex) {
             MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
             dir = s->z;
@@ -736,6 +1026,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             std::swap(s->r, s->tmp);
             dir = s->r;
             KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, it);
+        }
         }
         if (p.profile_spmv && !nested) {
             hipEvent_t e0, e1;
@@ -752,12 +1043,6 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->ar, s->tmp, n));
             std::swap(s->ar, s->tmp);
         }
-        const int lim = s->storage < iter_count ? s->storage : iter_count;  // src/GCR.h:251
-        // slot the new direction goes to (src/GCR.h:277-287)
-        int ic_next = iter_count;
-        if (iter_count % s->restart == 0) ic_next = 0;
-        const int nxt = ic_next % s->storage;
-        MGCR_TRY(ensure_slot(s, nxt));
         const int nchunk = (lim + ND - 1) / ND;
         for (int ch = 0; ch < nchunk; ch++) {
             DirPtrs d;
@@ -775,6 +1060,16 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             MGCR_TRY(comm_allreduce_dev(comm, s->dRB, 1 + 2 * lim));
             refB = {s->dRB + 1, 1, 1};
         }
+        if (lean) {
+            LeanArgs a;
+            a.g = g; a.nd = lim; a.rdir = flex; a.st = s->st; a.it = it; a.B = refB; a.R = refR; a.hist = s->hist;
+            a.hist_cap = s->hist_cap; a.den = s->den;
+            for (int j = 0; j < ND; j++) { int sl = j < lim ? j : 0; a.d.ps[j] = s->ps[sl]; a.d.aps[j] = s->aps[sl]; a.d.slot[j] = sl; }
+            a.dir = dir; a.r = rcur; a.ar = s->ar; a.p_out = s->ps[0]; a.ap_out = s->aps[nxt]; a.n = n; a.partsA = s->partsA;
+            a.x = x; a.lc = s->lc;
+            if (ic_next == 0) MGCR_TRY(launch_build_close(a));  // lim == restart: closes the cycle
+            else MGCR_TRY(launch_build_lean(a));                // lim == nxt
+        } else
         for (int ch = 0; ch < nchunk; ch++) {
             BuildArgs a;
             a.g = g;
@@ -848,7 +1143,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (defer) {  // x updates still pending (solve ended inside a restart cycle); ps[0..npend) hold their directions
         DirPtrs d0;
         for (int j = 0; j < ND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
-        KLAUNCH(flush_x_kernel, g, s->st, (const cplx *)s->alphas, d0, x, n);
+        KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n);
         hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);
         MGCR_HIP(hipGetLastError());
     }
@@ -872,8 +1167,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y) {
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
     const int64_t n = s->A->dim;
-    if (s->x0_mode == 0 && s->x0) MGCR_TRY(k_copy(y, s->x0, n));
-    else MGCR_TRY(k_zero(y, n));
+    if (s->x0_mode == 0 && s->x0) MGCR_TRY(k_copy_apply(y, s->x0, n));
+    else MGCR_TRY(k_zero_apply(y, n));
     return gcr_run(s, f, y, true, nullptr, 0, nullptr, nullptr);
 }
 

@@ -208,6 +208,7 @@ bool gcr_small_eligible(const Op *A, const mgcr_gcr_param &p, int storage, int64
     const Op *base = A->kind == OP_DIRAC ? A->base : A;
     if (base->kind != OP_CSR || base->dist || base->comm) return false;
     if (base->csr.nrow != base->csr.ncol) return false;
+    if (base->csr.pat_mode) return false;  // pattern-dictionary storage (>= 2^15 rows) has no slab to walk
     return true;
 }
 

@@ -81,6 +81,15 @@ struct CsrDev {
     cplx *ell_val = nullptr;       // complex slab, or ...
     double *ell_val_re = nullptr;  // ... real slab when every stored value has a zero imaginary part (12 B/nnz)
     int32_t *ell_col = nullptr;
+    // Row-pattern dictionary (spmv.hip): rows whose (column - row, value) tuples coincide share one
+    // table entry and store a 2-byte id.  pat_mode 1: offsets and values in the table (no slab at all);
+    // 2: offsets only (values stay in the slab, ell_col is dropped); 0: plain ELL.
+    int pat_mode = 0;
+    int32_t npat = 0;
+    uint16_t *pat_id = nullptr;   // [npad]
+    int32_t *pat_off = nullptr;   // [npat][W]
+    double *pat_re = nullptr, *pat_im = nullptr;  // [npat][W], mode 1
+    bool pat_real = false;        // mode 1: every imaginary part is zero
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]
@@ -116,6 +125,8 @@ struct Op {
 int red_grid(int64_t n);
 int k_copy(cplx *dst, const cplx *src, int64_t n);
 int k_zero(cplx *dst, int64_t n);
+int k_copy_apply(cplx *dst, const cplx *src, int64_t n);  // skip-aware (operator applies)
+int k_zero_apply(cplx *dst, int64_t n);
 int k_set_constant(cplx *dst, cplx c, int64_t n);
 int k_fill_rhs(cplx *dst, int64_t n, uint64_t seed, int64_t offset);
 int k_add_scaled(cplx *out, const cplx *a, cplx alpha, const cplx *b, int64_t n);  // out = a + alpha*b
@@ -128,6 +139,8 @@ int k_fold(const double *parts, int nblk, int nscal, double *out_dev);
 int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *h_col,
                      const double *h_val_ri, CsrDev *out);
 void csr_free(CsrDev *c);
+bool set_patterns_enabled(bool on);
+bool set_lean_enabled(bool on);
 // y = A x   or (shift) y = x - k*(A x); dist != nullptr: row block with halo exchange
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,

@@ -231,10 +231,10 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     MgLevel &L = m->lev[(size_t)l];
     const int nlev = (int)m->lev.size();
     if (l == nlev - 1) {
-        MGCR_TRY(k_zero(x, L.n));
+        MGCR_TRY(k_zero_apply(x, L.n));
         return gcr_run(L.coarse, b, x, true, nullptr, 0, nullptr, nullptr);
     }
-    MGCR_TRY(k_zero(x, L.n));
+    MGCR_TRY(k_zero_apply(x, L.n));
     MGCR_TRY(gcr_run(L.pre, b, x, true, nullptr, 0, nullptr, nullptr));
     MGCR_TRY(op_apply_raw(L.A, x, L.r, L.n));
     hipLaunchKernelGGL(residual_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, b, L.r, get_apply_skip().p, get_apply_skip().it);

@@ -34,6 +34,11 @@ struct RowSrc {
     const cplx *val;
     const double *val_re;
     const int32_t *col;
+    // row-pattern dictionary (CsrDev::pat_mode): ids, offsets and (mode 1) values replace col / val
+    int pat_mode;
+    const uint16_t *pid;
+    const int32_t *poff;
+    const double *pre, *pim;
     int64_t ntail;
     const int32_t *trows, *tptr, *tcol;
     const cplx *tval;
@@ -47,6 +52,12 @@ __device__ __forceinline__ void for_each_entry(const RowSrc &s, int64_t i, F f) 
     if (s.kind == 0) {
         for (int32_t w = 0; w < s.Wp; w++) {
             int64_t idx = ((int64_t)(w / s.L) * s.npad + i) * s.L + (w % s.L);
+            if (s.pat_mode) {
+                int32_t t = (int32_t)s.pid[i] * s.Wp + w;
+                cplx v = s.pat_mode == 1 ? make_double2(s.pre[t], s.pim[t]) : (s.val_re ? make_double2(s.val_re[idx], 0.) : s.val[idx]);
+                f(i + (int64_t)s.poff[t], v);
+                continue;
+            }
             cplx v = s.val_re ? make_double2(s.val_re[idx], 0.) : s.val[idx];
             f((int64_t)s.col[idx], v);
         }
@@ -221,6 +232,7 @@ static RowSrc row_source(const Op *op) {
     } else {
         const CsrDev &A = op->csr;
         s.kind = 0; s.npad = A.npad; s.Wp = A.nchunk * A.L; s.L = A.L; s.val = A.ell_val; s.val_re = A.ell_val_re; s.col = A.ell_col;
+        s.pat_mode = A.pat_mode; s.pid = A.pat_id; s.poff = A.pat_off; s.pre = A.pat_re; s.pim = A.pat_im;
         s.ntail = A.n_tail_rows; s.trows = A.tail_rows; s.tptr = A.tail_ptr; s.tcol = A.tail_col; s.tval = A.tail_val;
     }
     return s;

@@ -99,6 +99,7 @@ static int dev_upload(T **d, const T *h, size_t count) {
 
 void csr_free(CsrDev *c) {
     hipFree(c->ell_val); hipFree(c->ell_val_re); hipFree(c->ell_col);
+    hipFree(c->pat_id); hipFree(c->pat_off); hipFree(c->pat_re); hipFree(c->pat_im);
     hipFree(c->tail_rows); hipFree(c->tail_ptr); hipFree(c->tail_col); hipFree(c->tail_val);
     *c = CsrDev();
 }
@@ -133,6 +134,200 @@ static int32_t choose_lanes(int64_t nrow, int32_t W) {
         if (nrow * L >= (int64_t)1 << 17) break;
     }
     return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-pattern dictionary.  Operators that come from a lattice or a grid repeat a handful of row
+// patterns: the tuple (column - row, value) per stored entry is the same for every interior row and
+// for every row of a given boundary class (7-point Poisson: 27 patterns for any grid size; Galerkin
+// coarse operators of it likewise).  Such a matrix is stored as one 2-byte pattern id per row plus the
+// pattern table, which the SpMV reads through L1/L2 — the 12-20 B per stored entry the ELL slab costs
+// shrink to 2 B per ROW.  When the values differ from row to row but the sparsity pattern repeats
+// (lattice-QCD hopping terms), only the column indices go into the table and the values stay in the slab.
+// Entries are multiplied and added in the same order as the ELL kernels do, so y has the same bits.
+// The dictionary is found on the device: a hash set of 64-bit row hashes (open addressing, atomicCAS),
+// then every row is compared entry by entry with its pattern's first row, so a hash collision can only
+// cost the compression (fallback to the plain slab), never correctness.
+// ------------------------------------------------------------------------------------------------
+constexpr int PAT_TABLE_BITS = 14;  // 16384 slots
+constexpr int PAT_MAX = 4096;       // patterns: table stays L2-resident (<= 4096 * W * 20 B)
+constexpr int64_t PAT_MIN_ROWS = 1 << 15;
+
+__device__ __forceinline__ uint64_t pat_mix(uint64_t h, uint64_t v) {
+    h = (h ^ v) * 0xff51afd7ed558ccdull;
+    return h ^ (h >> 29);
+}
+
+template <bool VALS>
+__device__ __forceinline__ uint64_t pat_row_hash(int64_t i, int64_t npad, int32_t W, const int32_t *__restrict__ col,
+                                                 const cplx *__restrict__ val) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (int32_t w = 0; w < W; w++) {
+        int64_t idx = (int64_t)w * npad + i;
+        h = pat_mix(h, (uint64_t)(uint32_t)(col[idx] - (int32_t)i));
+        if (VALS) {
+            h = pat_mix(h, (uint64_t)__double_as_longlong(val[idx].x));
+            h = pat_mix(h, (uint64_t)__double_as_longlong(val[idx].y));
+        }
+    }
+    return h | 1ull;  // 0 marks an empty slot
+}
+
+__device__ __forceinline__ int pat_find(uint64_t h, const unsigned long long *keys) {
+    const int mask = (1 << PAT_TABLE_BITS) - 1;
+    int s = (int)(h >> 20) & mask;
+    for (int probe = 0; probe <= mask; probe++) {
+        if (keys[s] == h) return s;
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+
+template <bool VALS>
+__global__ void pat_insert_kernel(int64_t nrow, int64_t npad, int32_t W, const int32_t *__restrict__ col,
+                                  const cplx *__restrict__ val, unsigned long long *keys, int *rep, int *count,
+                                  volatile int *overflow) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrow || *overflow) return;
+    const uint64_t h = pat_row_hash<VALS>(i, npad, W, col, val);
+    const int mask = (1 << PAT_TABLE_BITS) - 1;
+    int s = (int)(h >> 20) & mask;
+    for (int probe = 0; probe <= mask; probe++) {
+        unsigned long long k = *(volatile unsigned long long *)(keys + s);
+        if (k == 0ull) {
+            k = atomicCAS(keys + s, 0ull, (unsigned long long)h);
+            if (k == 0ull) {
+                if (atomicAdd(count, 1) + 1 > PAT_MAX) *overflow = 1;
+                k = h;
+            }
+        }
+        if (k == h) {
+            if ((int)i < *(volatile int *)(rep + s)) atomicMin(rep + s, (int)i);
+            return;
+        }
+        if (*overflow) return;
+        s = (s + 1) & mask;
+    }
+    *overflow = 1;
+}
+
+template <bool VALS>
+__global__ void pat_assign_kernel(int64_t nrow, int64_t npad, int32_t W, const int32_t *__restrict__ col,
+                                  const cplx *__restrict__ val, const unsigned long long *__restrict__ keys,
+                                  const int *__restrict__ rep, const int *__restrict__ slot_id, uint16_t *__restrict__ pid,
+                                  int *__restrict__ mismatch) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= nrow) { pid[i] = 0; return; }
+    const uint64_t h = pat_row_hash<VALS>(i, npad, W, col, val);
+    int s = pat_find(h, keys);
+    if (s < 0) { *mismatch = 1; pid[i] = 0; return; }
+    const int64_t r = rep[s];
+    bool same = true;
+    for (int32_t w = 0; w < W; w++) {
+        int64_t a = (int64_t)w * npad + i, b = (int64_t)w * npad + r;
+        same = same && (col[a] - (int32_t)i) == (col[b] - (int32_t)r);
+        if (VALS)
+            same = same && __double_as_longlong(val[a].x) == __double_as_longlong(val[b].x) &&
+                   __double_as_longlong(val[a].y) == __double_as_longlong(val[b].y);
+    }
+    if (!same) *mismatch = 1;
+    pid[i] = (uint16_t)slot_id[s];
+}
+
+__global__ void pat_fill_kernel(int32_t npat, int32_t W, int64_t npad, const int *__restrict__ rep_row,
+                                const int32_t *__restrict__ col, const cplx *__restrict__ val, int32_t *__restrict__ off,
+                                double *__restrict__ re, double *__restrict__ im) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npat * W) return;
+    int id = t / W, w = t - id * W;
+    int64_t r = rep_row[id];
+    int64_t idx = (int64_t)w * npad + r;
+    off[t] = col[idx] - (int32_t)r;
+    if (re) { re[t] = val[idx].x; im[t] = val[idx].y; }
+}
+
+static int g_patterns = -1;
+static bool patterns_enabled() {
+    if (g_patterns < 0) g_patterns = !(getenv("MGCR_PATTERNS") && atoi(getenv("MGCR_PATTERNS")) == 0);
+    return g_patterns != 0;
+}
+bool set_patterns_enabled(bool on) {
+    bool prev = patterns_enabled();
+    g_patterns = on ? 1 : 0;
+    return prev;
+}
+
+// tries to build the dictionary for the (L = 1) slab of A; leaves A.pat_mode = 0 when it does not pay
+template <bool VALS>
+static int pat_try(CsrDev &A, bool *ok) {
+    Context &c = ctx();
+    *ok = false;
+    const int T = 1 << PAT_TABLE_BITS;
+    unsigned long long *d_keys = nullptr;
+    int *d_rep = nullptr, *d_small = nullptr, *d_slot_id = nullptr, *d_rep_row = nullptr;
+    std::vector<unsigned long long> keys((size_t)T);
+    std::vector<int> rep((size_t)T), slot_id((size_t)T, 0), small(3, 0);
+    int rc = MGCR_OK;
+    auto done = [&](int r) {
+        hipFree(d_keys); hipFree(d_rep); hipFree(d_small); hipFree(d_slot_id); hipFree(d_rep_row);
+        return r;
+    };
+    MGCR_HIP(hipMalloc((void **)&d_keys, sizeof(unsigned long long) * T));
+    if (hipMalloc((void **)&d_rep, sizeof(int) * T) != hipSuccess || hipMalloc((void **)&d_small, sizeof(int) * 3) != hipSuccess ||
+        hipMalloc((void **)&d_slot_id, sizeof(int) * T) != hipSuccess)
+        return done(MGCR_OK);  // no memory for the attempt: keep the plain slab
+    hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * T, c.stream);
+    hipMemsetAsync(d_rep, 0x7f, sizeof(int) * T, c.stream);
+    hipMemsetAsync(d_small, 0, sizeof(int) * 3, c.stream);
+    const unsigned grid = (unsigned)((A.nrow + 255) / 256), gridp = (unsigned)((A.npad + 255) / 256);
+    hipLaunchKernelGGL((pat_insert_kernel<VALS>), dim3(grid), dim3(256), 0, c.stream, A.nrow, A.npad, A.W, (const int32_t *)A.ell_col,
+                       (const cplx *)A.ell_val, d_keys, d_rep, d_small, d_small + 1);
+    hipMemcpyAsync(small.data(), d_small, sizeof(int) * 3, hipMemcpyDeviceToHost, c.stream);
+    MGCR_HIP(hipStreamSynchronize(c.stream));
+    const int npat = small[0];
+    // worth it only when the table is far smaller than the matrix
+    if (small[1] || npat < 1 || npat > PAT_MAX || (int64_t)npat * 64 > A.nrow) return done(MGCR_OK);
+    MGCR_HIP(hipMemcpy(keys.data(), d_keys, sizeof(unsigned long long) * T, hipMemcpyDeviceToHost));
+    MGCR_HIP(hipMemcpy(rep.data(), d_rep, sizeof(int) * T, hipMemcpyDeviceToHost));
+    // ids in the order of each pattern's first row: deterministic whatever order the inserts raced in
+    std::vector<std::pair<int, int>> order;  // (first row, slot)
+    for (int s = 0; s < T; s++)
+        if (keys[(size_t)s]) order.emplace_back(rep[(size_t)s], s);
+    std::sort(order.begin(), order.end());
+    if ((int)order.size() != npat) return done(MGCR_OK);
+    std::vector<int> rep_row((size_t)npat);
+    for (int id = 0; id < npat; id++) { slot_id[(size_t)order[(size_t)id].second] = id; rep_row[(size_t)id] = order[(size_t)id].first; }
+    if (hipMalloc((void **)&d_rep_row, sizeof(int) * npat) != hipSuccess) return done(MGCR_OK);
+    MGCR_HIP(hipMemcpy(d_slot_id, slot_id.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+    MGCR_HIP(hipMemcpy(d_rep_row, rep_row.data(), sizeof(int) * npat, hipMemcpyHostToDevice));
+    uint16_t *pid = nullptr;
+    int32_t *off = nullptr;
+    double *re = nullptr, *im = nullptr;
+    bool alloc_ok = hipMalloc((void **)&pid, sizeof(uint16_t) * (size_t)A.npad) == hipSuccess &&
+                    hipMalloc((void **)&off, sizeof(int32_t) * (size_t)npat * A.W) == hipSuccess;
+    if (alloc_ok && VALS)
+        alloc_ok = hipMalloc((void **)&re, sizeof(double) * (size_t)npat * A.W) == hipSuccess &&
+                   hipMalloc((void **)&im, sizeof(double) * (size_t)npat * A.W) == hipSuccess;
+    if (alloc_ok) {
+        hipLaunchKernelGGL((pat_assign_kernel<VALS>), dim3(gridp), dim3(256), 0, c.stream, A.nrow, A.npad, A.W,
+                           (const int32_t *)A.ell_col, (const cplx *)A.ell_val, (const unsigned long long *)d_keys, (const int *)d_rep,
+                           (const int *)d_slot_id, pid, d_small + 2);
+        hipLaunchKernelGGL(pat_fill_kernel, dim3((unsigned)((npat * A.W + 255) / 256)), dim3(256), 0, c.stream, npat, A.W, A.npad,
+                           (const int *)d_rep_row, (const int32_t *)A.ell_col, (const cplx *)A.ell_val, off, re, im);
+        hipMemcpyAsync(small.data(), d_small, sizeof(int) * 3, hipMemcpyDeviceToHost, c.stream);
+        if (hipStreamSynchronize(c.stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = MGCR_ERR_HIP;
+    }
+    if (!alloc_ok || rc != MGCR_OK || small[2]) {  // small[2]: two different rows shared a hash
+        hipFree(pid); hipFree(off); hipFree(re); hipFree(im);
+        if (rc != MGCR_OK) set_error("pattern dictionary kernels failed");
+        return done(rc);
+    }
+    A.pat_mode = VALS ? 1 : 2;
+    A.npat = npat;
+    A.pat_id = pid; A.pat_off = off; A.pat_re = re; A.pat_im = im;
+    *ok = true;
+    return done(MGCR_OK);
 }
 
 // device CSR (already resident) + host row pointers -> CsrDev
@@ -195,18 +390,34 @@ static int ell_from_device_csr(int64_t nrow, int64_t ncol, const int64_t *h_rowp
         MGCR_HIP(hipGetLastError());
     }
     MGCR_HIP(hipStreamSynchronize(c.stream));  // trows/tptr go out of scope
+    int has_imag = 1;
+    if (slab && A.nnz > 0) {
+        int *d_flag = nullptr;
+        MGCR_HIP(hipMalloc((void **)&d_flag, sizeof(int)));
+        MGCR_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), c.stream));
+        hipLaunchKernelGGL(imag_check_kernel, dim3((unsigned)((A.nnz + 255) / 256)), dim3(256), 0, c.stream, A.nnz, d_val, d_flag);
+        MGCR_HIP(hipMemcpyAsync(&has_imag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        MGCR_HIP(hipStreamSynchronize(c.stream));
+        hipFree(d_flag);
+    }
+    if (slab && A.L == 1 && A.W >= 1 && A.W <= 32 && A.nrow >= PAT_MIN_ROWS && patterns_enabled()) {
+        bool ok = false;
+        MGCR_TRY(pat_try<true>(A, &ok));
+        if (ok) {  // the table holds everything: no slab
+            A.pat_real = !has_imag;
+            hipFree(A.ell_val); hipFree(A.ell_col);
+            A.ell_val = nullptr; A.ell_col = nullptr;
+            *out = A;
+            return MGCR_OK;
+        }
+        MGCR_TRY(pat_try<false>(A, &ok));
+        if (ok) { hipFree(A.ell_col); A.ell_col = nullptr; }
+    }
     // Real matrices (every imaginary part exactly 0, e.g. Poisson): keep the slab's values as fp64
     // reals, 12 B instead of 20 B per stored entry.  v*(c+di) with v real is (vc, vd): the same numbers
     // the complex product (vc - 0*d, vd + 0*c) gives for finite x.
     if (slab && A.nnz > 0 && real_storage_enabled()) {
-        int *d_flag = nullptr, h_flag = 0;
-        MGCR_HIP(hipMalloc((void **)&d_flag, sizeof(int)));
-        MGCR_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), c.stream));
-        hipLaunchKernelGGL(imag_check_kernel, dim3((unsigned)((A.nnz + 255) / 256)), dim3(256), 0, c.stream, A.nnz, d_val, d_flag);
-        MGCR_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-        MGCR_HIP(hipStreamSynchronize(c.stream));
-        hipFree(d_flag);
-        if (!h_flag) {
+        if (!has_imag) {
             hipError_t e = hipMalloc((void **)&A.ell_val_re, sizeof(double) * slab);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(slab_real_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, c.stream, (int64_t)slab,
@@ -333,6 +544,48 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
     y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
 }
 
+// Row-pattern dictionary SpMV (L = 1): one thread per row; the row's 2-byte id selects the table row
+// holding its W column offsets (and, MODE 1, its W values).  Interior rows of a wave share one id, so
+// the table loads are single-line broadcasts out of L1.  Same multiply/add order as ell_spmv_rowthread.
+template <int WT, bool SHIFT, bool XCD, int MODE, bool REALV>
+__global__ void __launch_bounds__(256) pat_spmv_rowthread(int64_t row_begin, int64_t row_count, int64_t npad, int32_t Wrt,
+                                                          int64_t ntiles, const uint16_t *__restrict__ pid,
+                                                          const int32_t *__restrict__ poff, const double *__restrict__ pre,
+                                                          const double *__restrict__ pim, const void *__restrict__ val,
+                                                          const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
+                                                          cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
+    int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
+    if (tile >= ntiles) return;
+    int64_t rloc = tile * 256 + threadIdx.x;
+    if (rloc >= row_count) return;
+    const int64_t row = row_begin + rloc;
+    const int32_t W = WT ? WT : Wrt;
+    const int32_t t0 = (int32_t)__builtin_nontemporal_load(pid + row) * W;
+    cplx sum = make_double2(0., 0.);
+    auto term = [&](int32_t c, cplx xv) -> cplx {
+        if (MODE == 1) {
+            if (REALV) {
+                double v = pre[t0 + c];
+                return make_double2(v * xv.x, v * xv.y);
+            }
+            return cmul(make_double2(pre[t0 + c], pim[t0 + c]), xv);
+        }
+        return vmul<REALV, true>(val, (int64_t)c * npad + row, xv);
+    };
+    if (WT) {
+        cplx xv[WT ? WT : 1];
+#pragma unroll
+        for (int32_t c = 0; c < W; c++) xv[c] = gather_x(x, xh, n_own, (int32_t)row + poff[t0 + c]);
+#pragma unroll
+        for (int32_t c = 0; c < W; c++) sum = cadd(sum, term(c, xv[c]));
+    } else {
+#pragma unroll 4
+        for (int32_t c = 0; c < W; c++) sum = cadd(sum, term(c, gather_x(x, xh, n_own, (int32_t)row + poff[t0 + c])));
+    }
+    y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
+}
+
 // L in {2,4,8,16}: L consecutive lanes share a row; per chunk the (row, lane) pairs are contiguous
 template <int L, bool SHIFT, bool REALV>
 __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t row_count, int64_t npad, int32_t nchunk,
@@ -393,6 +646,26 @@ template <bool SHIFT>
 static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const cplx *x, const cplx *xh, int32_t n_own, cplx *y, cplx k) {
     Context &c = ctx();
     if (row_count <= 0) return MGCR_OK;
+    if (A.pat_mode) {
+        int64_t ntiles = (row_count + 255) / 256;
+        bool xcd = ntiles >= 64;
+        unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
+        const void *vals = A.ell_val_re ? (const void *)A.ell_val_re : (const void *)A.ell_val;
+        const bool realv = A.pat_mode == 1 ? A.pat_real : A.ell_val_re != nullptr;
+#define PT(WT, X, M, RV)                                                                                                       \
+    hipLaunchKernelGGL((pat_spmv_rowthread<WT, SHIFT, X, M, RV>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count,    \
+                       A.npad, A.W, ntiles, (const uint16_t *)A.pat_id, (const int32_t *)A.pat_off, (const double *)A.pat_re, \
+                       (const double *)A.pat_im, vals, x, xh, n_own, y, k, g_skip.p, g_skip.it)
+#define PT_RV(WT, X, M) do { if (realv) PT(WT, X, M, true); else PT(WT, X, M, false); } while (0)
+#define PT_X(WT, M) do { if (xcd) PT_RV(WT, true, M); else PT_RV(WT, false, M); } while (0)
+        if (A.pat_mode == 1) { if (A.W == 7) PT_X(7, 1); else PT_X(0, 1); }
+        else { if (A.W == 7) PT_X(7, 2); else PT_X(0, 2); }
+#undef PT_X
+#undef PT_RV
+#undef PT
+        MGCR_HIP(hipGetLastError());
+        return MGCR_OK;
+    }
     if (A.L == 1) {
         int64_t ntiles = (row_count + 255) / 256;
         bool xcd = ntiles >= 64;

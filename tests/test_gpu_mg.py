@@ -157,7 +157,7 @@ def _dense(op, n, wrap):
     return out
 
 
-@pytest.mark.parametrize("kind", ["poisson", "dirac"])
+@pytest.mark.parametrize("kind", ["poisson", "poisson32", "dirac"])
 def test_device_setup_bit_identical_to_oracle(kind, sample_matrix_path, mg_gold):
     """The hierarchy the device kernels build (mg_setup.hip) — aggregates, Gram-Schmidt'ed
     prolongator, every entry of every Galerkin coarse operator, the restricted near-null vectors
@@ -166,12 +166,13 @@ def test_device_setup_bit_identical_to_oracle(kind, sample_matrix_path, mg_gold)
     smo = orc.gcr_param(restart=10, max_iter=2, tol=1e-30)
     coo = orc.gcr_param(restart=10, max_iter=50, tol=1e-2)
     sm, co = GCR(GCR_Param(0, 10, 2, 1e-30, False)), GCR(GCR_Param(0, 10, 50, 1e-2, False))
-    if kind == "poisson":
-        n = 16
+    if kind.startswith("poisson"):
+        n = 32 if kind == "poisson32" else 16  # 32^3 rows: the fine operator is stored as a row-pattern dictionary
         N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
         dims, nlevel = (n, n, n), 2
         vecs = np.ones((1, N), np.complex128)
         A = Sparse(N, ncol, rowptr, col, val)
+        assert A.storage_format()[0] == (1 if n == 32 else 0)
         M = MG(A, MG_Param(Mesh(dims), 2, 1, None, co, sm, nlevel, None, None, null_vectors=vecs))
         Mo = orc.MG(orc.csr(N, ncol, rowptr, col, val), rowptr, col, val, dims, (1, 1, 1), 2, vecs, nlevel + 1, smo, coo)
     else:

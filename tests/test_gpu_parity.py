@@ -313,6 +313,110 @@ def test_spmv_bit_exact_when_one_thread_per_row():
     assert np.array_equal(y, ref)
 
 
+@pytest.mark.parametrize("case", ["real-constant", "complex-constant", "random-values", "random-columns"])
+def test_row_pattern_storage_is_bit_exact(case):
+    """Sparse matrices of >= 2^15 rows whose rows repeat a few (column - row, value) patterns are stored
+    as a 2-byte pattern id per row (format 1), or — values differing from row to row — with the columns
+    in the dictionary and the values in a slab (format 2).  Either way the SpMV multiplies and adds in
+    CSR order: y has the bits of the reference's row loop (src/Operator.h:338-341), with and without
+    the DiracOp epilogue, and the same bits as the plain ELL slab."""
+    n = 40  # 64000 rows
+    rng = np.random.default_rng(11)
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    want = 1
+    if case == "complex-constant":
+        val = val * (0.75 - 0.5j)
+    elif case == "random-values":
+        val = rng.standard_normal(val.size) + 1j * rng.standard_normal(val.size)
+        want = 2
+    elif case == "random-columns":
+        # sorted random columns per row: nothing repeats, the dictionary overflows and the slab stays
+        col = np.sort(rng.integers(0, ncol, size=(N, 5)), axis=1).ravel()
+        rowptr = np.arange(N + 1, dtype=np.int64) * 5
+        val = rng.standard_normal(col.size) + 1j * rng.standard_normal(col.size)
+        want = 0
+    x = problems.rhs_grid(N, 9)
+    O = orc.csr(N, ncol, rowptr, col, val)
+    ref = O(x)
+    A = Sparse(N, ncol, rowptr, col, val)
+    fmt, npat = A.storage_format()
+    assert fmt == want, (fmt, npat)
+    if case in ("real-constant", "complex-constant"):
+        assert npat == 27  # 3 boundary classes per axis
+    xf = Field((N,), x)
+    y = A(xf).to_numpy()
+    assert np.array_equal(y, ref)
+    k = 0.3 - 0.2j
+    assert np.array_equal(DiracOp(A, k)(xf).to_numpy(), orc.dirac(O, k)(x))
+    prev = mg.set_option("pattern_storage", 0)
+    try:
+        B = Sparse(N, ncol, rowptr, col, val)
+    finally:
+        mg.set_option("pattern_storage", prev)
+    assert B.storage_format() == (0, 0)
+    assert np.array_equal(B(xf).to_numpy(), y)
+    if want:
+        assert A.stored_bytes()["matrix_bytes"] < B.stored_bytes()["matrix_bytes"]
+
+
+def test_row_pattern_storage_same_solve():
+    """GCR on the pattern-dictionary operator and on the plain slab: identical histories and x."""
+    n = 40
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    b = Field((n, n, n)).fill_rhs(3)
+    out = []
+    for on in (1, 0):
+        prev = mg.set_option("pattern_storage", on)
+        try:
+            A = Sparse(N, ncol, rowptr, col, val)
+        finally:
+            mg.set_option("pattern_storage", prev)
+        g = GCR(A, GCR_Param(0, 5, 60, 1e-12, False))
+        x = Field((n, n, n)).set_zero()
+        g.solve(b, x)
+        out.append((A.storage_format()[0], g.last_history.copy(), x.to_numpy()))
+    assert out[0][0] == 1 and out[1][0] == 0
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("kind,restart,tol", [("poisson", 5, 1e-10), ("poisson", 1, 1e-6), ("poisson", 8, 1e-10),
+                                              ("dirac", 5, 1e-12), ("dirac", 3, 1e-12), ("flex", 4, 1e-10)])
+def test_lean_restart_cycles_match_classic(kind, restart, tol, sample, sample_oracle):
+    """Restart-mode GCR keeps, inside a cycle, the residuals the directions were started from instead of
+    the directions (gcr.hip header).  r, Ap and every scalar follow the same recurrences: the residual
+    history has the same bits as with the classic kernels; x is the same linear combination summed in a
+    different order: it differs by rounding, and its TRUE residual is as good."""
+    if kind == "dirac":
+        dims = DIMS
+        n = sample.get_dim()
+        A = DiracOp(sample, 0.18)
+        b = Field(dims, problems.rhs_grid(n, 5))
+        M = None
+    else:
+        n1 = 24
+        n, ncol, rowptr, col, val = problems.poisson3d_csr(n1)
+        dims = (n1, n1, n1)
+        A = Sparse(n, ncol, rowptr, col, val * (1.0 + 0.125j))
+        b = Field(dims, problems.rhs_grid(n, 5))
+        # the preconditioner runs in truncated mode, which has no lean variant: identical in both passes
+        M = GCR(A, GCR_Param(3, 0, 3, 1e-30, False)) if kind == "flex" else None
+    out = []
+    for on in (1, 0):
+        prev = mg.set_option("lean_cycles", on)
+        try:
+            g = GCR(A, GCR_Param(0, restart, 400, tol, False, None, M, flexible=M is not None))
+            x = Field(dims).set_zero()
+            g.solve(b, x)
+        finally:
+            mg.set_option("lean_cycles", prev)
+        true_res = (b - A(x)).norm() / b.norm()
+        out.append((g.last_history.copy(), x.to_numpy(), g.last_iterations, true_res))
+    (h1, x1, it1, t1), (h0, x0, it0, t0) = out
+    assert it1 == it0 and np.array_equal(h1, h0)
+    assert np.abs(x1 - x0).max() <= 1e-12 * np.abs(x0).max()
+    assert t1 <= max(2.0 * t0, 1.05 * tol)
+
+
 def test_gcr_vs_oracle_random_nonhermitian():
     """Seeded diagonally dominant complex matrix, every mode, against the CPU oracle."""
     rng = np.random.default_rng(42)
