@@ -13,8 +13,8 @@ inputs resident in HBM, bracketed by barrier + device synchronisation; the max o
 reported.  N > 1: the grid grows along i to (128 N) x 128 x 128 and is slab-partitioned, 128
 planes (= the N=1 problem) per GPU — weak scaling; value = N * iterations/s (shard-iterations/s).
 
-One JSON line on stdout (rank 0), with `roofline` (SpMV kernel, hipEvent-timed on the library's
-own stream) and `cpu_baseline` (the real reference, oracle/_ref/ref_harness, on this box's host
+One JSON line on stdout (rank 0), with `roofline` (the phase of the iteration that takes longest,
+hipEvent-timed on the library's own stream inside a solve) and `cpu_baseline` (the real reference, oracle/_ref/ref_harness, on this box's host
 cores; falls back to the oracle port when that binary is absent).
 """
 import argparse
@@ -156,64 +156,81 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     it_per_s = args.steps / dt
 
-    # dominant kernel: SpMV.  Timed IN SITU: a third solve of the same length with hipEvents (library
-    # stream) around every operator apply of the loop — back-to-back replays of one SpMV would be
-    # served from the 256 MiB Infinity Cache once matrix + x + y fit in it, which they do here.
+    # Per-phase timing IN SITU: a third solve of the same length with hipEvents (library stream) between
+    # the phases of every iteration — back-to-back replays of one kernel would be served from the
+    # 256 MiB Infinity Cache once its operands fit, which at this size they do.
     import ctypes
     run(args.steps, profile=True)
-    ms_c, n_c = ctypes.c_double(), ctypes.c_int32()
-    mg.lib().mgcr_gcr_last_profile(ctypes.byref(ms_c), ctypes.byref(n_c))
-    spmv_ms = ms_c.value
+    ph_ms = (ctypes.c_double * 3)()
+    n_it, fused = ctypes.c_int32(), ctypes.c_int32()
+    mg.lib().mgcr_gcr_last_profile(ph_ms, ctypes.byref(n_it), ctypes.byref(fused))
+    ph_us = [1e3 * v / max(n_it.value, 1) for v in ph_ms]           # average microseconds per iteration
     y = Field(dims)
     spmv_ms_replay = A.bench_apply(rhs, y, reps=args.spmv_reps)
-    b_spmv = spmv_algorithmic_bytes(nnz, N, ncol)
     stored = A.stored_bytes()
-    # Bytes the kernel has to move with the layout it actually stores ("if the
-    # implementation stores something else ... it must report with its stored sizes"): the ELL slab
-    # (12 B per entry when the matrix is real — Poisson is — else 20 B) + x read once + y written once.
-    b_stored = stored["matrix_bytes"] + 16 * ncol + 16 * N
-    real_vals = stored["matrix_bytes"] < 20 * nnz
-    achieved = b_stored / (spmv_ms * 1e-3) / 1e9
-    achieved_survey = b_spmv / (spmv_ms * 1e-3) / 1e9
+    fmt, npat = A.storage_format() if world == 1 else (None, None)
+    V = 16 * N
+    R = args.restart
+    # Bytes each phase has to move per launch with the layout actually stored ("if the
+    # implementation stores something else ... it must report with its stored sizes"), averaged over a
+    # restart cycle (lim = number of stored directions the step orthogonalises against):
+    #   xr      r, Ap read + r written                                              3 V
+    #   apply   matrix (pattern ids + tables, or slab) + r read + Ar written + lim Aps_j read (+ Ar re-read
+    #           by the separate multidot kernel when the fused kernel is not used)
+    #   build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
+    lim_avg = (R + 1) / 2.0
+    b_phase = [3.0 * V,
+               stored["matrix_bytes"] + 16 * ncol + 16 * N + lim_avg * V + (0 if fused.value else V),
+               (sum(3 + l for l in range(1, R)) + 2 * R + 6) * V / float(R)]
+    names = ["xr_update_kernel (alpha, residual ring, |r|^2)",
+             "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value else "SpMV + multidot_kernel",
+             "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
+    keys = ["xr", "apply_dots", "build"]
+    dom = max(range(3), key=lambda k: ph_us[k])
+    achieved = b_phase[dom] / (ph_us[dom] * 1e-6) / 1e9
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
             d = json.load(open(prof))
-            if d.get("n") == n:
-                traffic = d.get("hbm_bytes_per_launch")
+            if d.get("n") == n and world == 1:
+                traffic = d["phase_hbm_bytes_per_launch"].get(keys[dom])
         except Exception:
             traffic = None
-    V = 16 * N
-    mean_lim = (args.restart + 1) / 2.0
-    iter_bytes_model = b_spmv + (13 + 3 * mean_lim) * V       # SURVEY.md §8(d) accounting
-    iter_bytes_ours = b_spmv + (11 + 3 * mean_lim) * V        # what this implementation moves (gcr.hip header)
+    b_spmv_survey = spmv_algorithmic_bytes(nnz, N, ncol)
+    mean_lim = (R + 1) / 2.0
+    iter_bytes_survey = b_spmv_survey + (13 + 3 * mean_lim) * V   # SURVEY.md §8(d) accounting
+    iter_bytes_ours = sum(b_phase)                                # what this implementation moves
 
     out = {
         "metric": "gcr_iterations_per_sec", "value": it_per_s * world, "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "complex-f64", "data": "synthetic",
-        "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, fp64 complex, x0=0, "
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, complex fp64, x0=0, "
                                "RHS splitmix64 seed 0" % (n, args.restart),
-                   "rows": N, "nnz": nnz, "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],
+                   "rows": N, "nnz": nnz, "complex": True,
+                   "matrix_storage": {None: "row block of a distributed Sparse", 0: "ELL slab",
+                                      1: "row-pattern dictionary, %s patterns (2 B per row + table)" % npat,
+                                      2: "row-pattern dictionary for the columns (%s patterns) + value slab" % npat}[fmt],
+                   "stored_matrix_bytes": stored["matrix_bytes"], "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],
                    "partition": "1 GPU" if world == 1 else "slab x%d (grid %dx%dx%d), %s" % (
                        world, world * n, n, n, "host-staged transport (bring-up, not a result)" if host_transport
                        else "RCCL halo exchange + all-reduce")},
-        "spmv": {"ms": spmv_ms, "timed": "in situ, hipEvents around each of the %d applies of a GCR solve" % n_c.value,
-                 "ms_back_to_back_replay": spmv_ms_replay, "includes_halo_exchange": world > 1,
-                 "value_storage": "real fp64, 12 B/entry (all imaginary parts are zero)" if real_vals else "complex fp64, 20 B/entry",
-                 "stored_matrix_bytes": stored["matrix_bytes"], "bytes_moved_stored_layout": b_stored, "GBps": achieved,
-                 "frac_hbm_peak": achieved / HBM_PEAK_GBS,
-                 "algorithmic_bytes_survey_formula": b_spmv, "GBps_survey_formula": achieved_survey,
-                 "frac_hbm_peak_survey_formula": achieved_survey / HBM_PEAK_GBS},
-        "iteration": {"algorithmic_bytes_survey": iter_bytes_model, "bytes_moved_model": iter_bytes_ours,
-                      "GBps_survey": iter_bytes_model / (ms_per_step * 1e-3) / 1e9,
-                      "frac_hbm_peak_survey": iter_bytes_model / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "roofline": {"kernel": "ell_spmv_rowthread<7> (SpMV)", "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_launch": b_stored,
-                     "note": "achieved = bytes of the stored layout (slab + x + y) / hipEvent-timed launch; with the "
-                             "20 B/nnz formula of SURVEY 8(d) it would read %.0f GB/s" % achieved_survey},
+        "phases": {keys[k]: {"kernel": names[k], "us_per_iteration": ph_us[k], "bytes_per_launch": b_phase[k],
+                             "GBps": b_phase[k] / (ph_us[k] * 1e-6) / 1e9 if ph_us[k] > 0 else None} for k in range(3)},
+        "phases_timed": "in situ: hipEvents between the phases of each of the %d iterations of a GCR solve" % n_it.value,
+        "spmv": {"ms_back_to_back_replay": spmv_ms_replay, "includes_halo_exchange": world > 1,
+                 "bytes_moved_stored_layout": stored["matrix_bytes"] + 16 * ncol + 16 * N,
+                 "algorithmic_bytes_survey_formula": b_spmv_survey},
+        "iteration": {"bytes_moved_model": iter_bytes_ours, "GBps": iter_bytes_ours / (ms_per_step * 1e-3) / 1e9,
+                      "frac_hbm_peak": iter_bytes_ours / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "algorithmic_bytes_survey": iter_bytes_survey,
+                      "GBps_survey": iter_bytes_survey / (ms_per_step * 1e-3) / 1e9},
+        "roofline": {"kernel": names[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": b_phase[dom],
+                     "us_per_launch": ph_us[dom],
+                     "note": "dominant phase of the iteration by time; achieved = bytes of the stored layout the phase's "
+                             "kernel has to move per launch (average over a restart cycle) / its hipEvent-timed duration"},
         "final_rel_residual": float(hist[-1]),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

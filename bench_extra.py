@@ -85,9 +85,12 @@ def main():
             x.set_zero()
             gcr = GCR(A, GCR_Param(0, 5, iters, 0.0, False, check_every=iters, profile_spmv=True))
             dt = timed_solve(mg, gcr, rhs, x)
-            ms, na = ctypes.c_double(), ctypes.c_int32()
-            mg.lib().mgcr_gcr_last_profile(ctypes.byref(ms), ctypes.byref(na))
-            b_stored = stored["matrix_bytes"] + 2 * V
+            ph, na, fu = (ctypes.c_double * 3)(), ctypes.c_int32(), ctypes.c_int32()
+            mg.lib().mgcr_gcr_last_profile(ph, ctypes.byref(na), ctypes.byref(fu))
+            ms = ctypes.c_double(ph[1] / max(na.value, 1))   # operator apply (+ beta dots when fused)
+            out["phase_us_per_iteration"] = [1e3 * v / max(na.value, 1) for v in ph]
+            out["apply_fused_with_dots"] = bool(fu.value)
+            b_stored = stored["matrix_bytes"] + 2 * V + (3 * V if fu.value else 0)
             b_survey = nnz * 20 + (N + 1) * 4 + 2 * V
             out.update(n=n, rows=N, nnz=nnz, iterations=iters, ms_per_iteration=dt * 1e3 / iters, it_per_s=iters / dt,
                        spmv_ms_in_situ=ms.value, spmv_GBps_stored_layout=b_stored / ms.value / 1e6,

@@ -106,7 +106,9 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  *   "pattern_storage" ($MGCR_PATTERNS): try the row-pattern dictionary for every Sparse of >= 2^15 rows
  *                      created while it is on;
  *   "lean_cycles"     ($MGCR_LEAN): restart-mode GCR keeps residuals instead of search directions inside
- *                      a restart cycle (same r, Ap and scalars; x differs by rounding).
+ *                      a restart cycle (same r, Ap and scalars; x differs by rounding);
+ *   "fused_apply"     ($MGCR_FUSE): GCR on a single-GPU Sparse / DiracOp runs the SpMV and the beta dot
+ *                      products of its result as one kernel (same bits as the two kernels).
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);
 
@@ -126,8 +128,8 @@ typedef struct mgcr_gcr_param {
                             instead of the reference's literal r = M(r) (src/GCR.h:236-238) */
     int32_t check_every; /* host looks at the device-side convergence flag every this many
                             iterations (0 = library default); results do not depend on it */
-    int32_t profile_spmv; /* 1: bracket every operator apply of the loop with hipEvents on the
-                            library stream; read the result with mgcr_gcr_last_profile (bench.py) */
+    int32_t profile_spmv; /* 1: bracket the phases of every iteration with hipEvents on the library
+                            stream; read the result with mgcr_gcr_last_profile (bench.py) */
 } mgcr_gcr_param;
 
 /* GCR::solve(rhs, x) (src/GCR.h:158-302).  hist[0] is the step-0 entry, hist[k] the value
@@ -236,9 +238,12 @@ int mgcr_dcsr_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t n
 /* runs `reps` applies back to back on the library stream, bracketed by hipEvents there;
  * returns the average milliseconds per apply */
 int mgcr_bench_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y, int32_t reps, double *ms_avg);
-/* average in-loop duration of the operator apply (SpMV incl. halo exchange) of the last
- * mgcr_gcr_solve that ran with profile_spmv = 1, and the number of applies it was averaged over */
-int mgcr_gcr_last_profile(double *spmv_ms_avg, int32_t *n_applies);
+/* In-loop timing of the last solve that ran with profile_spmv = 1: total milliseconds, over its
+ * *n_iter iterations, of the three phases of an iteration — [0] alpha / residual update (+ right
+ * preconditioner), [1] operator apply (incl. halo exchange) + beta dot products, [2] direction build —
+ * from hipEvents recorded on the library stream between the phases.  *fused = 1 when phase 1 ran as
+ * the single SpMV+dot kernel. */
+int mgcr_gcr_last_profile(double *phase_ms_total, int32_t *n_iter, int32_t *fused);
 /* opaque hipEvent-based stopwatch on the library stream */
 int mgcr_timer_start(void);
 int mgcr_timer_stop(double *ms);

@@ -136,6 +136,7 @@ int mgcr_set_option(const char *name, int value, int *previous) {
     bool prev;
     if (!strcmp(name, "pattern_storage")) prev = set_patterns_enabled(value != 0);
     else if (!strcmp(name, "lean_cycles")) prev = set_lean_enabled(value != 0);
+    else if (!strcmp(name, "fused_apply")) prev = set_fuse_enabled(value != 0);
     else { set_error("mgcr_set_option: unknown option '%s'", name); return MGCR_ERR_INVALID; }
     if (previous) *previous = prev ? 1 : 0;
     return MGCR_OK;
@@ -251,13 +252,12 @@ int mgcr_set_small_solve_rows(int64_t rows) {
     return MGCR_OK;
 }
 
-int mgcr_gcr_last_profile(double *spmv_ms_avg, int32_t *n_applies) {
-    MGCR_CHECK(spmv_ms_avg && n_applies, MGCR_ERR_INVALID, "null argument");
-    double ms = 0.;
-    int n = 0;
-    gcr_last_profile(&ms, &n);
-    *spmv_ms_avg = ms;
-    *n_applies = n;
+int mgcr_gcr_last_profile(double *phase_ms_total, int32_t *n_iter, int32_t *fused) {
+    MGCR_CHECK(phase_ms_total && n_iter && fused, MGCR_ERR_INVALID, "null argument");
+    int n = 0, f = 0;
+    gcr_last_profile(phase_ms_total, &n, &f);
+    *n_iter = n;
+    *fused = f;
     return MGCR_OK;
 }
 

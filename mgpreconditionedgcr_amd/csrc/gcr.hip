@@ -43,44 +43,9 @@
 
 #include "internal.h"
 #include "reduce.h"
+#include "gcr_dev.h"
 
 namespace mgcr {
-
-constexpr int ND = 8;  // directions per multidot / build launch
-#ifndef MGCR_NT_SLOTS
-#define MGCR_NT_SLOTS 1
-#endif
-constexpr bool NTS = MGCR_NT_SLOTS != 0;  // non-temporal access to the old direction slots
-
-struct DevState {
-    // Iteration at which the solve ended (INT_MAX while running).  Every kernel of the solve gets the
-    // iteration number `it` it belongs to and returns at once when stop_at < it.  The bookkeeping of
-    // step k (inside build_kernel) writes stop_at = k, which is >= the `it` of every kernel of step
-    // k: no kernel ever acts on a value written by a concurrently running workgroup of itself.
-    int stop_at;
-    // Iteration numbers reach the kernels as base + it: `it` is a launch argument counted from the last
-    // advance_kernel, `base` lives here.  Eager launches never advance (base = 0, it = global count);
-    // a captured restart cycle (hipGraph) is replayed with it = 1..R and followed by base += R.
-    int base;
-    int iter;      // global_count
-    int npend;     // x updates deferred so far in this restart cycle (see xr_update_kernel)
-    double bnorm2; // |b|^2
-    double rr;     // |r|^2 of the last finished step
-    double tol2;
-};
-
-struct DirPtrs {
-    const cplx *ps[ND];
-    const cplx *aps[ND];
-    int slot[ND];
-};
-
-// lean restart cycles: p_k = t[k] P0 + sum_{1<=m<=k} T[k][m] D_m;  cx = coefficients of the pending x update
-struct LeanCoef {
-    cplx T[ND * ND];
-    cplx t[ND];
-    cplx cx[ND];
-};
 
 static int g_lean = -1;
 static bool lean_enabled() {
@@ -93,9 +58,16 @@ bool set_lean_enabled(bool on) {
     return prev;
 }
 
-static double g_prof_spmv_ms = 0.;
-static int g_prof_spmv_n = 0;
-void gcr_last_profile(double *ms, int *n) { *ms = g_prof_spmv_ms; *n = g_prof_spmv_n; }
+// profile_spmv: hipEvents around the three phases of every iteration of the last profiled solve:
+// 0 = alpha/r update (+ preconditioner), 1 = operator apply + beta dot products, 2 = direction build
+static double g_prof_phase_ms[3] = {0., 0., 0.};
+static int g_prof_iters = 0;
+static bool g_prof_fused = false;
+void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused) {
+    for (int k = 0; k < 3; k++) phase_ms_total[k] = g_prof_phase_ms[k];
+    *n_iter = g_prof_iters;
+    *fused = g_prof_fused ? 1 : 0;
+}
 
 struct GcrState {
     Op *A = nullptr;
@@ -224,18 +196,8 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
         *den_slot = den;
         if (DEFER) {
             st->npend = slot + 1;
-            if (LEAN) {
-                // x += alpha p_slot, in terms of P0 and D_1..D_slot
-                if (slot == 0) {
-                    lc->cx[0] = alpha;
-                    for (int m = 1; m < ND; m++) lc->cx[m] = make_double2(0., 0.);
-                } else {
-                    lc->cx[0] = cadd(lc->cx[0], cmul(alpha, lc->t[slot]));
-                    for (int m = 1; m <= slot; m++) lc->cx[m] = cadd(lc->cx[m], cmul(alpha, lc->T[slot * ND + m]));
-                }
-            } else {
-                alphas[slot] = alpha;
-            }
+            if (LEAN) lean_pending_update(lc, slot, alpha);
+            else alphas[slot] = alpha;
         }
     }
     double v[1] = {0.};
@@ -269,20 +231,23 @@ __global__ void advance_kernel(DevState *st, int by) { st->base += by; }
 // load in flight cannot cover HBM latency, even at 32 waves per CU).
 template <int NDT, int U>
 __global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *__restrict__ st, int it, const cplx *__restrict__ ar,
-                                                               DirPtrs d, int base, int64_t n,
+                                                               DirPtrs d, int base, int64_t n, int trips,
                                                                double *__restrict__ partsB) {
     __shared__ double lds[2 * NDT * 17];
     if (st->stop_at < st->base + it) return;
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+    // workgroup b owns the contiguous rows [b * trips * RED_THREADS, (b + 1) * trips * RED_THREADS), one
+    // RED_THREADS-wide slice per trip: the row -> (workgroup, thread, trip) map of gcr_fused.hip's
+    // step_apply_kernel, so that either kernel yields the same partial sums
+    const int64_t first = (int64_t)blockIdx.x * trips * RED_THREADS + threadIdx.x;
+    for (int k0 = 0; k0 < trips; k0 += U) {
         cplx a[U], b[U][NDT];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t i = i0 + u * stride;
-            if (i < n) {
+            const int64_t i = first + (int64_t)(k0 + u) * RED_THREADS;
+            if (k0 + u < trips && i < n) {
                 a[u] = ar[i];
 #pragma unroll
                 for (int j = 0; j < NDT; j++) b[u][j] = ld_stream<NTS>(d.aps[j] + i);
@@ -753,7 +718,8 @@ struct SkipGuard {
 };
 
 static int launch_multidot(int g, int nd, const DevState *st, int it, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB) {
-#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, partsB)
+    const int trips = red_trips(n);
+#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, trips, partsB)
     switch (nd) {
         case 1: MD(1, 2); break;
         case 2: MD(2, 2); break;
@@ -982,6 +948,12 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
     const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
     const cplx *rcur = s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
+    // operator apply fused with the beta dot products: single-GPU Sparse / DiracOp in a one-thread-per-row layout
+    bool fuse_ok = false;
+    if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !multi && !p.left_precond) {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        fuse_ok = b0->kind == OP_CSR && csr_fusable(b0->csr, b0->dist) && b0->csr.nrow == n;
+    }
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;
@@ -989,6 +961,15 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     auto one_iteration = [&](int it) -> int {
         iter_count++;
         set_apply_skip(SkipRef{&s->st->stop_at, it});
+        auto mark = [&]() -> int {
+            if (!(p.profile_spmv && !nested)) return MGCR_OK;
+            hipEvent_t e;
+            MGCR_HIP(hipEventCreate(&e));
+            MGCR_HIP(hipEventRecord(e, c.stream));
+            prof_events.push_back(e);
+            return MGCR_OK;
+        };
+        MGCR_TRY(mark());  // 4 events per iteration: | xr (+M) | apply + dots | build |
         // slot the new direction goes to (src/GCR.h:277-287)
         const int lim = s->storage < iter_count ? s->storage : iter_count;  // src/GCR.h:251
         int ic_next = iter_count;
@@ -1028,22 +1009,20 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, it);
         }
         }
-        if (p.profile_spmv && !nested) {
-            hipEvent_t e0, e1;
-            MGCR_HIP(hipEventCreate(&e0));
-            MGCR_HIP(hipEventCreate(&e1));
-            MGCR_HIP(hipEventRecord(e0, c.stream));
-            MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));
-            MGCR_HIP(hipEventRecord(e1, c.stream));
-            prof_events.push_back(e0);
-            prof_events.push_back(e1);
-        } else
+        MGCR_TRY(mark());
+        const int nchunk = (lim + ND - 1) / ND;
+        if (fuse_ok && nchunk == 1) {
+            // Ar = A dir and the <Ar, Aps_j> partials in one pass (spmv.hip)
+            const cplx *vecs[ND];
+            for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < lim ? j : 0];
+            const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->partsB));
+        } else {
         MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
         if (p.left_precond) {                         // src/GCR.h:245-247
             MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->ar, s->tmp, n));
             std::swap(s->ar, s->tmp);
         }
-        const int nchunk = (lim + ND - 1) / ND;
         for (int ch = 0; ch < nchunk; ch++) {
             DirPtrs d;
             int nd = lim - ch * ND < ND ? lim - ch * ND : ND;
@@ -1053,6 +1032,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             }
             MGCR_TRY(launch_multidot(g, nd, cst, it, (const cplx *)s->ar, d, ch * ND, n, s->partsB));
         }
+        }
+        MGCR_TRY(mark());
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
         if (multi) {  // one all-reduce for |r|^2 and all beta numerators of the step
             MGCR_TRY(k_fold(s->partsR, g, 1, s->dRB));
@@ -1090,6 +1071,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
             MGCR_TRY(comm_allreduce_dev(comm, s->dA, 4));
         }
+        MGCR_TRY(mark());
         iter_count = ic_next;
         cur = nxt;
         return MGCR_OK;
@@ -1150,14 +1132,15 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (nested) return MGCR_OK;
     if (!prof_events.empty()) {
         MGCR_HIP(hipStreamSynchronize(c.stream));
-        double tot = 0.;
-        for (size_t i = 0; i + 1 < prof_events.size(); i += 2) {
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]);
-            tot += ms;
-        }
-        g_prof_spmv_n = (int)(prof_events.size() / 2);
-        g_prof_spmv_ms = tot / g_prof_spmv_n;
+        for (int k = 0; k < 3; k++) g_prof_phase_ms[k] = 0.;
+        for (size_t i = 0; i + 3 < prof_events.size(); i += 4)
+            for (int k = 0; k < 3; k++) {
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, prof_events[i + k], prof_events[i + k + 1]);
+                g_prof_phase_ms[k] += ms;
+            }
+        g_prof_iters = (int)(prof_events.size() / 4);
+        g_prof_fused = fuse_ok;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
     return gcr_finish(s, hist, hist_cap, n_iter, converged);

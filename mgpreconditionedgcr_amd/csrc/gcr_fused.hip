@@ -1,0 +1,137 @@
+// GCR step kernel that embeds the operator apply (single-GPU Sparse / DiracOp, one thread per row):
+// Ar = A r  and the partial sums of <Ar, Aps_j> (conj on Ar, src/GCR.h:258), j < NDT, in ONE pass — Ar is
+// not read back from HBM and the SpMV's dependent id -> table -> gather chain overlaps with the Aps_j
+// streams (Poisson 128^3: 39.8 us against 21.9 + 22.6 us for the two kernels).
+//
+// Same launch shape as gcr.hip's multidot kernel (RED_THREADS-wide workgroups, one contiguous chunk of rows each,
+// per-thread accumulation in ascending row order, block_sum_bcast) and the same per-row arithmetic as the
+// SpMV kernels (spmv_dev.h): Ar AND the partial sums have the bits the separate kernels produce
+// (tests/test_gpu_parity.py::test_fused_apply_and_dots_same_bits).  Workgroups are renumbered so that
+// each XCD works on one contiguous band of rows (every workgroup owns one contiguous chunk, walked in
+// RED_THREADS-wide slices); partials are indexed by the logical number.  The
+// row's pattern id is fetched one trip ahead and the pattern table sits in LDS, so only the gathers are
+// a dependent HBM round trip.
+//
+// Tried and dropped (measured on MI355X, Poisson 128^3): also folding the residual update
+// r' = r - alpha Ap into this kernel (r' recomputed for the 7 gathered entries): 65 us against
+// 21.9 + 39.8 us — 14 gathers per row and 112-126 VGPRs; staging the workgroup's 1024 entries of r in
+// LDS to serve the +-1 / +-n neighbours: slower still (two barriers per trip); temporal instead of
+// non-temporal loads of the Aps_j so that build_* finds them in the Infinity Cache: no gain.
+#include "internal.h"
+#include "reduce.h"
+#include "spmv_dev.h"
+#include "gcr_dev.h"
+
+namespace mgcr {
+
+struct DotVecs {
+    const cplx *v[ND];
+};
+
+template <int MODE, int WT, int NDT>
+__global__ void __launch_bounds__(RED_THREADS) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                                 DotVecs d, int64_t n, int nlogical, int trips,
+                                                                 double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
+    __shared__ double lds[2 * NDT * 17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    // logical workgroup number: XCD x (physical b & 7) owns the band [x * per, (x + 1) * per)
+    const int per = (int)(gridDim.x >> 3);
+    const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (lb >= nlogical) return;
+    const int32_t W = WT ? WT : m.W;
+    // rows [lb * trips * RED_THREADS, (lb + 1) * trips * RED_THREADS), one slice per trip (= multidot_kernel's map)
+    int64_t i = (int64_t)lb * trips * RED_THREADS + threadIdx.x;
+    int32_t t0 = 0;
+    if (MODE != 0 && i < n) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    PatLds pl{nullptr, nullptr, nullptr};
+    if (MODE == 1) pl = stage_patterns(m, step_smem);
+    double v[2 * NDT];
+#pragma unroll
+    for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
+    for (int k = 0; k < trips && i < n; k++, i += RED_THREADS) {
+        int32_t t0_next = 0;
+        if (MODE != 0 && k + 1 < trips && i + RED_THREADS < n) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + RED_THREADS) * W;
+        cplx b[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) b[j] = ld_stream<true>(d.v[j] + i);
+        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return x[j]; });
+        const cplx yi = m.shift ? csub(x[i], cmul(m.k, sum)) : sum;
+        y[i] = yi;
+#pragma unroll
+        for (int j = 0; j < NDT; j++) {
+            cplx t = cconj_mul(yi, b[j]);
+            v[2 * j] += t.x;
+            v[2 * j + 1] += t.y;
+        }
+        t0 = t0_next;
+    }
+    block_sum_bcast<2 * NDT>(v, lds);
+    if (threadIdx.x < 2 * NDT) {
+        double mine = 0.;
+#pragma unroll
+        for (int j = 0; j < 2 * NDT; j++)
+            if (j == (int)threadIdx.x) mine = v[j];
+        parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    }
+}
+
+static int g_fuse = -1;
+static bool fuse_enabled() {
+    if (g_fuse < 0) g_fuse = !(getenv("MGCR_FUSE") && atoi(getenv("MGCR_FUSE")) == 0);
+    return g_fuse != 0;
+}
+bool set_fuse_enabled(bool on) {
+    bool prev = fuse_enabled();
+    g_fuse = on ? 1 : 0;
+    return prev;
+}
+bool csr_fusable(const CsrDev &A, const DistCsr *dist) {
+    if (A.pat_mode == 1 && (int64_t)A.npat * A.W * 20 > 48 * 1024) return false;  // pattern table must fit LDS
+    return fuse_enabled() && !dist && A.L == 1 && A.n_tail_rows == 0 && A.nrow == A.ncol && A.nrow >= 1 && A.W >= 1;
+}
+
+template <int MODE, int WT>
+static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *x, cplx *y, const DotVecs &d, int64_t n,
+                      int g, double *parts, SkipRef sk) {
+#define SK(NDT)                                                                                                          \
+    hipLaunchKernelGGL((step_apply_kernel<MODE, WT, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
+                       g, red_trips(n), parts, sk.p, sk.it)
+    switch (nd) {
+        case 1: SK(1); break;
+        case 2: SK(2); break;
+        case 3: SK(3); break;
+        case 4: SK(4); break;
+        case 5: SK(5); break;
+        case 6: SK(6); break;
+        case 7: SK(7); break;
+        default: SK(8); break;
+    }
+#undef SK
+}
+
+// y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= ND, laid out like gcr.hip's partsB
+int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts) {
+    MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
+    MGCR_CHECK(nd >= 1 && nd <= ND, MGCR_ERR_INVALID, "csr_step_apply: 1..8 vectors");
+    const RowMat m = row_mat(A, shift, k);
+    DotVecs d;
+    for (int j = 0; j < ND; j++) d.v[j] = vecs[j < nd ? j : 0];
+    const int g = red_grid(A.nrow);
+    const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);  // multiple of 8 => XCD bands
+    const size_t lds_bytes = row_mat_lds_bytes(A);
+    const SkipRef sk = get_apply_skip();
+#define ST_W(MODE)                                                                              \
+    do {                                                                                        \
+        if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk); \
+        else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk);          \
+    } while (0)
+    if (A.pat_mode == 1) ST_W(1);
+    else if (A.pat_mode == 2) ST_W(2);
+    else ST_W(0);
+#undef ST_W
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
+}  // namespace mgcr

@@ -123,6 +123,7 @@ struct Op {
 
 // ---- blas1.hip -------------------------------------------------------------------------------
 int red_grid(int64_t n);
+int red_trips(int64_t n);
 int k_copy(cplx *dst, const cplx *src, int64_t n);
 int k_zero(cplx *dst, int64_t n);
 int k_copy_apply(cplx *dst, const cplx *src, int64_t n);  // skip-aware (operator applies)
@@ -141,8 +142,12 @@ int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const 
 void csr_free(CsrDev *c);
 bool set_patterns_enabled(bool on);
 bool set_lean_enabled(bool on);
+bool set_fuse_enabled(bool on);
 // y = A x   or (shift) y = x - k*(A x); dist != nullptr: row block with halo exchange
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr);
+// SpMV fused with <y, v_j> partials (gcr_fused.hip); parts laid out like gcr.hip's partsB, red_grid(nrow) partials each
+bool csr_fusable(const CsrDev &A, const DistCsr *dist);
+int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
                       const double *h_blocks, BcsrDev *out);
 void bcsr_free(BcsrDev *b);
@@ -190,7 +195,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 void gcr_state_set_use_x0(GcrState *s, bool use_x0);
 int gcr_state_set_param(GcrState *s, const mgcr_gcr_param *p);
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);
-void gcr_last_profile(double *ms, int *n);
+void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused);
 
 // ---- gcr_small.hip ---------------------------------------------------------------------------
 void gcr_small_set_limit(int64_t rows);

@@ -14,6 +14,7 @@
 
 #include "internal.h"
 #include "reduce.h"
+#include "spmv_dev.h"
 
 namespace mgcr {
 
@@ -472,45 +473,6 @@ int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const 
 // ------------------------------------------------------------------------------------------------
 // SpMV
 // ------------------------------------------------------------------------------------------------
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give each XCD
-// one contiguous band of rows, so that the x entries a stencil-like matrix re-reads (row +-1,
-// +-n, +-n^2) stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
-__device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
-    int64_t b = blockIdx.x;
-    int64_t per = (ntiles + 7) >> 3;
-    return (b & 7) * per + (b >> 3);
-}
-
-// L = 1: one thread per row, entries in CSR order (bit-identical to the reference's row sum)
-// gather of x: columns >= n_own live in the halo segment xh (multi-GPU row blocks); n_own is
-// INT32_MAX and xh unused otherwise
-__device__ __forceinline__ cplx gather_x(const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own, int32_t j) {
-    return j < n_own ? x[j] : xh[j - n_own];
-}
-
-// one stored value times an x entry; REALV: the value is a real fp64
-// NT: the matrix stream is read exactly once per SpMV — load it non-temporally so that it does not
-// displace the vectors (x, and the solver's r / Ar / direction slots) from L2 and the Infinity Cache.
-template <bool REALV, bool NT = false>
-__device__ __forceinline__ cplx vmul(const void *__restrict__ val, int64_t idx, cplx xv) {
-    if (REALV) {
-        const double *p = reinterpret_cast<const double *>(val) + idx;
-        double v = NT ? __builtin_nontemporal_load(p) : *p;
-        return make_double2(v * xv.x, v * xv.y);
-    }
-    const cplx *p = reinterpret_cast<const cplx *>(val) + idx;
-    cplx v;
-    if (NT) {
-        v.x = __builtin_nontemporal_load(&p->x);
-        v.y = __builtin_nontemporal_load(&p->y);
-    } else {
-        v = *p;
-    }
-    return cmul(v, xv);
-}
-template <bool NT>
-__device__ __forceinline__ int32_t ldcol(const int32_t *__restrict__ p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-
 template <int WT, bool SHIFT, bool XCD, bool REALV, bool NT>
 __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int64_t row_count, int64_t npad, int32_t Wrt,
                                                           int64_t ntiles, const void *__restrict__ val,
@@ -586,6 +548,76 @@ __global__ void __launch_bounds__(256) pat_spmv_rowthread(int64_t row_begin, int
     y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
 }
 
+// Same, with the pattern table staged in LDS (one dependent memory round trip less per row: id -> LDS ->
+// gathers; 17.6 against 20.7 us at Poisson 128^3).  MODE 1 only.  R rows per thread with all id loads and
+// gathers in flight together was measured too (R = 2, 4; 256 / 512 threads): no faster than R = 1.
+template <int WT, bool SHIFT, bool REALV, int R, int BLK>
+__global__ void __launch_bounds__(BLK) pat_spmv_lds(int64_t row_begin, int64_t row_count, int32_t Wrt, int64_t ntiles, int xcd,
+                                                    int32_t npat, const uint16_t *__restrict__ pid,
+                                                    const int32_t *__restrict__ poff, const double *__restrict__ pre,
+                                                    const double *__restrict__ pim, const cplx *__restrict__ x,
+                                                    const cplx *__restrict__ xh, int32_t n_own, cplx *__restrict__ y, cplx k,
+                                                    const int *__restrict__ skip, int skip_it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pat_smem[];
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
+    const int64_t tile = xcd ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int32_t W = WT ? WT : Wrt;
+    const int32_t ne = npat * W;
+    double *sre = reinterpret_cast<double *>(pat_smem);
+    double *sim = sre + (REALV ? 0 : ne);
+    int32_t *soff = reinterpret_cast<int32_t *>(sim + ne);
+    int64_t row[R];
+    bool live[R];
+    int32_t t0[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int64_t rloc = tile * (BLK * R) + r * BLK + threadIdx.x;
+        live[r] = rloc < row_count;
+        row[r] = row_begin + (live[r] ? rloc : 0);
+        t0[r] = (int32_t)__builtin_nontemporal_load(pid + row[r]) * W;
+    }
+    for (int32_t e = threadIdx.x; e < ne; e += BLK) {
+        soff[e] = poff[e];
+        sre[e] = pre[e];
+        if (!REALV) sim[e] = pim[e];
+    }
+    __syncthreads();
+    if (WT) {
+        cplx xv[R][WT ? WT : 1];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int32_t c = 0; c < W; c++) xv[r][c] = gather_x(x, xh, n_own, (int32_t)row[r] + soff[t0[r] + c]);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cplx sum = make_double2(0., 0.);
+#pragma unroll
+            for (int32_t c = 0; c < W; c++) {
+                cplx t;
+                if (REALV) { double v = sre[t0[r] + c]; t = make_double2(v * xv[r][c].x, v * xv[r][c].y); }
+                else t = cmul(make_double2(sre[t0[r] + c], sim[t0[r] + c]), xv[r][c]);
+                sum = cadd(sum, t);
+            }
+            if (live[r]) y[row[r]] = SHIFT ? csub(x[row[r]], cmul(k, sum)) : sum;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cplx sum = make_double2(0., 0.);
+#pragma unroll 4
+            for (int32_t c = 0; c < W; c++) {
+                cplx xv = gather_x(x, xh, n_own, (int32_t)row[r] + soff[t0[r] + c]);
+                cplx t;
+                if (REALV) { double v = sre[t0[r] + c]; t = make_double2(v * xv.x, v * xv.y); }
+                else t = cmul(make_double2(sre[t0[r] + c], sim[t0[r] + c]), xv);
+                sum = cadd(sum, t);
+            }
+            if (live[r]) y[row[r]] = SHIFT ? csub(x[row[r]], cmul(k, sum)) : sum;
+        }
+    }
+}
+
 // L in {2,4,8,16}: L consecutive lanes share a row; per chunk the (row, lane) pairs are contiguous
 template <int L, bool SHIFT, bool REALV>
 __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t row_count, int64_t npad, int32_t nchunk,
@@ -646,6 +678,22 @@ template <bool SHIFT>
 static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const cplx *x, const cplx *xh, int32_t n_own, cplx *y, cplx k) {
     Context &c = ctx();
     if (row_count <= 0) return MGCR_OK;
+    if (A.pat_mode == 1 && (int64_t)A.npat * A.W * 20 <= 48 * 1024) {  // pattern table fits LDS
+        const int64_t ntiles = (row_count + 255) / 256;
+        const bool xcd = ntiles >= 64;
+        const unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
+        const size_t lds = (size_t)A.npat * A.W * (A.pat_real ? 12 : 20);
+#define PL(WT, RV)                                                                                                            \
+    hipLaunchKernelGGL((pat_spmv_lds<WT, SHIFT, RV, 1, 256>), dim3(grid), dim3(256), lds, c.stream, row_begin, row_count, A.W, \
+                       ntiles, xcd ? 1 : 0, A.npat, (const uint16_t *)A.pat_id, (const int32_t *)A.pat_off,                   \
+                       (const double *)A.pat_re, (const double *)A.pat_im, x, xh, n_own, y, k, g_skip.p, g_skip.it)
+#define PL_V(WT) do { if (A.pat_real) PL(WT, true); else PL(WT, false); } while (0)
+        if (A.W == 7) PL_V(7); else PL_V(0);
+#undef PL_V
+#undef PL
+        MGCR_HIP(hipGetLastError());
+        return MGCR_OK;
+    }
     if (A.pat_mode) {
         int64_t ntiles = (row_count + 255) / 256;
         bool xcd = ntiles >= 64;

@@ -417,6 +417,44 @@ def test_lean_restart_cycles_match_classic(kind, restart, tol, sample, sample_or
     assert t1 <= max(2.0 * t0, 1.05 * tol)
 
 
+@pytest.mark.parametrize("fmt", ["pattern", "slab", "dirac-pattern", "slab-generic-width"])
+@pytest.mark.parametrize("mode", [dict(restart=5), dict(truncation=3), dict()])
+def test_fused_apply_and_dots_same_bits(fmt, mode):
+    """SpMV + beta dot products as one kernel (spmv.hip: spmv_multidot_kernel) against the two separate
+    kernels: same y, same partial sums, hence the same residual history and the same x, bit for bit —
+    for every storage format, with the DiracOp epilogue, in restart / truncated / full mode."""
+    n1 = 40 if "pattern" in fmt else 20
+    n, ncol, rowptr, col, val = problems.poisson3d_csr(n1)
+    val = val * (1.0 - 0.25j)
+    if fmt == "slab-generic-width":   # rows of up to 5 entries: the run-time-width code path
+        keep = np.ones(val.size, bool)
+        keep[rowptr[:-1]] = np.diff(rowptr) < 6
+        keep[rowptr[1:] - 1] = np.diff(rowptr) < 7
+        newptr = np.concatenate([[0], np.cumsum(np.add.reduceat(keep, rowptr[:-1]))]).astype(np.int64)
+        rowptr, col, val = newptr, col[keep], val[keep]
+        val[rowptr[:-1] + (np.diff(rowptr) // 2)] += 7.0  # keep it diagonally dominant enough to converge
+    prev = mg.set_option("pattern_storage", 1 if "pattern" in fmt else 0)
+    try:
+        A = Sparse(n, ncol, rowptr, col, val)
+    finally:
+        mg.set_option("pattern_storage", prev)
+    assert (A.storage_format()[0] != 0) == ("pattern" in fmt)
+    op = DiracOp(A, 0.05 + 0.02j) if fmt.startswith("dirac") else A
+    b = Field((n,), problems.rhs_grid(n, 8))
+    out = []
+    for on in (1, 0):
+        prev = mg.set_option("fused_apply", on)
+        try:
+            g = GCR(op, GCR_Param(mode.get("truncation", 0), mode.get("restart", 0), 40, 1e-11, False))
+            x = Field((n,)).set_zero()
+            g.solve(b, x)
+        finally:
+            mg.set_option("fused_apply", prev)
+        out.append((g.last_history.copy(), x.to_numpy()))
+    assert out[0][0].size > 5
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_gcr_vs_oracle_random_nonhermitian():
     """Seeded diagonally dominant complex matrix, every mode, against the CPU oracle."""
     rng = np.random.default_rng(42)
