@@ -665,6 +665,9 @@ static int gcr_prepare(GcrState *s, int64_t n) {
     int storage = p.max_iter, restart;
     if (p.truncation != 0) storage = p.truncation;
     if (p.restart != 0) { restart = p.restart; storage = restart; } else restart = p.max_iter;
+    // a restart cycle longer than the whole solve never closes: iteration k writes slot k <= max_iter,
+    // so max_iter + 1 slots behave exactly like `restart` slots (smoothers: 2 sweeps of GCR(10))
+    if (p.restart != 0 && p.max_iter >= 1 && p.max_iter + 1 < storage) storage = p.max_iter + 1;
     if (storage < 1) storage = 1;
     if (restart < 1) restart = 1;
     bool precond = p.left_precond || p.right_precond;
