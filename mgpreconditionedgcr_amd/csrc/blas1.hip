@@ -13,13 +13,6 @@ int red_grid(int64_t n) {
     return (int)g;
 }
 
-// slices of RED_THREADS rows each workgroup of a red_grid(n) launch walks when rows are dealt in
-// contiguous chunks per workgroup (multidot / step_apply kernels)
-int red_trips(int64_t n) {
-    const int64_t per = (int64_t)red_grid(n) * RED_THREADS;
-    return (int)((n + per - 1) / per);
-}
-
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 

@@ -230,24 +230,26 @@ __global__ void advance_kernel(DevState *st, int by) { st->base += by; }
 // with no branch between them: the kernel is latency-bound otherwise (a wave with a single 1-KiB
 // load in flight cannot cover HBM latency, even at 32 waves per CU).
 template <int NDT, int U>
-__global__ void __launch_bounds__(RED_THREADS) multidot_kernel(const DevState *__restrict__ st, int it, const cplx *__restrict__ ar,
-                                                               DirPtrs d, int base, int64_t n, int trips,
+__global__ void __launch_bounds__(RED_THREADS, (NDT <= 6 ? 8 : 4)) multidot_kernel(const DevState *__restrict__ st, int it, const cplx *__restrict__ ar,
+                                                               DirPtrs d, int base, int64_t n,
                                                                double *__restrict__ partsB) {
     __shared__ double lds[2 * NDT * 17];
     if (st->stop_at < st->base + it) return;
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
-    // workgroup b owns the contiguous rows [b * trips * RED_THREADS, (b + 1) * trips * RED_THREADS), one
-    // RED_THREADS-wide slice per trip: the row -> (workgroup, thread, trip) map of gcr_fused.hip's
-    // step_apply_kernel, so that either kernel yields the same partial sums
-    const int64_t first = (int64_t)blockIdx.x * trips * RED_THREADS + threadIdx.x;
-    for (int k0 = 0; k0 < trips; k0 += U) {
+    // grid-stride: trip k of workgroup b covers rows (k * gridDim.x + b) * RED_THREADS ..., so at any moment
+    // the whole machine sweeps one contiguous window of every stream (a contiguous chunk per workgroup was
+    // measured 9 % slower at 128^3: 512 workgroups then walk 512 separate 16-KiB-wide fronts).  The row ->
+    // (workgroup, thread, trip) map is shared with gcr_fused.hip's step_apply_kernel, so that either
+    // kernel yields the same partial sums.
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
         cplx a[U], b[U][NDT];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t i = first + (int64_t)(k0 + u) * RED_THREADS;
-            if (k0 + u < trips && i < n) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
                 a[u] = ar[i];
 #pragma unroll
                 for (int j = 0; j < NDT; j++) b[u][j] = ld_stream<NTS>(d.aps[j] + i);
@@ -397,8 +399,10 @@ __device__ __forceinline__ void close_step(DevState *st, int it, double rr, doub
 // its image is formed:  Ap_k = Ar - sum_{j<k} beta_j Ap_j  (same order as build_kernel), with the
 // <r,Ap_k>, <Ap_k,Ap_k> partials; workgroup 0 extends the coefficient table by row k:
 //   p_k = D_k - sum_j beta_j p_j   =>   t_k = -sum_j beta_j t_j ,  T_km = -sum_{j>=m} beta_j T_jm ,  T_kk = 1.
+// (second launch bound: up to NDT = 5 the kernel fits 64 VGPRs, i.e. two 1024-thread workgroups per CU; left
+// alone the compiler takes 84 for NDT = 4 and halves the residency: 48.4 us against 42 us at 128^3)
 template <int NDT>
-__global__ void __launch_bounds__(RED_THREADS) build_lean_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
+__global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
                                                                  int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
                                                                  int strideR, double *__restrict__ hist, int hist_cap,
                                                                  const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ r,
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(RED_THREADS) build_lean_kernel(DevState *__res
 //   Ap_0' = Ar - sum_j beta_j Ap_j                           with cp_m = sum_{j>=m} beta_j T_jm, cp_0 = sum_j beta_j t_j
 // written in place over slot 0, plus the <r,Ap'>, <Ap',Ap'> partials and the step's bookkeeping.
 template <int NDT, bool RDIR>
-__global__ void __launch_bounds__(RED_THREADS) build_close_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
+__global__ void __launch_bounds__(RED_THREADS, (NDT <= 2 ? 8 : 4)) build_close_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
                                                                   int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
                                                                   int strideR, double *__restrict__ hist, int hist_cap,
                                                                   const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ dir,
@@ -721,8 +725,7 @@ struct SkipGuard {
 };
 
 static int launch_multidot(int g, int nd, const DevState *st, int it, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB) {
-    const int trips = red_trips(n);
-#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, trips, partsB)
+#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, partsB)
     switch (nd) {
         case 1: MD(1, 2); break;
         case 2: MD(2, 2); break;

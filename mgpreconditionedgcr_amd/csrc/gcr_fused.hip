@@ -3,12 +3,11 @@
 // not read back from HBM and the SpMV's dependent id -> table -> gather chain overlaps with the Aps_j
 // streams (Poisson 128^3: 39.8 us against 21.9 + 22.6 us for the two kernels).
 //
-// Same launch shape as gcr.hip's multidot kernel (RED_THREADS-wide workgroups, one contiguous chunk of rows each,
+// Same launch shape as gcr.hip's multidot kernel (grid-stride over RED_THREADS-wide workgroups,
 // per-thread accumulation in ascending row order, block_sum_bcast) and the same per-row arithmetic as the
 // SpMV kernels (spmv_dev.h): Ar AND the partial sums have the bits the separate kernels produce
 // (tests/test_gpu_parity.py::test_fused_apply_and_dots_same_bits).  Workgroups are renumbered so that
-// each XCD works on one contiguous band of rows (every workgroup owns one contiguous chunk, walked in
-// RED_THREADS-wide slices); partials are indexed by the logical number.  The
+// each XCD works on one contiguous band of rows per trip; partials are indexed by the logical number.  The
 // row's pattern id is fetched one trip ahead and the pattern table sits in LDS, so only the gathers are
 // a dependent HBM round trip.
 //
@@ -16,7 +15,9 @@
 // r' = r - alpha Ap into this kernel (r' recomputed for the 7 gathered entries): 65 us against
 // 21.9 + 39.8 us — 14 gathers per row and 112-126 VGPRs; staging the workgroup's 1024 entries of r in
 // LDS to serve the +-1 / +-n neighbours: slower still (two barriers per trip); temporal instead of
-// non-temporal loads of the Aps_j so that build_* finds them in the Infinity Cache: no gain.
+// non-temporal loads of the Aps_j so that build_* finds them in the Infinity Cache: no gain; one contiguous
+// chunk of rows per workgroup instead of grid-stride (x then crosses XCD bands less: 123 instead of 134 MB
+// of HBM traffic per launch by PMC): 9 % slower — 512 separate 16-KiB-wide fronts instead of one sweep.
 #include "internal.h"
 #include "reduce.h"
 #include "spmv_dev.h"
@@ -30,8 +31,8 @@ struct DotVecs {
 
 template <int MODE, int WT, int NDT>
 __global__ void __launch_bounds__(RED_THREADS) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
-                                                                 DotVecs d, int64_t n, int nlogical, int trips,
-                                                                 double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
+                                                                 DotVecs d, int64_t n, int nlogical, double *__restrict__ parts,
+                                                                 const int *__restrict__ skip, int skip_it) {
     __shared__ double lds[2 * NDT * 17];
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     if (skip && skip[0] < skip[1] + skip_it) return;
@@ -40,8 +41,9 @@ __global__ void __launch_bounds__(RED_THREADS) step_apply_kernel(RowMat m, const
     const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (lb >= nlogical) return;
     const int32_t W = WT ? WT : m.W;
-    // rows [lb * trips * RED_THREADS, (lb + 1) * trips * RED_THREADS), one slice per trip (= multidot_kernel's map)
-    int64_t i = (int64_t)lb * trips * RED_THREADS + threadIdx.x;
+    // grid-stride over logical workgroups (= multidot_kernel's row -> (workgroup, thread, trip) map)
+    const int64_t stride = (int64_t)nlogical * RED_THREADS;
+    int64_t i = (int64_t)lb * RED_THREADS + threadIdx.x;
     int32_t t0 = 0;
     if (MODE != 0 && i < n) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
     PatLds pl{nullptr, nullptr, nullptr};
@@ -49,9 +51,9 @@ __global__ void __launch_bounds__(RED_THREADS) step_apply_kernel(RowMat m, const
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
-    for (int k = 0; k < trips && i < n; k++, i += RED_THREADS) {
+    for (; i < n; i += stride) {
         int32_t t0_next = 0;
-        if (MODE != 0 && k + 1 < trips && i + RED_THREADS < n) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + RED_THREADS) * W;
+        if (MODE != 0 && i + stride < n) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
         cplx b[NDT];
 #pragma unroll
         for (int j = 0; j < NDT; j++) b[j] = ld_stream<true>(d.v[j] + i);
@@ -96,7 +98,7 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
                       int g, double *parts, SkipRef sk) {
 #define SK(NDT)                                                                                                          \
     hipLaunchKernelGGL((step_apply_kernel<MODE, WT, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
-                       g, red_trips(n), parts, sk.p, sk.it)
+                       g, parts, sk.p, sk.it)
     switch (nd) {
         case 1: SK(1); break;
         case 2: SK(2); break;

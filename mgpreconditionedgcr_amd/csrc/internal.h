@@ -123,7 +123,6 @@ struct Op {
 
 // ---- blas1.hip -------------------------------------------------------------------------------
 int red_grid(int64_t n);
-int red_trips(int64_t n);
 int k_copy(cplx *dst, const cplx *src, int64_t n);
 int k_zero(cplx *dst, int64_t n);
 int k_copy_apply(cplx *dst, const cplx *src, int64_t n);  // skip-aware (operator applies)

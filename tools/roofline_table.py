@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel achieved-HBM-rate table from a rocprofv3 --kernel-trace --stats CSV of `bench.py`
-(Poisson n^3, restart 5).  Bytes are the models of DESIGN.md section 3 for the stored layout.
+(Poisson n^3, restart 5).  Bytes are the models of DESIGN.md section 3 for the stored layout
+(row-pattern dictionary, lean restart cycles, fused SpMV + dots).
 
     python tools/roofline_table.py profiles/r01_bench_kernel_stats_v3.csv [n]
 """
@@ -14,7 +15,9 @@ N = n ** 3
 nnz = 7 * N - 6 * n * n
 V = 16 * N
 slab = 7 * ((N + 63) // 64 * 64)
-B_spmv = slab * 12 + 2 * V          # real-valued slab (8 B) + int32 column + x + y
+B_pat = 2 * ((N + 63) // 64 * 64) + 27 * 7 * 12    # row-pattern dictionary: 2 B per row + the table
+B_spmv = B_pat + 2 * V
+R = 5
 rows = list(csv.DictReader(open(path)))
 print("| kernel | calls | avg µs | bytes / launch (model) | GB/s | of 8 TB/s |")
 print("|---|---|---|---|---|---|")
@@ -25,15 +28,24 @@ for r in rows:
     m = re.match(r"multidot_kernel<(\d+)", name)
     if m:
         b = (1 + int(m.group(1))) * V
+    m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
+    if m:
+        b = B_spmv + int(m.group(1)) * V            # SpMV + lim direction streams, Ar written once
+    m = re.match(r"build_lean_kernel<(\d+)>", name)
+    if m:
+        b = (3 + int(m.group(1))) * V               # r, Ar, lim Aps read; Ap written
+    m = re.match(r"build_close_kernel<(\d+)", name)
+    if m:
+        b = (2 * int(m.group(1)) + 6) * V           # R ps + R Aps + dir + Ar + x read; p, Ap, x written
     m = re.match(r"build_kernel<(\d+), true, true, (true|false), (true|false)>", name)
     if m:
         lim = int(m.group(1))
-        b = (4 + 2 * lim) * V + (2 * V if m.group(3) == "true" else 0)   # + x read/write on the cycle-closing step
-    if name.startswith("xr_update_kernel<true>"):
+        b = (4 + 2 * lim) * V + (2 * V if m.group(3) == "true" else 0)
+    if name.startswith("xr_update_kernel<true"):
         b = 3 * V
-    if name.startswith("xr_update_kernel<false>"):
+    if name.startswith("xr_update_kernel<false"):
         b = 6 * V
-    if name.startswith("ell_spmv_rowthread"):
+    if name.startswith(("ell_spmv_rowthread", "pat_spmv")):
         b = B_spmv
     if name.startswith("copy_kernel"):
         b = 2 * V
