@@ -230,7 +230,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": b_phase[dom],
                      "us_per_launch": ph_us[dom],
                      "note": "dominant phase of the iteration by time; achieved = bytes of the stored layout the phase's "
-                             "kernel has to move per launch (average over a restart cycle) / its hipEvent-timed duration"},
+                             "kernel has to move per launch (average over a restart cycle) / its hipEvent-timed duration"
+                             + ("" if world == 1 else "; N > 1: the phase times include the halo exchange (apply_dots) and both "
+                                                      "all-reduces of the iteration (build)")},
         "final_rel_residual": float(hist[-1]),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

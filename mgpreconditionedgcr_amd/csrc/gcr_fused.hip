@@ -1,7 +1,7 @@
 // GCR step kernel that embeds the operator apply (single-GPU Sparse / DiracOp, one thread per row):
 // Ar = A r  and the partial sums of <Ar, Aps_j> (conj on Ar, src/GCR.h:258), j < NDT, in ONE pass — Ar is
 // not read back from HBM and the SpMV's dependent id -> table -> gather chain overlaps with the Aps_j
-// streams (Poisson 128^3: 39.8 us against 21.9 + 22.6 us for the two kernels).
+// streams (Poisson 128^3: 36.8 us against 21.9 + 22.6 us for the two kernels).
 //
 // Same launch shape as gcr.hip's multidot kernel (grid-stride over RED_THREADS-wide workgroups,
 // per-thread accumulation in ascending row order, block_sum_bcast) and the same per-row arithmetic as the
@@ -30,7 +30,7 @@ struct DotVecs {
 };
 
 template <int MODE, int WT, int NDT>
-__global__ void __launch_bounds__(RED_THREADS) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+__global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                  DotVecs d, int64_t n, int nlogical, double *__restrict__ parts,
                                                                  const int *__restrict__ skip, int skip_it) {
     __shared__ double lds[2 * NDT * 17];
@@ -54,12 +54,16 @@ __global__ void __launch_bounds__(RED_THREADS) step_apply_kernel(RowMat m, const
     for (; i < n; i += stride) {
         int32_t t0_next = 0;
         if (MODE != 0 && i + stride < n) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
-        cplx b[NDT];
-#pragma unroll
-        for (int j = 0; j < NDT; j++) b[j] = ld_stream<true>(d.v[j] + i);
         const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return x[j]; });
         const cplx yi = m.shift ? csub(x[i], cmul(m.k, sum)) : sum;
         y[i] = yi;
+        // the direction streams are loaded only now (the scheduler must not hoist them): the gathers and
+        // these loads then never hold registers at the same time, the kernel fits 64 VGPRs up to NDT = 5
+        // and two 1024-thread workgroups share a CU — 36.8 against 39.8 us at 128^3
+        __builtin_amdgcn_sched_barrier(0);
+        cplx b[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) b[j] = ld_stream<true>(d.v[j] + i);
 #pragma unroll
         for (int j = 0; j < NDT; j++) {
             cplx t = cconj_mul(yi, b[j]);
