@@ -168,7 +168,7 @@ def main():
     y = Field(dims)
     spmv_ms_replay = A.bench_apply(rhs, y, reps=args.spmv_reps)
     stored = A.stored_bytes()
-    fmt, npat = A.storage_format() if world == 1 else (None, None)
+    fmt, npat = A.storage_format()
     V = 16 * N
     R = args.restart
     # Bytes each phase has to move per launch with the layout actually stored ("if the
@@ -209,7 +209,7 @@ def main():
         "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, complex fp64, x0=0, "
                                "RHS splitmix64 seed 0" % (n, args.restart),
                    "rows": N, "nnz": nnz, "complex": True,
-                   "matrix_storage": {None: "row block of a distributed Sparse", 0: "ELL slab",
+                   "matrix_storage": {0: "ELL slab",
                                       1: "row-pattern dictionary, %s patterns (2 B per row + table)" % npat,
                                       2: "row-pattern dictionary for the columns (%s patterns) + value slab" % npat}[fmt],
                    "stored_matrix_bytes": stored["matrix_bytes"], "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],

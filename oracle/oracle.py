@@ -228,6 +228,21 @@ def gcr_reorder_sensitivity(A, param, rhs, x0=None):
     return ref, dev, (min(its), max(its))
 
 
+def gcr_x_sensitivity(A, param, rhs, x0=None):
+    """Same question for the solution: max over the summation orders of max_i |x_order[i] - x_ref[i]|
+    after the same number of steps (solves that stop at different steps are not comparable: inf)."""
+    x_ref, _, it0, _ = gcr_solve(A, param, rhs, x0)
+    dev = 0.0
+    try:
+        for mode in (1, 2):
+            lib().orc_set_sum_order(mode)
+            x, _, it, _ = gcr_solve(A, param, rhs, x0)
+            dev = np.inf if it != it0 else max(dev, float(np.abs(x - x_ref).max()))
+    finally:
+        lib().orc_set_sum_order(0)
+    return x_ref, dev
+
+
 def gcr_op(A, param, x0_mode=1):
     """GCR used as an Operator (preconditioner / smoother), src/GCR.h:62-68."""
     return Op(lib().orc_op_gcr(A.h if A is not None else None, C.byref(param), x0_mode), keep=(A, param))

@@ -24,8 +24,10 @@ def split_rows(n, world):
 
 def problem(kind):
     from mgpreconditionedgcr_amd import problems
-    if kind == "poisson":
-        n = 6
+    if kind in ("poisson", "poisson48"):
+        # 48^3: every rank's row block has >= 2^15 rows, i.e. is stored as a row-pattern dictionary
+        # (halo columns included: nloc + slot - row is constant along a boundary plane)
+        n = 6 if kind == "poisson" else 48
         N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
         return N, rowptr, col, val, (n * n)  # rows per plane: slabs must hold whole planes
     rng = np.random.default_rng(7)
@@ -81,7 +83,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    for kind in ("poisson", "random"):
+    for kind in ("poisson", "random") + (("poisson48",) if mode == "gcr" else ()):
         N, rowptr, col, val, gran = problem(kind)
         offs = split_rows(N // gran, world)
         r0, r1 = offs[rank] * gran, offs[rank + 1] * gran
@@ -131,7 +133,7 @@ def main():
             xt = Field((r1 - r0,)).set_zero()
             g2.solve(b, xt)
             results[kind] = dict(y=y, r0=r0, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations,
-                                 hist_trunc=g2.last_history, x_trunc=xt.to_numpy())
+                                 hist_trunc=g2.last_history, x_trunc=xt.to_numpy(), format=A.storage_format()[0])
     np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()

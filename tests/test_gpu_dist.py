@@ -24,9 +24,10 @@ from oracle import oracle as orc  # noqa: E402  (checker only)
 def test_distributed_gcr_matches_single_process(tmp_path, world):
     mg.init()
     res = run_workers("gcr", world, tmp_path, timeout=500)
-    for kind in ("poisson", "random"):
+    for kind in ("poisson", "random", "poisson48"):
         N, rowptr, col, val, gran = problem(kind)
         A = Sparse(N, N, rowptr, col, val)
+        assert res[0][kind]["format"] == (1 if kind == "poisson48" else 0)
         x = problems.rhs_grid(N, 5)
         y = A(Field((N,), x)).to_numpy()
         got = np.concatenate([res[r][kind]["y"] for r in range(world)])
@@ -37,6 +38,7 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
                               ("_trunc", GCR_Param(11, 0, 25, 1e-30, False), dict(truncation=11, max_iter=25, tol=1e-30))):
             # how far the reference algorithm itself moves under re-association of its dot products
             _, sens, _ = orc.gcr_reorder_sensitivity(Ao, orc.gcr_param(**okw), problems.rhs_grid(N, 1))
+            _, xsens = orc.gcr_x_sensitivity(Ao, orc.gcr_param(**okw), problems.rhs_grid(N, 1))
             xs = Field((N,)).set_zero()
             gcr = GCR(A, prm)
             gcr.solve(b, xs)
@@ -48,7 +50,9 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
                 assert (np.abs(h - gcr.last_history)[1:] <= tol[1:]).all(), (kind, tag, r)
                 assert np.array_equal(h, res[0][kind]["hist" + tag])  # every rank sees identical scalars
             xd = np.concatenate([res[r][kind]["x" + tag] for r in range(world)])
-            assert np.abs(xd - xs.to_numpy()).max() <= max(1e-7, 50 * sens[-1] / gcr.last_history[-1]) * np.abs(xs.to_numpy()).max()
+            # x after the same number of steps: within what the reference algorithm's own x moves when its
+            # dot products are summed in another order (unconverged solves amplify that: poisson48)
+            assert np.abs(xd - xs.to_numpy()).max() <= max(1e-7 * np.abs(xs.to_numpy()).max(), 20 * xsens)
 
 
 def test_rccl_single_rank_collectives(tmp_path):
