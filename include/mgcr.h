@@ -107,7 +107,7 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  *                      created while it is on;
  *   "lean_cycles"     ($MGCR_LEAN): restart-mode GCR keeps residuals instead of search directions inside
  *                      a restart cycle (same r, Ap and scalars; x differs by rounding);
- *   "fused_apply"     ($MGCR_FUSE): GCR on a single-GPU Sparse / DiracOp runs the SpMV and the beta dot
+ *   "fused_apply"     ($MGCR_FUSE): GCR on a Sparse / DiracOp runs the SpMV and the beta dot
  *                      products of its result as one kernel (same bits as the two kernels).
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);

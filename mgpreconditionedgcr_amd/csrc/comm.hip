@@ -300,6 +300,8 @@ static bool halo_overlap() {
     static const bool on = getenv("MGCR_HALO_OVERLAP") && atoi(getenv("MGCR_HALO_OVERLAP")) != 0;
     return on;
 }
+bool dist_halo_overlaps() { return halo_overlap(); }
+
 
 __global__ void __launch_bounds__(256) pack_kernel(int64_t n, const int32_t *__restrict__ idx, const cplx *__restrict__ x,
                                                    cplx *__restrict__ out, const int *__restrict__ skip, int skip_it) {

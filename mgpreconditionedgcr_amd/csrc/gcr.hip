@@ -954,9 +954,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
     const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
     const cplx *rcur = s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
-    // operator apply fused with the beta dot products: single-GPU Sparse / DiracOp in a one-thread-per-row layout
+    // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
     bool fuse_ok = false;
-    if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !multi && !p.left_precond) {
+    if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !p.left_precond) {
         const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
         fuse_ok = b0->kind == OP_CSR && csr_fusable(b0->csr, b0->dist) && b0->csr.nrow == n;
     }
@@ -1022,7 +1022,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             const cplx *vecs[ND];
             for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < lim ? j : 0];
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
-            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->partsB));
+            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->partsB, b0->dist));
         } else {
         MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
         if (p.left_precond) {                         // src/GCR.h:245-247

@@ -1,4 +1,5 @@
-// GCR step kernel that embeds the operator apply (single-GPU Sparse / DiracOp, one thread per row):
+// GCR step kernel that embeds the operator apply (Sparse / DiracOp stored one thread per row; single GPU, or
+// the row block of a distributed matrix once its halo has arrived):
 // Ar = A r  and the partial sums of <Ar, Aps_j> (conj on Ar, src/GCR.h:258), j < NDT, in ONE pass — Ar is
 // not read back from HBM and the SpMV's dependent id -> table -> gather chain overlaps with the Aps_j
 // streams (Poisson 128^3: 36.8 us against 21.9 + 22.6 us for the two kernels).
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
     for (; i < n; i += stride) {
         int32_t t0_next = 0;
         if (MODE != 0 && i + stride < n) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
-        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return x[j]; });
+        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
         const cplx yi = m.shift ? csub(x[i], cmul(m.k, sum)) : sum;
         y[i] = yi;
         // the direction streams are loaded only now (the scheduler must not hoist them): the gathers and
@@ -94,7 +95,10 @@ bool set_fuse_enabled(bool on) {
 }
 bool csr_fusable(const CsrDev &A, const DistCsr *dist) {
     if (A.pat_mode == 1 && (int64_t)A.npat * A.W * 20 > 48 * 1024) return false;  // pattern table must fit LDS
-    return fuse_enabled() && !dist && A.L == 1 && A.n_tail_rows == 0 && A.nrow == A.ncol && A.nrow >= 1 && A.W >= 1;
+    // a row block of a distributed matrix qualifies when its halo exchange is ordered on the compute stream
+    // (the default): the one kernel then simply runs after it
+    if (dist ? dist_halo_overlaps() : A.nrow != A.ncol) return false;
+    return fuse_enabled() && A.L == 1 && A.n_tail_rows == 0 && A.nrow >= 1 && A.W >= 1;
 }
 
 template <int MODE, int WT>
@@ -116,11 +120,20 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
 #undef SK
 }
 
-// y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= ND, laid out like gcr.hip's partsB
-int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts) {
+// y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= ND, laid out like gcr.hip's partsB;
+// dist: A is this rank's row block, the halo exchange of x is enqueued first
+int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
+                   DistCsr *dist) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
     MGCR_CHECK(nd >= 1 && nd <= ND, MGCR_ERR_INVALID, "csr_step_apply: 1..8 vectors");
-    const RowMat m = row_mat(A, shift, k);
+    RowMat m = row_mat(A, shift, k);
+    if (dist) {
+        int64_t ib = 0, ie = 0;
+        dist_info(dist, &m.xh, &ib, &ie);
+        m.n_own = (int32_t)A.nrow;
+        MGCR_TRY(dist_halo_begin(dist, x));
+        MGCR_TRY(dist_halo_end(dist));
+    }
     DotVecs d;
     for (int j = 0; j < ND; j++) d.v[j] = vecs[j < nd ? j : 0];
     const int g = red_grid(A.nrow);

@@ -146,7 +146,8 @@ bool set_fuse_enabled(bool on);
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr);
 // SpMV fused with <y, v_j> partials (gcr_fused.hip); parts laid out like gcr.hip's partsB, red_grid(nrow) partials each
 bool csr_fusable(const CsrDev &A, const DistCsr *dist);
-int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts);
+int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
+                   DistCsr *dist);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
                       const double *h_blocks, BcsrDev *out);
 void bcsr_free(BcsrDev *b);
@@ -165,6 +166,7 @@ SkipRef get_apply_skip();
 // ---- comm.hip --------------------------------------------------------------------------------
 int dist_halo_begin(DistCsr *d, const cplx *x);
 int dist_halo_end(DistCsr *d);
+bool dist_halo_overlaps();  // MGCR_HALO_OVERLAP: exchange on the communication stream, overlapped with interior rows
 void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *interior_end);
 void dist_free(DistCsr *d);
 Comm *dist_comm(DistCsr *d);

@@ -1,6 +1,8 @@
 // Device-side pieces of the Sparse SpMV shared by spmv.hip (the operator apply) and gcr_fused.hip
 // (the GCR step kernels that apply the operator and take the step's dot products in one pass).
 #pragma once
+#include <climits>
+
 #include "internal.h"
 #include "reduce.h"
 
@@ -61,6 +63,8 @@ struct RowMat {
     const double *pre, *pim;  // MODE 1
     int shift;
     cplx k;
+    const cplx *xh;        // halo segment of x (row block of a distributed matrix), columns >= n_own
+    int32_t n_own;
 };
 
 inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
@@ -70,6 +74,7 @@ inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
     m.realv = A.pat_mode == 1 ? (A.pat_real ? 1 : 0) : (A.ell_val_re ? 1 : 0);
     m.pid = A.pat_id; m.poff = A.pat_off; m.pre = A.pat_re; m.pim = A.pat_im;
     m.shift = shift ? 1 : 0; m.k = k;
+    m.xh = nullptr; m.n_own = INT32_MAX;
     return m;
 }
 inline size_t row_mat_lds_bytes(const CsrDev &A) { return A.pat_mode == 1 ? (size_t)A.npat * A.W * (A.pat_real ? 12 : 20) : 0; }
