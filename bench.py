@@ -15,7 +15,8 @@ planes (= the N=1 problem) per GPU — weak scaling; value = N * iterations/s (s
 
 One JSON line on stdout (rank 0), with `roofline` (the phase of the iteration that takes longest,
 hipEvent-timed on the library's own stream inside a solve) and `cpu_baseline` (the real reference, oracle/_ref/ref_harness, on this box's host
-cores; falls back to the oracle port when that binary is absent).
+cores; falls back to the oracle port when that binary is absent) plus `cpu_baseline_optimised` (an OpenMP,
+fused-pass CPU port on all host cores).
 """
 import argparse
 import json
@@ -63,6 +64,39 @@ def cpu_baseline(n, iters=10):
     return {"value": iters / dt, "unit": "it/s", "cores": 1, "kind": "port",
             "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by oracle/mgcr_oracle.c, 1 thread"
                       % (iters, n), "host_cores": ncores}
+
+
+def cpu_baseline_optimised(n, restart, seconds=8.0):
+    """SURVEY.md §8(d) "optimised CPU" row: the OpenMP port with fused passes (oracle/mgcr_cpu_opt.c) on all
+    of this box's host cores, bounded to about `seconds` of work."""
+    from oracle import oracle as orc
+    ncores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = ncores
+    # The visible core count is not the usable one: a 1-GPU box exposes 256 cores and its cgroup grants 16
+    # (cpu.max "1600000 100000"); more threads than that are throttled, not run.
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                usable = max(1, min(usable, int(q / per + 0.5)))
+        except Exception:
+            pass
+    dt, _ = orc.opt_gcr_poisson(n, restart, 5, usable)          # page-in + a first rate estimate
+    iters = int(max(10, min(500, seconds / max(dt / 5, 1e-6))))
+    dt, hist = orc.opt_gcr_poisson(n, restart, iters, usable)
+    return {"value": iters / dt, "unit": "it/s", "cores": usable, "kind": "port",
+            "sample": "%d GCR iterations (restart %d) of the same Poisson %d^3 system by oracle/mgcr_cpu_opt.c: OpenMP over "
+                      "%d threads (= the CPU share this process is granted), CSR with int32 columns and real values, update / "
+                      "SpMV+dots / build fused as on the GPU" % (iters, restart, n, usable),
+            "final_rel_residual": float(hist[-1]), "host_cores": ncores}
 
 
 def main():
@@ -240,6 +274,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         except Exception as e:  # the baseline leg must never take the GPU numbers down with it
             out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
+        try:
+            out["cpu_baseline_optimised"] = cpu_baseline_optimised(n, args.restart)
+        except Exception as e:
+            out["cpu_baseline_optimised"] = {"value": None, "unit": "it/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     # orderly teardown: solver state and operator first, then the communicator, then the process group

@@ -6,6 +6,8 @@ that is bench.py).  One JSON line per workload on stdout.
   python bench_extra.py --workload poisson256 config 2 at 256^3: unpreconditioned GCR restart 5, 100 iterations
   python bench_extra.py --workload mg256      config 3: Poisson 256^3, 3-level aggregation MG (2^3 aggregates,
                                               piecewise-constant P, Galerkin), 2 GCR sweeps, flexible GCR restart 5
+  python bench_extra.py --workload poisson128tol  config 2 time-to-tolerance: GCR restart 5 to 1e-13 on Poisson 128^3
+                                              (bounded at 200 000 iterations), and the same solve MG-preconditioned
   python bench_extra.py --workload bcsr       config 5 (single GPU): unstructured HierarchicalSparse, bs = 20,
                                               skewed blocks/row, >= 2 GB of blocks: apply GB/s + GCR on it
 """
@@ -36,7 +38,7 @@ def timed_solve(mg, gcr, rhs, x):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["sample", "poisson256", "mg256", "bcsr"])
+    ap.add_argument("--workload", required=True, choices=["sample", "poisson256", "mg256", "poisson128tol", "bcsr"])
     ap.add_argument("--grid", dest="n", type=int, default=256)
     ap.add_argument("--levels", type=int, default=2, help="number of coarse grids (2 = 3-level)")
     args = ap.parse_args()
@@ -65,6 +67,35 @@ def main():
                    reference_final=float(ref[-1]),
                    max_rel_dev_first_60_steps=float(np.max(np.abs(gcr.last_history[1:60] - ref[1:60]) / ref[1:60])),
                    note="N = 3072: latency-bound (4 launches/iteration), the reference CPU path does ~1.7k it/s on this input")
+    elif args.workload == "poisson128tol":
+        n = 128
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        A = Sparse(N, ncol, rowptr, col, val)
+        del rowptr, col, val
+        dims = (n, n, n)
+        rhs = Field(dims).fill_rhs(0)
+        x = Field(dims).set_zero()
+        tol = 1e-13
+        cap = 200000
+        gcr = GCR(A, GCR_Param(0, 5, cap, tol, False, check_every=50))
+        dt = timed_solve(mg, gcr, rhs, x)
+        r = rhs - A(x)
+        out.update(n=n, rows=N, tol=tol, iterations=gcr.last_iterations, converged=gcr.last_converged, seconds_to_tol=dt,
+                   it_per_s=gcr.last_iterations / dt, final_rel_residual=float(gcr.last_history[-1]),
+                   true_rel_residual=r.norm() / rhs.norm())
+        # the same system and tolerance with the 3-level MG of config 3 as flexible right preconditioner
+        prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                       2, None, None, null_vectors=np.ones((1, N), np.complex128))
+        t0 = time.perf_counter()
+        M = MG(A, prm)
+        mg.lib().mgcr_synchronize()
+        out["mg_setup_seconds"] = time.perf_counter() - t0
+        x.set_zero()
+        outer = GCR(A, GCR_Param(0, 5, 500, tol, False, None, M, flexible=True, check_every=2))
+        dt = timed_solve(mg, outer, rhs, x)
+        r = rhs - A(x)
+        out.update(mg_outer_iterations=outer.last_iterations, mg_converged=outer.last_converged, mg_seconds_to_tol=dt,
+                   mg_true_rel_residual=r.norm() / rhs.norm())
     elif args.workload in ("poisson256", "mg256"):
         n = args.n
         t0 = time.perf_counter()
@@ -116,6 +147,23 @@ def main():
                 M(rhs, out=y)
             mg.lib().mgcr_synchronize()
             out["vcycle_ms"] = (time.perf_counter() - t0) * 1e3 / reps
+            # SURVEY.md §8(d) "algorithmic bytes — V-cycle": per level, nu_pre + nu_post smoother iterations
+            # B_iter(lim) = B_spmv + (13 + 3 lim) V with lim = 1, 2, the residual B_spmv + 2 V, restrict
+            # V_l + V_(l+1) and prolong+add V_(l+1) + 2 V_l (piecewise-constant P); the coarsest solve is not
+            # counted (its iteration count is data dependent).  nnz_l = 7 n_l^3 - 6 n_l^2.
+            model, nl = [], n
+            for l in range(args.levels):
+                Nl, nnzl = nl ** 3, 7 * nl ** 3 - 6 * nl ** 2
+                Vl, Vc = 16 * Nl, 16 * (nl // 2) ** 3
+                bsp = nnzl * 20 + (Nl + 1) * 4 + 2 * Vl
+                smooth = 2 * sum(bsp + (13 + 3 * lim) * Vl for lim in (1, 2))
+                model.append(dict(level=l, rows=Nl, smoother_bytes=smooth, residual_bytes=bsp + 2 * Vl, restrict_bytes=Vl + Vc,
+                                  prolong_bytes=Vc + 2 * Vl))
+                nl //= 2
+            tot = sum(m["smoother_bytes"] + m["residual_bytes"] + m["restrict_bytes"] + m["prolong_bytes"] for m in model)
+            out["vcycle_bytes_model_survey"] = model
+            out["vcycle_GBps_survey"] = tot / (out["vcycle_ms"] * 1e-3) / 1e9
+            out["vcycle_frac_hbm_peak_survey"] = out["vcycle_GBps_survey"] / HBM_PEAK_GBS
             tol = 1e-8
             outer = GCR(A, GCR_Param(0, 5, 200, tol, False, None, M, flexible=True, check_every=2))
             dt = timed_solve(mg, outer, rhs, x)

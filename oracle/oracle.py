@@ -30,9 +30,23 @@ class GcrParamC(C.Structure):
 def build():
     """Compile the oracle (gcc) if the .so is missing or older than its sources."""
     srcs = [os.path.join(_HERE, f) for f in ("mgcr_oracle.c", "mgcr_oracle_mg.c")]
-    if (not os.path.exists(_LIB_PATH)
-            or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)):
+    opt = os.path.join(_HERE, "libmgcr_cpu_opt.so")
+    if (not os.path.exists(_LIB_PATH) or not os.path.exists(opt)
+            or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+            or os.path.getmtime(os.path.join(_HERE, "mgcr_cpu_opt.c")) > os.path.getmtime(opt)):
         subprocess.run(["make", "-C", _HERE, "oracle"], check=True, capture_output=True)
+
+
+def opt_gcr_poisson(n, restart, iters, nthreads=0):
+    """Optimised CPU port (oracle/mgcr_cpu_opt.c: OpenMP, fused passes) on Poisson n^3, RHS seed 0, x0 = 0:
+    returns (seconds in the iterations, history[0..iters]).  bench.py's second CPU baseline."""
+    build()
+    L = C.CDLL(os.path.join(_HERE, "libmgcr_cpu_opt.so"))
+    L.orc_opt_gcr_poisson.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, _f64p]
+    L.orc_opt_gcr_poisson.restype = C.c_double
+    hist = np.zeros(iters + 1)
+    dt = L.orc_opt_gcr_poisson(n, restart, iters, nthreads, hist)
+    return dt, hist
 
 
 def lib():

@@ -217,3 +217,16 @@ def test_mg_cycle_oracle_converges():
     x1, h1, it1, c1 = orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=400, tol=1e-8, right=M, flexible=True), b)
     assert c0 and c1 and it1 * 3 < it0
     assert np.linalg.norm(b - A(x1)) / np.linalg.norm(b) < 2e-8
+
+
+def test_optimised_cpu_port_follows_the_oracle():
+    """bench.py's second CPU baseline (oracle/mgcr_cpu_opt.c, OpenMP + fused passes) is the same algorithm:
+    its residual history follows the oracle's up to the order its parallel reductions sum in."""
+    n = 12
+    N, rowptr, col, val = orc.poisson3d(n)
+    A = orc.csr(N, N, rowptr, col, val)
+    b = orc.fill_rhs(N, 0)
+    _, h, _, _ = orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=30, tol=0.0), b)
+    _, ho = orc.opt_gcr_poisson(n, 5, 30, 2)
+    _, sens, _ = orc.gcr_reorder_sensitivity(A, orc.gcr_param(restart=5, max_iter=30, tol=0.0), b)
+    assert (np.abs(ho - h[:31]) <= np.maximum(1e-9 * h[:31], 8 * sens[:31]) + 1e-17).all()
