@@ -3,17 +3,17 @@
 //
 //   * x, r and the stored directions live in HBM for the whole solve; p and Ap are not separate
 //     vectors but the ring slot that was written last (the reference copies them, :286-287);
-//   * per iteration three fused BLAS-1 kernels + one SpMV instead of ~90 vector passes
-//     (SURVEY.md §8(a) A3):
+//   * per iteration three kernels instead of ~90 vector passes:
 //        xr_update   x += a p, r -= a Ap, |r|^2 partials                         6 V  (3 V when the
 //                    x update is deferred to the end of the restart cycle, see xr_update_kernel)
-//        SpMV        Ar = A r                                                     B_spmv
-//        multidot    <Ar, Aps[i]> partials for all stored i in one pass           (1+lim) V
+//        apply+dots  Ar = A r and the <Ar, Aps[i]> partials for all stored i      B_matrix + (2+lim) V
+//                    (gcr_fused.hip: one kernel for a Sparse / DiracOp stored one thread per row; else
+//                    the operator's own apply followed by multidot_kernel, (1+lim) V more)
 //        build       p' = r - sum b_i ps[i], Ap' = Ar - sum b_i Aps[i] written straight into the
 //                    ring slot, plus <r,Ap'> and <Ap',Ap'> partials and the step's bookkeeping
 //                    (history entry, convergence predicate)                        (4+2 lim) V
-//     = B_spmv + (11 + 3 lim) V of HBM traffic per iteration;
-//   * restart mode without the literal preconditioner hooks runs LEAN: inside a restart cycle the
+//     = B_matrix + (9 + 3 lim) V of HBM traffic per iteration in the classic form, and
+//   * restart mode (restart <= 8) without the literal preconditioner hooks runs LEAN: inside a restart cycle the
 //     directions p_k are never formed.  Only x needs them, and x is updated once per cycle, so the
 //     solver keeps what p_k is a combination of — the cycle's first direction P0 and the residuals
 //     (or M r, flexible mode) D_1..D_k the later directions were started from — plus the small
