@@ -158,6 +158,28 @@ __global__ void __launch_bounds__(RED_THREADS) dot2_partials_kernel(const cplx *
     if (threadIdx.x < 4) parts[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
 }
 
+// |r|^2 (written twice: it is |b|^2 as well when r0 = b), <r,Ap> and <Ap,Ap> in one pass; same sums, in the
+// same order, as norm_partials_kernel + dot2_partials_kernel
+__global__ void __launch_bounds__(RED_THREADS) init3_partials_kernel(const cplx *__restrict__ r, const cplx *__restrict__ ap,
+                                                                    int64_t n, double *__restrict__ partsN,
+                                                                    double *__restrict__ partsR, double *__restrict__ partsA,
+                                                                    const DevState *st, int it) {
+    __shared__ double lds[5 * 17];
+    if (st->stop_at < st->base + it) return;
+    double v[5] = {0., 0., 0., 0., 0.};
+    GRID_STRIDE(i, n) {
+        cplx rv = r[i], a = ap[i];
+        v[4] += rv.x * rv.x + rv.y * rv.y;
+        cplx t = cconj_mul(rv, a);
+        v[0] += t.x; v[1] += t.y;
+        cplx u = cconj_mul(a, a);
+        v[2] += u.x; v[3] += u.y;
+    }
+    block_sum_bcast<5>(v, lds);
+    if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+    if (threadIdx.x == 4) { partsN[blockIdx.x] = v[4]; partsR[blockIdx.x] = v[4]; }
+}
+
 // step 0 bookkeeping (src/GCR.h:213-216)
 __global__ void __launch_bounds__(RED_THREADS) init_kernel(DevState *st, const double *__restrict__ partsN, int nblkN,
                                                            int strideN, const double *__restrict__ partsR, int nblkR,
@@ -903,21 +925,30 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     MGCR_HIP(hipGetLastError());
     SkipGuard guard(SkipRef{&s->st->stop_at, 0});
 
+    // restart mode with all slots handled by one build launch: defer the x updates of a cycle ...
+    const bool defer = p.restart != 0 && s->storage <= ND;
+    // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
+    const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
+    // A lean solve from x0 = 0 that ends before its first restart cycle closes (smoothers: 2 sweeps of
+    // GCR(10)) never overwrites its first direction and never updates r in place: r0 and P0 simply ARE rhs —
+    // no copies, and |b|^2 = |r0|^2 comes out of the pass that takes <r,Ap> and <Ap,Ap>.
+    const bool alias0 = lean && !flex && !p.use_x0 && p.max_iter >= 1 && p.max_iter < p.restart;
+    const cplx *p0 = alias0 ? rhs : s->ps[0];
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
         MGCR_TRY(op_apply_raw(s->A, x, s->ar, n));
         KLAUNCH(sub_kernel, g, s->r, rhs, s->ar, n, (const DevState *)s->st, 0);
-    } else {
+    } else if (!alias0) {
         MGCR_TRY(k_copy(s->r, rhs, n));
     }
     // p = r (or M r); Ap = A p; both go straight into slot 0 (src/GCR.h:190-191,208-211)
     if (flex) {
         MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
         MGCR_TRY(k_copy(s->ps[0], s->z, n));
-    } else {
+    } else if (!alias0) {
         MGCR_TRY(k_copy(s->ps[0], s->r, n));
     }
-    MGCR_TRY(op_apply_raw(s->A, s->ps[0], s->aps[0], n));
+    MGCR_TRY(op_apply_raw(s->A, p0, s->aps[0], n));
     if (!flex) {  // literal hooks, src/GCR.h:197-204 (after p and Ap were formed)
         if (p.right_precond) { MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
         if (p.left_precond) { MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
@@ -930,9 +961,13 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     MGCR_CHECK(!multi || (!p.left_precond && (!p.right_precond || flex)), MGCR_ERR_UNSUPPORTED,
                "on a distributed operator only flexible right preconditioning is available (set flexible = 1)");
     const DevState *cst = s->st;
-    KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
-    KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, 0);
-    KLAUNCH(dot2_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, s->partsA, cst, 0);
+    if (alias0) {
+        KLAUNCH(init3_partials_kernel, g, rhs, (const cplx *)s->aps[0], n, s->partsN, s->partsR, s->partsA, cst, 0);
+    } else {
+        KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
+        KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, 0);
+        KLAUNCH(dot2_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, s->partsA, cst, 0);
+    }
     RedRef refA = {s->partsA, g, RED_MAX_BLOCKS}, refR = {s->partsR, g, RED_MAX_BLOCKS};
     if (multi) {
         MGCR_TRY(k_fold(s->partsN, g, 1, s->dN));
@@ -949,11 +984,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
     int check_every = p.check_every > 0 ? p.check_every : 10;
-    // restart mode with all slots handled by one build launch: defer the x updates of a cycle
-    const bool defer = p.restart != 0 && s->storage <= ND;
-    // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
-    const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
-    const cplx *rcur = s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
+    const cplx *rcur = alias0 ? rhs : s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
     // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
     bool fuse_ok = false;
     if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !p.left_precond) {
@@ -1131,6 +1162,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (defer) {  // x updates still pending (solve ended inside a restart cycle); ps[0..npend) hold their directions
         DirPtrs d0;
         for (int j = 0; j < ND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
+        d0.ps[0] = p0;
         KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n);
         hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);
         MGCR_HIP(hipGetLastError());
