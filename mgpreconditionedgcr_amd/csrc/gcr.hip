@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(RED_THREADS) init3_partials_kernel(const cplx 
                                                                     double *__restrict__ partsR, double *__restrict__ partsA,
                                                                     const DevState *st, int it) {
     __shared__ double lds[5 * 17];
-    if (st->stop_at < st->base + it) return;
+    if (st->stop_at < st->base + it) return;  // partsN == nullptr: r is not b (use_x0), |b|^2 is taken separately
     double v[5] = {0., 0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
         cplx rv = r[i], a = ap[i];
@@ -177,7 +177,10 @@ __global__ void __launch_bounds__(RED_THREADS) init3_partials_kernel(const cplx 
     }
     block_sum_bcast<5>(v, lds);
     if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
-    if (threadIdx.x == 4) { partsN[blockIdx.x] = v[4]; partsR[blockIdx.x] = v[4]; }
+    if (threadIdx.x == 4) {
+        partsR[blockIdx.x] = v[4];
+        if (partsN) partsN[blockIdx.x] = v[4];
+    }
 }
 
 // step 0 bookkeeping (src/GCR.h:213-216)
@@ -929,11 +932,13 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool defer = p.restart != 0 && s->storage <= ND;
     // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
     const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
-    // A lean solve from x0 = 0 that ends before its first restart cycle closes (smoothers: 2 sweeps of
-    // GCR(10)) never overwrites its first direction and never updates r in place: r0 and P0 simply ARE rhs —
-    // no copies, and |b|^2 = |r0|^2 comes out of the pass that takes <r,Ap> and <Ap,Ap>.
-    const bool alias0 = lean && !flex && !p.use_x0 && p.max_iter >= 1 && p.max_iter < p.restart;
-    const cplx *p0 = alias0 ? rhs : s->ps[0];
+    // A lean solve that ends before its first restart cycle closes (smoothers: 2 sweeps of GCR(10)) never
+    // overwrites its first direction and never updates r in place (the residual ring takes the updates): P0
+    // simply IS r0 — no copy — and from x0 = 0 r0 IS rhs, in which case |b|^2 = |r0|^2 comes out of the pass
+    // that takes <r,Ap> and <Ap,Ap>.
+    const bool alias_p0 = lean && !flex && p.max_iter >= 1 && p.max_iter < p.restart;
+    const bool alias0 = alias_p0 && !p.use_x0;
+    const cplx *p0 = alias0 ? rhs : alias_p0 ? (const cplx *)s->r : (const cplx *)s->ps[0];
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
         MGCR_TRY(op_apply_raw(s->A, x, s->ar, n));
@@ -945,7 +950,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (flex) {
         MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
         MGCR_TRY(k_copy(s->ps[0], s->z, n));
-    } else if (!alias0) {
+    } else if (!alias_p0) {
         MGCR_TRY(k_copy(s->ps[0], s->r, n));
     }
     MGCR_TRY(op_apply_raw(s->A, p0, s->aps[0], n));
@@ -963,6 +968,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const DevState *cst = s->st;
     if (alias0) {
         KLAUNCH(init3_partials_kernel, g, rhs, (const cplx *)s->aps[0], n, s->partsN, s->partsR, s->partsA, cst, 0);
+    } else if (alias_p0) {
+        KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
+        KLAUNCH(init3_partials_kernel, g, (const cplx *)s->r, (const cplx *)s->aps[0], n, (double *)nullptr, s->partsR, s->partsA, cst, 0);
     } else {
         KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
         KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, 0);
