@@ -13,7 +13,7 @@
 //                    ring slot, plus <r,Ap'> and <Ap',Ap'> partials and the step's bookkeeping
 //                    (history entry, convergence predicate)                        (4+2 lim) V
 //     = B_matrix + (9 + 3 lim) V of HBM traffic per iteration in the classic form, and
-//   * restart mode (restart <= 8) without the literal preconditioner hooks runs LEAN: inside a restart cycle the
+//   * restart mode (restart <= 16) without the literal preconditioner hooks runs LEAN: inside a restart cycle the
 //     directions p_k are never formed.  Only x needs them, and x is updated once per cycle, so the
 //     solver keeps what p_k is a combination of — the cycle's first direction P0 and the residuals
 //     (or M r, flexible mode) D_1..D_k the later directions were started from — plus the small
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(RED_THREADS) flush_x_kernel(DevState *__restri
     if (np <= 0) return;
     GRID_STRIDE(i, n) {
         cplx xv = x[i];
-        for (int j = 0; j < np && j < ND; j++) xv = cadd(xv, cmul(alphas[j], d0.ps[j][i]));
+        for (int j = 0; j < np && j < LND; j++) xv = cadd(xv, cmul(alphas[j], d0.ps[j][i]));
         x[i] = xv;
     }
 }
@@ -431,8 +431,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
                                                                  int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
                                                                  int strideR, double *__restrict__ hist, int hist_cap,
                                                                  const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ r,
-                                                                 const cplx *__restrict__ ar, cplx *__restrict__ ap_out, int64_t n,
-                                                                 double *__restrict__ partsA, LeanCoef *__restrict__ lc) {
+                                                                 const cplx *__restrict__ ar, cplx *ap_out, int64_t n,
+                                                                 double *__restrict__ partsA, LeanCoef *__restrict__ lc, int closing) {
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT];
     if (st->stop_at < st->base + it) return;
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     if (blockIdx.x == 0) {
         double rr[1];
         fold_partials<1>(partsR, nblkR, strideR, rr, lds);
-        if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, false);
+        if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, closing != 0);
     }
     if (threadIdx.x < NDT) {
         cplx num = make_double2(0., 0.);
@@ -451,17 +451,19 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
         sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // closing (restart > 8: the cycle-closing step is close_x_kernel + this kernel with NDT = restart, writing
+    // Ap_0' over slot 0 in place): no table row — the next cycle starts a new table
+    if (!closing && blockIdx.x == 0 && threadIdx.x == 0) {
         constexpr int k = NDT;
         cplx tk = make_double2(0., 0.);
         for (int j = 0; j < k; j++) tk = csub(tk, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
         lc->t[k] = tk;
         for (int m = 1; m < k; m++) {
             cplx a = make_double2(0., 0.);
-            for (int j = m; j < k; j++) a = csub(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * ND + m]));
-            lc->T[k * ND + m] = a;
+            for (int j = m; j < k; j++) a = csub(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * LND + m]));
+            lc->T[k * LND + m] = a;
         }
-        lc->T[k * ND + k] = make_double2(1., 0.);
+        lc->T[k * LND + k] = make_double2(1., 0.);
     }
     cplx beta[NDT];
 #pragma unroll
@@ -486,6 +488,57 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     if (threadIdx.x < 4) {
         double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
         partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
+    }
+}
+
+// LEAN, restart > 8: the x / P0 half of the cycle-closing step (the Ap half is build_lean_kernel with
+// closing = 1).  Same sums, in the same order, as build_close_kernel; the 2 * NDT coefficients stay in LDS.
+// Launched with RED_THREADS / 2 threads per workgroup (256 VGPRs each: 16 direction loads in flight plus the
+// coefficients the compiler hoists out of the loop do not fit 128); it produces no partial sums, and
+// fold_partials only needs blockDim >= the number of partials (<= RED_MAX_BLOCKS = RED_THREADS / 2).
+template <int NDT>
+__global__ void __launch_bounds__(RED_THREADS / 2) close_x_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
+                                                              int nblkB, int strideB, const cplx *__restrict__ den, DirPtrs d,
+                                                              const cplx *__restrict__ dir, cplx *p_out, int64_t n,
+                                                              cplx *__restrict__ x, const LeanCoef *__restrict__ lc) {
+    __shared__ double lds[2 * NDT * 17];
+    __shared__ cplx sbeta[NDT], scp[NDT], scx[NDT];
+    if (st->stop_at < st->base + it) return;
+    double s[2 * NDT];
+    fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
+    if (threadIdx.x < NDT) {
+        cplx num = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++)
+            if (j == (int)threadIdx.x) num = make_double2(s[2 * j], s[2 * j + 1]);
+        sbeta[threadIdx.x] = cdiv(num, den[d.slot[threadIdx.x]]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NDT) {
+        const int m = threadIdx.x;
+        cplx a = make_double2(0., 0.);
+        if (m == 0) {
+            for (int j = 0; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
+        } else {
+            for (int j = m; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * LND + m]));
+        }
+        scp[m] = a;
+        scx[m] = lc->cx[m];
+    }
+    __syncthreads();
+    GRID_STRIDE(i, n) {
+        cplx pj[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) pj[j] = ld_stream<NTS>(d.ps[j] + i);
+        const cplx dv = dir[i];
+        cplx xv = x[i];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) xv = cadd(xv, cmul(scx[j], pj[j]));
+        x[i] = xv;
+        cplx pc = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++) pc = csub(pc, cmul(scp[j], pj[j]));
+        st_stream<NTS>(p_out + i, cadd(dv, pc));
     }
 }
 
@@ -527,7 +580,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 2 ? 8 : 4)) build_close_k
         if (m == 0) {
             for (int j = 0; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
         } else {
-            for (int j = m; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * ND + m]));
+            for (int j = m; j < NDT; j++) a = cadd(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * LND + m]));
         }
         scp[m] = a;
     }
@@ -838,10 +891,10 @@ struct LeanArgs {
     LeanCoef *lc;
 };
 
-static int launch_build_lean(const LeanArgs &a) {
+static int launch_build_lean(const LeanArgs &a, int closing) {
 #define BL(NDT)                                                                                                               \
     KLAUNCH((build_lean_kernel<NDT>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk, a.R.stride, a.hist,      \
-            a.hist_cap, a.den, a.d, a.r, a.ar, a.ap_out, a.n, a.partsA, a.lc)
+            a.hist_cap, a.den, a.d, a.r, a.ar, a.ap_out, a.n, a.partsA, a.lc, closing)
     switch (a.nd) {
         case 1: BL(1); break;
         case 2: BL(2); break;
@@ -849,9 +902,39 @@ static int launch_build_lean(const LeanArgs &a) {
         case 4: BL(4); break;
         case 5: BL(5); break;
         case 6: BL(6); break;
-        default: BL(7); break;  // a cycle of ND slots has at most ND - 1 in-cycle builds
+        case 7: BL(7); break;
+        case 8: BL(8); break;
+        case 9: BL(9); break;
+        case 10: BL(10); break;
+        case 11: BL(11); break;
+        case 12: BL(12); break;
+        case 13: BL(13); break;
+        case 14: BL(14); break;
+        case 15: BL(15); break;
+        default: BL(16); break;
     }
 #undef BL
+    return MGCR_OK;
+}
+
+static int launch_close_x(const LeanArgs &a) {
+#define CX(NDT)                                                                                                               \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((close_x_kernel<NDT>), dim3(2 * a.g), dim3(RED_THREADS / 2), 0, ctx().stream, a.st, a.it, a.B.p,   \
+                           a.B.nblk, a.B.stride, a.den, a.d, a.dir, a.p_out, a.n, a.x, (const LeanCoef *)a.lc);               \
+        MGCR_HIP(hipGetLastError());                                                                                          \
+    } while (0)
+    switch (a.nd) {
+        case 9: CX(9); break;
+        case 10: CX(10); break;
+        case 11: CX(11); break;
+        case 12: CX(12); break;
+        case 13: CX(13); break;
+        case 14: CX(14); break;
+        case 15: CX(15); break;
+        default: CX(16); break;
+    }
+#undef CX
     return MGCR_OK;
 }
 
@@ -929,9 +1012,10 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     SkipGuard guard(SkipRef{&s->st->stop_at, 0});
 
     // restart mode with all slots handled by one build launch: defer the x updates of a cycle ...
-    const bool defer = p.restart != 0 && s->storage <= ND;
-    // ... and without the literal hooks (which replace r itself) the cycle runs lean: see the file header
-    const bool lean = defer && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
+    // ... and without the literal hooks (which replace r itself) the cycle runs lean (up to LND slots): see the
+    // file header
+    const bool lean = p.restart != 0 && s->storage <= LND && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
+    const bool defer = lean || (p.restart != 0 && s->storage <= ND);
     // A lean solve that ends before its first restart cycle closes (smoothers: 2 sweeps of GCR(10)) never
     // overwrites its first direction and never updates r in place (the residual ring takes the updates): P0
     // simply IS r0 — no copy — and from x0 = 0 r0 IS rhs, in which case |b|^2 = |r0|^2 comes out of the pass
@@ -1090,11 +1174,17 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             LeanArgs a;
             a.g = g; a.nd = lim; a.rdir = flex; a.st = s->st; a.it = it; a.B = refB; a.R = refR; a.hist = s->hist;
             a.hist_cap = s->hist_cap; a.den = s->den;
-            for (int j = 0; j < ND; j++) { int sl = j < lim ? j : 0; a.d.ps[j] = s->ps[sl]; a.d.aps[j] = s->aps[sl]; a.d.slot[j] = sl; }
+            for (int j = 0; j < LND; j++) { int sl = j < lim ? j : 0; a.d.ps[j] = s->ps[sl]; a.d.aps[j] = s->aps[sl]; a.d.slot[j] = sl; }
             a.dir = dir; a.r = rcur; a.ar = s->ar; a.p_out = s->ps[0]; a.ap_out = s->aps[nxt]; a.n = n; a.partsA = s->partsA;
             a.x = x; a.lc = s->lc;
-            if (ic_next == 0) MGCR_TRY(launch_build_close(a));  // lim == restart: closes the cycle
-            else MGCR_TRY(launch_build_lean(a));                // lim == nxt
+            if (ic_next != 0) {
+                MGCR_TRY(launch_build_lean(a, 0));              // lim == nxt
+            } else if (lim <= ND) {
+                MGCR_TRY(launch_build_close(a));                // lim == restart: closes the cycle
+            } else {                                            // ... in two kernels when restart > 8
+                MGCR_TRY(launch_close_x(a));
+                MGCR_TRY(launch_build_lean(a, 1));
+            }
         } else
         for (int ch = 0; ch < nchunk; ch++) {
             BuildArgs a;
@@ -1169,7 +1259,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
     if (defer) {  // x updates still pending (solve ended inside a restart cycle); ps[0..npend) hold their directions
         DirPtrs d0;
-        for (int j = 0; j < ND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
+        for (int j = 0; j < LND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
         d0.ps[0] = p0;
         KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n);
         hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);

@@ -6,7 +6,8 @@
 
 namespace mgcr {
 
-constexpr int ND = 8;  // directions per multidot / build launch
+constexpr int ND = 8;    // directions per multidot / classic build launch
+constexpr int LND = 16;  // slots a lean restart cycle can have (restart <= 16)
 #ifndef MGCR_NT_SLOTS
 #define MGCR_NT_SLOTS 1
 #endif
@@ -29,17 +30,17 @@ struct DevState {
     double tol2;
 };
 
-struct DirPtrs {
-    const cplx *ps[ND];
-    const cplx *aps[ND];
-    int slot[ND];
+struct DirPtrs {  // the classic kernels use the first ND entries (one chunk), the lean ones up to LND
+    const cplx *ps[LND];
+    const cplx *aps[LND];
+    int slot[LND];
 };
 
 // lean restart cycles: p_k = t[k] P0 + sum_{1<=m<=k} T[k][m] D_m;  cx = coefficients of the pending x update
 struct LeanCoef {
-    cplx T[ND * ND];
-    cplx t[ND];
-    cplx cx[ND];
+    cplx T[LND * LND];
+    cplx t[LND];
+    cplx cx[LND];
 };
 
 
@@ -47,10 +48,10 @@ struct LeanCoef {
 __device__ __forceinline__ void lean_pending_update(LeanCoef *lc, int slot, cplx alpha) {
     if (slot == 0) {
         lc->cx[0] = alpha;
-        for (int m = 1; m < ND; m++) lc->cx[m] = make_double2(0., 0.);
+        for (int m = 1; m < LND; m++) lc->cx[m] = make_double2(0., 0.);
     } else {
         lc->cx[0] = cadd(lc->cx[0], cmul(alpha, lc->t[slot]));
-        for (int m = 1; m <= slot; m++) lc->cx[m] = cadd(lc->cx[m], cmul(alpha, lc->T[slot * ND + m]));
+        for (int m = 1; m <= slot; m++) lc->cx[m] = cadd(lc->cx[m], cmul(alpha, lc->T[slot * LND + m]));
     }
 }
 

@@ -380,7 +380,9 @@ def test_row_pattern_storage_same_solve():
 
 
 @pytest.mark.parametrize("kind,restart,tol", [("poisson", 5, 1e-10), ("poisson", 1, 1e-6), ("poisson", 8, 1e-10),
-                                              ("dirac", 5, 1e-12), ("dirac", 3, 1e-12), ("flex", 4, 1e-10)])
+                                              ("poisson", 9, 1e-10), ("poisson", 10, 1e-10), ("poisson", 16, 1e-10),
+                                              ("dirac", 5, 1e-12), ("dirac", 3, 1e-12), ("dirac", 12, 1e-12),
+                                              ("flex", 4, 1e-10), ("flex", 11, 1e-10)])
 def test_lean_restart_cycles_match_classic(kind, restart, tol, sample, sample_oracle):
     """Restart-mode GCR keeps, inside a cycle, the residuals the directions were started from instead of
     the directions (gcr.hip header).  r, Ap and every scalar follow the same recurrences: the residual
@@ -418,7 +420,7 @@ def test_lean_restart_cycles_match_classic(kind, restart, tol, sample, sample_or
 
 
 @pytest.mark.parametrize("fmt", ["pattern", "slab", "dirac-pattern", "slab-generic-width"])
-@pytest.mark.parametrize("mode", [dict(restart=5), dict(truncation=3), dict()])
+@pytest.mark.parametrize("mode", [dict(restart=5), dict(restart=10), dict(truncation=3), dict()])
 def test_fused_apply_and_dots_same_bits(fmt, mode):
     """SpMV + beta dot products as one kernel (spmv.hip: spmv_multidot_kernel) against the two separate
     kernels: same y, same partial sums, hence the same residual history and the same x, bit for bit —
