@@ -1140,19 +1140,24 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         }
         MGCR_TRY(mark());
         const int nchunk = (lim + ND - 1) / ND;
-        if (fuse_ok && nchunk == 1) {
-            // Ar = A dir and the <Ar, Aps_j> partials in one pass (spmv.hip)
+        int ch0 = 0;
+        if (fuse_ok) {
+            // Ar = A dir and the <Ar, Aps_j> partials of the first ND stored directions in one pass (gcr_fused.hip);
+            // directions beyond that (restart > 8) go through multidot_kernel below
+            const int nf = lim < ND ? lim : ND;
             const cplx *vecs[ND];
-            for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < lim ? j : 0];
+            for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < nf ? j : 0];
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
-            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->partsB, b0->dist));
+            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist));
+            ch0 = 1;
         } else {
-        MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
-        if (p.left_precond) {                         // src/GCR.h:245-247
-            MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->ar, s->tmp, n));
-            std::swap(s->ar, s->tmp);
+            MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
+            if (p.left_precond) {                         // src/GCR.h:245-247
+                MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->ar, s->tmp, n));
+                std::swap(s->ar, s->tmp);
+            }
         }
-        for (int ch = 0; ch < nchunk; ch++) {
+        for (int ch = ch0; ch < nchunk; ch++) {
             DirPtrs d;
             int nd = lim - ch * ND < ND ? lim - ch * ND : ND;
             for (int j = 0; j < ND; j++) {
@@ -1160,7 +1165,6 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
             MGCR_TRY(launch_multidot(g, nd, cst, it, (const cplx *)s->ar, d, ch * ND, n, s->partsB));
-        }
         }
         MGCR_TRY(mark());
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
