@@ -73,12 +73,23 @@ __global__ void __launch_bounds__(RED_THREADS) dot_partials_kernel(const cplx *_
     }
 }
 
-__global__ void __launch_bounds__(RED_THREADS) fold_kernel(const double *__restrict__ parts, int nblk, int nscal, double *__restrict__ out) {
-    __shared__ double lds[17];
-    for (int k = 0; k < nscal; k++) {
-        double v[1];
-        fold_partials<1>(parts + (size_t)k * RED_MAX_BLOCKS, nblk, RED_MAX_BLOCKS, v, lds);
-        if (threadIdx.x == 0) out[k] = v[0];
+// Folds partial slabs to scalars, one WAVE per scalar (all scalars of up to two slabs in one launch): wave w walks
+// the 16 wave-sized pieces of its scalar's slab and adds the pieces' shuffle-tree sums in index order — the very
+// tree fold_partials / block_sum_bcast build over a 1024-thread workgroup, so the result has the same bits as the
+// in-kernel folds of the single-GPU path.
+__global__ void __launch_bounds__(64) fold_kernel(const double *__restrict__ pa, int na, double *__restrict__ outa,
+                                                  const double *__restrict__ pb, int nb, double *__restrict__ outb, int nblk) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const double *src = k < na ? pa + (size_t)k * RED_MAX_BLOCKS : pb + (size_t)(k - na) * RED_MAX_BLOCKS;
+    double acc = 0.;
+    for (int w = 0; w < RED_THREADS / 64; w++) {
+        const int t = w * 64 + lane;
+        double s = wave_sum(t < nblk ? src[t] : 0.);
+        if (lane == 0) acc += s;
+    }
+    if (lane == 0) {
+        if (k < na) outa[k] = acc;
+        else outb[k - na] = acc;
     }
 }
 
@@ -134,9 +145,14 @@ int k_dot_partials(const cplx *a, const cplx *b, int64_t n, double *parts, int *
     *nblk = g;
     return MGCR_OK;
 }
-int k_fold(const double *parts, int nblk, int nscal, double *out_dev) {
-    LAUNCH(fold_kernel, 1, parts, nblk, nscal, out_dev);
+int k_fold2(const double *pa, int na, double *outa, const double *pb, int nb, double *outb, int nblk) {
+    if (na + nb <= 0) return MGCR_OK;
+    hipLaunchKernelGGL(fold_kernel, dim3(na + nb), dim3(64), 0, ctx().stream, pa, na, outa, pb, nb, outb, nblk);
+    MGCR_HIP(hipGetLastError());
     return MGCR_OK;
+}
+int k_fold(const double *parts, int nblk, int nscal, double *out_dev) {
+    return k_fold2(parts, nscal, out_dev, nullptr, 0, nullptr, nblk);
 }
 
 }  // namespace mgcr

@@ -1062,8 +1062,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
     RedRef refA = {s->partsA, g, RED_MAX_BLOCKS}, refR = {s->partsR, g, RED_MAX_BLOCKS};
     if (multi) {
-        MGCR_TRY(k_fold(s->partsN, g, 1, s->dN));
-        MGCR_TRY(k_fold(s->partsR, g, 1, s->dN + 1));
+        MGCR_TRY(k_fold2(s->partsN, 1, s->dN, s->partsR, 1, s->dN + 1, g));
         MGCR_TRY(comm_allreduce_dev(comm, s->dN, 2));
         MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
         MGCR_TRY(comm_allreduce_dev(comm, s->dA, 4));
@@ -1169,8 +1168,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         MGCR_TRY(mark());
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
         if (multi) {  // one all-reduce for |r|^2 and all beta numerators of the step
-            MGCR_TRY(k_fold(s->partsR, g, 1, s->dRB));
-            MGCR_TRY(k_fold(s->partsB, g, 2 * lim, s->dRB + 1));
+            MGCR_TRY(k_fold2(s->partsR, 1, s->dRB, s->partsB, 2 * lim, s->dRB + 1, g));
             MGCR_TRY(comm_allreduce_dev(comm, s->dRB, 1 + 2 * lim));
             refB = {s->dRB + 1, 1, 1};
         }

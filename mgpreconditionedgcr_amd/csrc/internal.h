@@ -134,6 +134,8 @@ int k_scale(cplx *v, cplx alpha, int64_t n);
 // generic reductions into a partial slab, then fold to `out` (device, nscal cplx) by a 1-block kernel
 int k_dot_partials(const cplx *a, const cplx *b, int64_t n, double *parts /*[2][RED_MAX_BLOCKS]*/, int *nblk);
 int k_fold(const double *parts, int nblk, int nscal, double *out_dev);
+// two slabs in one launch: na scalars of pa -> outa, nb scalars of pb -> outb
+int k_fold2(const double *pa, int na, double *outa, const double *pb, int nb, double *outb, int nblk);
 
 // ---- spmv.hip --------------------------------------------------------------------------------
 int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const int64_t *h_col,
