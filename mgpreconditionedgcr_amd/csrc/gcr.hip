@@ -120,12 +120,6 @@ __global__ void reset_kernel(DevState *st, const int *inherit, int inherit_it, d
     st->tol2 = tol2;
 }
 
-// r = b - t  (use_x0 extension)
-__global__ void __launch_bounds__(RED_THREADS) sub_kernel(cplx *__restrict__ out, const cplx *__restrict__ a,
-                                                          const cplx *__restrict__ b, int64_t n, const DevState *st, int it) {
-    if (st->stop_at < st->base + it) return;
-    GRID_STRIDE(i, n) out[i] = csub(a[i], b[i]);
-}
 
 // partials of |a|^2 -> parts[blk]
 __global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *__restrict__ a, int64_t n,
@@ -666,6 +660,23 @@ int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n) {
     }
 }
 
+// r = b - op(x): one pass for a Sparse (the SpMV epilogue takes b), apply + subtract otherwise
+__global__ void __launch_bounds__(RED_THREADS) resid_sub_kernel(cplx *r, const cplx *__restrict__ b, int64_t n,
+                                                                const int *__restrict__ skip, int skip_it) {
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    GRID_STRIDE(i, n) r[i] = csub(b[i], r[i]);
+}
+int op_residual_raw(Op *op, const cplx *x, const cplx *b, cplx *r, int64_t n) {
+    MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
+    if (op->kind == OP_CSR && op->csr.nrow == n && (op->dist ? true : op->csr.ncol == n) && b != r)
+        return csr_apply(op->csr, x, r, true, make_double2(1., 0.), op->dist, b);
+    MGCR_TRY(op_apply_raw(op, x, r, n));
+    const SkipRef sk = get_apply_skip();
+    hipLaunchKernelGGL(resid_sub_kernel, dim3(red_grid(n)), dim3(RED_THREADS), 0, ctx().stream, r, b, n, sk.p, sk.it);
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
 static void gcr_free_vectors(GcrState *s) {
     if (s->graph_exec) { hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     for (cplx *p : s->ps) hipFree(p);
@@ -1025,8 +1036,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const cplx *p0 = alias0 ? rhs : alias_p0 ? (const cplx *)s->r : (const cplx *)s->ps[0];
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
-        MGCR_TRY(op_apply_raw(s->A, x, s->ar, n));
-        KLAUNCH(sub_kernel, g, s->r, rhs, s->ar, n, (const DevState *)s->st, 0);
+        MGCR_TRY(op_residual_raw(s->A, x, rhs, s->r, n));
     } else if (!alias0) {
         MGCR_TRY(k_copy(s->r, rhs, n));
     }

@@ -144,8 +144,9 @@ void csr_free(CsrDev *c);
 bool set_patterns_enabled(bool on);
 bool set_lean_enabled(bool on);
 bool set_fuse_enabled(bool on);
-// y = A x   or (shift) y = x - k*(A x); dist != nullptr: row block with halo exchange
-int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr);
+// y = A x   or (shift) y = w - k*(A x) with w = x unless given (w = b, k = 1: the residual b - A x in one pass);
+// dist != nullptr: row block with halo exchange
+int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr, const cplx *w = nullptr);
 // SpMV fused with <y, v_j> partials (gcr_fused.hip); parts laid out like gcr.hip's partsB, red_grid(nrow) partials each
 bool csr_fusable(const CsrDev &A, const DistCsr *dist);
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
@@ -188,6 +189,7 @@ int mg_apply(MgState *m, const cplx *f, cplx *y);
 
 // ---- gcr.hip ---------------------------------------------------------------------------------
 int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n);
+int op_residual_raw(Op *op, const cplx *x, const cplx *b, cplx *r, int64_t n);  // r = b - op(x)
 int gcr_state_create(Op *A, const mgcr_gcr_param *p, int x0_mode, GcrState **out);
 void gcr_state_destroy(GcrState *s);
 int gcr_state_set_operator(GcrState *s, Op *A);

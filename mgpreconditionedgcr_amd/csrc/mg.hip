@@ -63,13 +63,6 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
     x[i] = add ? cadd(x[i], cmul(damp, s)) : s;
 }
 
-// r = b - r   (r holds A x on entry)
-__global__ void __launch_bounds__(256) residual_kernel(int64_t n, const cplx *__restrict__ b, cplx *__restrict__ r,
-                                                       const int *__restrict__ skip, int skip_it) {
-    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) r[i] = csub(b[i], r[i]);
-}
 
 // ------------------------------------------------------------------------------------------------
 // hierarchy
@@ -236,9 +229,7 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     }
     MGCR_TRY(k_zero_apply(x, L.n));
     MGCR_TRY(gcr_run(L.pre, b, x, true, nullptr, 0, nullptr, nullptr));
-    MGCR_TRY(op_apply_raw(L.A, x, L.r, L.n));
-    hipLaunchKernelGGL(residual_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, b, L.r, get_apply_skip().p, get_apply_skip().it);
-    MGCR_HIP(hipGetLastError());
+    MGCR_TRY(op_residual_raw(L.A, x, b, L.r, L.n));  // one pass for a Sparse (b enters the SpMV epilogue)
     MgLevel &C = m->lev[(size_t)l + 1];
     MGCR_TRY(mg_restrict(m, l, L.r, C.b));
     MGCR_TRY(mg_cycle(m, l + 1, C.b, C.x));

@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
                                                           int64_t ntiles, const void *__restrict__ val,
                                                           const int32_t *__restrict__ col, const cplx *__restrict__ x,
                                                           const cplx *__restrict__ xh, int32_t n_own,
-                                                          cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+                                                          cplx *__restrict__ y, cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
             sum = cadd(sum, vmul<REALV, NT>(val, (int64_t)c * npad + row, gather_x(x, xh, n_own, j)));
         }
     }
-    y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
+    y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
 }
 
 // Row-pattern dictionary SpMV (L = 1): one thread per row; the row's 2-byte id selects the table row
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) pat_spmv_rowthread(int64_t row_begin, int
                                                           const int32_t *__restrict__ poff, const double *__restrict__ pre,
                                                           const double *__restrict__ pim, const void *__restrict__ val,
                                                           const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
-                                                          cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+                                                          cplx *__restrict__ y, cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(256) pat_spmv_rowthread(int64_t row_begin, int
 #pragma unroll 4
         for (int32_t c = 0; c < W; c++) sum = cadd(sum, term(c, gather_x(x, xh, n_own, (int32_t)row + poff[t0 + c])));
     }
-    y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
+    y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
 }
 
 // Same, with the pattern table staged in LDS (one dependent memory round trip less per row: id -> LDS ->
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(BLK) pat_spmv_lds(int64_t row_begin, int64_t r
                                                     const int32_t *__restrict__ poff, const double *__restrict__ pre,
                                                     const double *__restrict__ pim, const cplx *__restrict__ x,
                                                     const cplx *__restrict__ xh, int32_t n_own, cplx *__restrict__ y, cplx k,
-                                                    const int *__restrict__ skip, int skip_it) {
+                                                    const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pat_smem[];
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     const int64_t tile = xcd ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(BLK) pat_spmv_lds(int64_t row_begin, int64_t r
                 else t = cmul(make_double2(sre[t0[r] + c], sim[t0[r] + c]), xv[r][c]);
                 sum = cadd(sum, t);
             }
-            if (live[r]) y[row[r]] = SHIFT ? csub(x[row[r]], cmul(k, sum)) : sum;
+            if (live[r]) y[row[r]] = SHIFT ? csub((w ? w : x)[row[r]], cmul(k, sum)) : sum;
         }
     } else {
 #pragma unroll
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(BLK) pat_spmv_lds(int64_t row_begin, int64_t r
                 else t = cmul(make_double2(sre[t0[r] + c], sim[t0[r] + c]), xv);
                 sum = cadd(sum, t);
             }
-            if (live[r]) y[row[r]] = SHIFT ? csub(x[row[r]], cmul(k, sum)) : sum;
+            if (live[r]) y[row[r]] = SHIFT ? csub((w ? w : x)[row[r]], cmul(k, sum)) : sum;
         }
     }
 }
@@ -623,7 +623,7 @@ template <int L, bool SHIFT, bool REALV>
 __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t row_count, int64_t npad, int32_t nchunk,
                                                       const void *__restrict__ val, const int32_t *__restrict__ col,
                                                       const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
-                                                      cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+                                                      cplx *__restrict__ y, cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t rloc = t / L;
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t
         sum.x += __shfl_down(sum.x, off, L);
         sum.y += __shfl_down(sum.y, off, L);
     }
-    if (row < nrow && l == 0) y[row] = SHIFT ? csub(x[row], cmul(k, sum)) : sum;
+    if (row < nrow && l == 0) y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
 }
 
 // CSR tail: one wave per long row, lanes stride the remaining entries, wave64 shuffle reduction
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
                                                        const int32_t *__restrict__ tail_col,
                                                        const cplx *__restrict__ tail_val, const cplx *__restrict__ x,
                                                        const cplx *__restrict__ xh, int32_t n_own,
-                                                       cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+                                                       cplx *__restrict__ y, cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
@@ -675,7 +675,8 @@ SkipRef get_apply_skip() { return g_skip; }
 
 // rows [row_begin, row_begin + row_count) of the ELL part
 template <bool SHIFT>
-static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const cplx *x, const cplx *xh, int32_t n_own, cplx *y, cplx k) {
+static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const cplx *x, const cplx *xh, int32_t n_own, cplx *y, cplx k,
+                    const cplx *w) {
     Context &c = ctx();
     if (row_count <= 0) return MGCR_OK;
     if (A.pat_mode == 1 && (int64_t)A.npat * A.W * 20 <= 48 * 1024) {  // pattern table fits LDS
@@ -686,7 +687,7 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
 #define PL(WT, RV)                                                                                                            \
     hipLaunchKernelGGL((pat_spmv_lds<WT, SHIFT, RV, 1, 256>), dim3(grid), dim3(256), lds, c.stream, row_begin, row_count, A.W, \
                        ntiles, xcd ? 1 : 0, A.npat, (const uint16_t *)A.pat_id, (const int32_t *)A.pat_off,                   \
-                       (const double *)A.pat_re, (const double *)A.pat_im, x, xh, n_own, y, k, g_skip.p, g_skip.it)
+                       (const double *)A.pat_re, (const double *)A.pat_im, x, xh, n_own, y, k, w, g_skip.p, g_skip.it)
 #define PL_V(WT) do { if (A.pat_real) PL(WT, true); else PL(WT, false); } while (0)
         if (A.W == 7) PL_V(7); else PL_V(0);
 #undef PL_V
@@ -703,7 +704,7 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
 #define PT(WT, X, M, RV)                                                                                                       \
     hipLaunchKernelGGL((pat_spmv_rowthread<WT, SHIFT, X, M, RV>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count,    \
                        A.npad, A.W, ntiles, (const uint16_t *)A.pat_id, (const int32_t *)A.pat_off, (const double *)A.pat_re, \
-                       (const double *)A.pat_im, vals, x, xh, n_own, y, k, g_skip.p, g_skip.it)
+                       (const double *)A.pat_im, vals, x, xh, n_own, y, k, w, g_skip.p, g_skip.it)
 #define PT_RV(WT, X, M) do { if (realv) PT(WT, X, M, true); else PT(WT, X, M, false); } while (0)
 #define PT_X(WT, M) do { if (xcd) PT_RV(WT, true, M); else PT_RV(WT, false, M); } while (0)
         if (A.pat_mode == 1) { if (A.W == 7) PT_X(7, 1); else PT_X(0, 1); }
@@ -725,10 +726,10 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     do {                                                                                                                         \
         if (nt)                                                                                                                  \
             hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X, RV, true>), dim3(grid), dim3(256), 0, c.stream, row_begin,      \
-                               row_count, A.npad, A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it);        \
+                               row_count, A.npad, A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);        \
         else                                                                                                                     \
             hipLaunchKernelGGL((ell_spmv_rowthread<WT, SHIFT, X, RV, false>), dim3(grid), dim3(256), 0, c.stream, row_begin,     \
-                               row_count, A.npad, A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it);        \
+                               row_count, A.npad, A.W, ntiles, vals, A.ell_col, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);        \
     } while (0)
         if (A.ell_val_re) {
             if (A.W == 7) { if (xcd) RT(7, true, true); else RT(7, false, true); }
@@ -746,10 +747,10 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     do {                                                                                                                            \
         if (A.ell_val_re)                                                                                                           \
             hipLaunchKernelGGL((ell_spmv_lanes<LL, SHIFT, true>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, \
-                               A.nchunk, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it);                                 \
+                               A.nchunk, vals, A.ell_col, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);                                 \
         else                                                                                                                        \
             hipLaunchKernelGGL((ell_spmv_lanes<LL, SHIFT, false>), dim3(grid), dim3(256), 0, c.stream, row_begin, row_count, A.npad, \
-                               A.nchunk, vals, A.ell_col, x, xh, n_own, y, k, g_skip.p, g_skip.it);                                 \
+                               A.nchunk, vals, A.ell_col, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);                                 \
     } while (0)
         switch (A.L) {
             case 2: LN(2); break;
@@ -764,7 +765,7 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
 }
 
 template <bool SHIFT>
-static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr *dist) {
+static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr *dist, const cplx *w) {
     Context &c = ctx();
     if (A.nrow == 0) return MGCR_OK;
     const cplx *xh = nullptr;
@@ -775,25 +776,26 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
         dist_info(dist, &xh, &ib, &ie);
         n_own = (int32_t)A.nrow;
         MGCR_TRY(dist_halo_begin(dist, x));
-        MGCR_TRY(ell_rows<SHIFT>(A, ib, ie - ib, x, xh, n_own, y, k));
+        MGCR_TRY(ell_rows<SHIFT>(A, ib, ie - ib, x, xh, n_own, y, k, w));
         MGCR_TRY(dist_halo_end(dist));
-        MGCR_TRY(ell_rows<SHIFT>(A, 0, ib, x, xh, n_own, y, k));
-        MGCR_TRY(ell_rows<SHIFT>(A, ie, A.nrow - ie, x, xh, n_own, y, k));
+        MGCR_TRY(ell_rows<SHIFT>(A, 0, ib, x, xh, n_own, y, k, w));
+        MGCR_TRY(ell_rows<SHIFT>(A, ie, A.nrow - ie, x, xh, n_own, y, k, w));
     } else {
-        MGCR_TRY(ell_rows<SHIFT>(A, 0, A.nrow, x, xh, n_own, y, k));
+        MGCR_TRY(ell_rows<SHIFT>(A, 0, A.nrow, x, xh, n_own, y, k, w));
     }
     if (A.n_tail_rows) {
         int64_t threads = A.n_tail_rows * 64;
         hipLaunchKernelGGL((csr_tail_kernel<SHIFT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream,
-                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, g_skip.p, g_skip.it);
+                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);
         MGCR_HIP(hipGetLastError());
     }
     return MGCR_OK;
 }
 
-int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist) {
+int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist, const cplx *w) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
-    return shift ? csr_apply_t<true>(A, x, y, k, dist) : csr_apply_t<false>(A, x, y, k, dist);
+    MGCR_CHECK(!w || (shift && w != y), MGCR_ERR_INVALID, "csr_apply: w needs the shifted form and its own storage");
+    return shift ? csr_apply_t<true>(A, x, y, k, dist, w) : csr_apply_t<false>(A, x, y, k, dist, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
