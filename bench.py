@@ -269,6 +269,15 @@ def main():
                                                       "all-reduces of the iteration (build)")},
         "final_rel_residual": float(hist[-1]),
     }
+    if world > 1:
+        # what the iteration's two all-reduces (4 doubles; 1 + 2 lim doubles) and its halo exchange cost on their own
+        us = ctypes.c_double()
+        comm_us = {}
+        for cnt in (4, 1 + 2 * args.restart):
+            mg.lib().mgcr_comm_bench_allreduce(comm.h, cnt, 50, ctypes.byref(us))
+            comm_us["allreduce_%d_doubles_us" % cnt] = us.value
+        out["comm"] = comm_us
+        out["comm"]["spmv_with_halo_exchange_ms_replay"] = spmv_ms_replay
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(n)

@@ -215,6 +215,9 @@ typedef int (*mgcr_exchange_cb)(void *user, int32_t npeers, const int32_t *peers
 int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgcr_exchange_cb exchange, void *user,
                           mgcr_comm_t *out);
 int mgcr_comm_destroy(mgcr_comm_t comm);
+/* measurement aid (bench.py, N > 1): average microseconds of one in-place device all-reduce of `count` doubles,
+ * issued `reps` times back to back on the library stream (collective: every rank must call it) */
+int mgcr_comm_bench_allreduce(mgcr_comm_t comm, int32_t count, int32_t reps, double *us_avg);
 /* Partition plan of a row block [row0, row0 + nrow_local) of an n_global-row matrix given with
  * GLOBAL column indices: which remote x entries this rank needs (halo), from whom, what it has
  * to send to whom, and where the rows that touch no remote column sit (they can be multiplied

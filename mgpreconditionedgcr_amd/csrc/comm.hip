@@ -547,6 +547,25 @@ int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgc
     return MGCR_OK;
 }
 
+int mgcr_comm_bench_allreduce(mgcr_comm_t c, int32_t count, int32_t reps, double *us_avg) {
+    MGCR_CHECK(c && count > 0 && count <= 64 && reps > 0 && us_avg, MGCR_ERR_INVALID, "mgcr_comm_bench_allreduce: bad argument");
+    MGCR_TRY(require_ctx());
+    Context &cx = ctx();
+    double *d = nullptr;
+    MGCR_HIP(hipMalloc((void **)&d, sizeof(double) * 64));
+    MGCR_HIP(hipMemsetAsync(d, 0, sizeof(double) * 64, cx.stream));
+    int rc = comm_allreduce_dev(c, d, count);  // warm-up
+    MGCR_HIP(hipEventRecord(cx.ev0, cx.stream));
+    for (int i = 0; i < reps && rc == MGCR_OK; i++) rc = comm_allreduce_dev(c, d, count);
+    MGCR_HIP(hipEventRecord(cx.ev1, cx.stream));
+    MGCR_HIP(hipEventSynchronize(cx.ev1));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, cx.ev0, cx.ev1);
+    hipFree(d);
+    *us_avg = 1e3 * (double)ms / reps;
+    return rc;
+}
+
 int mgcr_comm_destroy(mgcr_comm_t c) {
     if (!c) return MGCR_OK;
     if (ctx().ready) {
