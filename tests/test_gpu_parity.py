@@ -562,6 +562,11 @@ def test_error_paths(sample):
         GCR(sample, GCR_Param(3, 3, 10, 1e-8, False))  # Do not support concurrent restarting and truncation.
     with pytest.raises(MgcrError):
         Sparse(2, 2, [0, 1, 2], [0, 5], [1.0, 1.0])  # column out of range
+    with pytest.raises(MgcrError):
+        mg.set_option("no_such_switch", 1)
+    with pytest.raises(MgcrError):
+        GCR(sample, GCR_Param(0, 5, 10, 1e-8, False)).storage_format()  # not a Sparse
+    assert mg.set_option("lean_cycles", 1) in (0, 1) and mg.set_option("fused_apply", 1) in (0, 1)
 
 
 # ------------------------------------------------------------------ edge cases
