@@ -550,7 +550,10 @@ __global__ void __launch_bounds__(256) pat_spmv_rowthread(int64_t row_begin, int
 
 // Same, with the pattern table staged in LDS (one dependent memory round trip less per row: id -> LDS ->
 // gathers; 17.6 against 20.7 us at Poisson 128^3).  MODE 1 only.  R rows per thread with all id loads and
-// gathers in flight together was measured too (R = 2, 4; 256 / 512 threads): no faster than R = 1.
+// gathers in flight together was measured too (R = 2, 4; 256 / 512 threads): no faster than R = 1, warm or
+// cold; nor was staging the workgroup's own 256..1024 entries of x in LDS to serve the +-1 / +-n columns
+// (26 against 25 us cold) — PMC: TA busy 61 %, L2 hit rate 0.61, 90 % of wave cycles waiting; the kernel
+// moves 71 MB in 17 (warm) .. 25 us (cold caches) where a 67 MB copy takes 11.4 us.
 template <int WT, bool SHIFT, bool REALV, int R, int BLK>
 __global__ void __launch_bounds__(BLK) pat_spmv_lds(int64_t row_begin, int64_t row_count, int32_t Wrt, int64_t ntiles, int xcd,
                                                     int32_t npat, const uint16_t *__restrict__ pid,
