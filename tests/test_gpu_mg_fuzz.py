@@ -1,0 +1,96 @@
+"""Seeded random sweep of multigrid hierarchies against the oracle (tests/test_oracle_golden.py pins the
+oracle's aggregates / prolongator / restrict / expand / Galerkin product to the real reference's golden G9):
+meshes of 2..5 dimensions with 1..4 of them blocked, 1..3 near-null vectors with random complex entries,
+1 or 2 coarse levels, operators with random values on random sparsity patterns, with and without the
+DiracOp shift.  The device set-up (mg_setup.hip) must reproduce the oracle's hierarchy BIT FOR BIT (same
+evaluation order, no contraction): aggregate map, Gram-Schmidt'ed prolongator, every entry of every coarse
+operator; restrict is bit-identical too (ascending member order), prolongation to 1e-15, and one corrected
+V-cycle agrees to 1e-9 (its smoothers' dot products are summed in a different order).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+mg = pytest.importorskip("mgpreconditionedgcr_amd")
+from mgpreconditionedgcr_amd import DiracOp, Field, GCR, GCR_Param, MG, MG_Param, Mesh, Sparse, problems  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    mg.init()
+    yield
+
+
+def _dense(apply, n):
+    out = np.empty((n, n), np.complex128)
+    for c in range(n):
+        e = np.zeros(n, np.complex128)
+        e[c] = 1.0
+        out[:, c] = apply(e)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_hierarchy_vs_oracle(seed):
+    rng = np.random.default_rng(500 + seed)
+    sub = 2
+    nlevel = int(rng.choice([1, 2]))
+    ndim = int(rng.integers(2, 6))
+    blocked = np.zeros(ndim, np.int32)
+    nblocked = int(rng.integers(1, min(4, ndim) + 1))
+    blocked[rng.choice(ndim, size=nblocked, replace=False)] = 1
+    # blocked dimensions must be divisible by sub^nlevel; keep the mesh small (dense views of the coarse operators)
+    dims = [int(sub ** nlevel * rng.integers(1, 3)) if blocked[d] else int(rng.integers(1, 4)) for d in range(ndim)]
+    N = int(np.prod(dims))
+    if N < 8 or N > 1500:
+        pytest.skip("mesh of %d points" % N)
+    ne = int(rng.integers(1, 4))
+    rowptr, col, val = problems.random_csr(N, N, rng, min_len=1, max_len=6)
+    # dominant diagonal appended to every row (the smoothers / coarsest solve then converge)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    rowsum = np.bincount(rows, weights=np.abs(val), minlength=N)
+    newptr = rowptr + np.arange(N + 1)
+    ncol_arr, nval = np.empty(newptr[-1], np.int64), np.empty(newptr[-1], np.complex128)
+    for r in range(N):
+        s, e = rowptr[r], rowptr[r + 1]
+        ncol_arr[newptr[r]:newptr[r] + (e - s)] = col[s:e]
+        nval[newptr[r]:newptr[r] + (e - s)] = val[s:e]
+        ncol_arr[newptr[r + 1] - 1] = r
+        nval[newptr[r + 1] - 1] = 2.0 * rowsum[r] + 1.0
+    rowptr, col, val = newptr, ncol_arr, nval
+    vecs = rng.standard_normal((ne, N)) + 1j * rng.standard_normal((ne, N))
+    shift = complex(rng.uniform(0.02, 0.08), rng.uniform(-0.03, 0.03)) if rng.random() < 0.4 else None
+
+    smo, coo = orc.gcr_param(restart=10, max_iter=2, tol=1e-30), orc.gcr_param(restart=10, max_iter=40, tol=1e-3)
+    Ao = orc.csr(N, N, rowptr, col, val)
+    if shift is not None:
+        Ao = orc.dirac(Ao, shift)
+    Mo = orc.MG(Ao, rowptr, col, val, dims, blocked, sub, vecs, nlevel + 1, smo, coo, shift=shift)
+
+    A0 = Sparse(N, N, rowptr, col, val)
+    A = DiracOp(A0, shift) if shift is not None else A0
+    prm = MG_Param(Mesh(dims), sub, ne, None, GCR(GCR_Param(0, 10, 40, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   nlevel, None, None, spacetime=[bool(b) for b in blocked], null_vectors=vecs)
+    M = MG(A, prm)
+    what = "dims=%s blocked=%s ne=%d levels=%d shift=%s" % (dims, blocked.tolist(), ne, nlevel, shift)
+    for l in range(nlevel):
+        pv, agg = M.prolongator(l)
+        pvo, aggo = Mo.prolongator(l)
+        assert np.array_equal(agg, aggo), what
+        assert np.array_equal(pv, pvo), what
+    for l in range(1, nlevel + 1):
+        nc = M.level_info(l)["dim"]
+        assert nc == Mo.level_dim(l), what
+        Ac, Aco = M.level_operator(l), Mo.level_op(l)
+        assert np.array_equal(_dense(lambda e: Ac(Field((nc,), e)).to_numpy(), nc), _dense(lambda e: Aco(e), nc)), what
+    v = problems.rhs_grid(N, 7)
+    Rv = M.restrict(Field(tuple(dims), v))
+    Rvo = Mo.restrict(0, v)
+    assert np.array_equal(Rv.to_numpy(), Rvo), what
+    PRv = M.expand(Rv).to_numpy()
+    assert np.abs(PRv - Mo.expand(0, Rvo)).max() <= 1e-15 * max(np.abs(PRv).max(), 1.0), what
+    y = M(Field(tuple(dims), v)).to_numpy()
+    yo = Mo(v)
+    assert np.abs(y - yo).max() <= 1e-9 * np.abs(yo).max(), what
