@@ -250,25 +250,23 @@ __global__ void advance_kernel(DevState *st, int by) { st->base += by; }
 // load in flight cannot cover HBM latency, even at 32 waves per CU).
 template <int NDT, int U>
 __global__ void __launch_bounds__(RED_THREADS, (NDT <= 6 ? 8 : 4)) multidot_kernel(const DevState *__restrict__ st, int it, const cplx *__restrict__ ar,
-                                                               DirPtrs d, int base, int64_t n,
+                                                               DirPtrs d, int base, int64_t n, RowMap rm,
                                                                double *__restrict__ partsB) {
     __shared__ double lds[2 * NDT * 17];
     if (st->stop_at < st->base + it) return;
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
-    // grid-stride: trip k of workgroup b covers rows (k * gridDim.x + b) * RED_THREADS ..., so at any moment
-    // the whole machine sweeps one contiguous window of every stream (a contiguous chunk per workgroup was
-    // measured 9 % slower at 128^3: 512 workgroups then walk 512 separate 16-KiB-wide fronts).  The row ->
-    // (workgroup, thread, trip) map is shared with gcr_fused.hip's step_apply_kernel, so that either
-    // kernel yields the same partial sums.
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+    // rows of this workgroup's threads: RowMap (gcr_dev.h), shared with gcr_fused.hip's step_apply_kernel so that
+    // either kernel yields the same partial sums
+    int64_t first, end, step;
+    row_range(rm, (int)blockIdx.x, (int)gridDim.x, n, &first, &end, &step);
+    for (int64_t i0 = first; i0 < end; i0 += step * U) {
         cplx a[U], b[U][NDT];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t i = i0 + u * stride;
-            if (i < n) {
+            const int64_t i = i0 + u * step;
+            if (i < end) {
                 a[u] = ar[i];
 #pragma unroll
                 for (int j = 0; j < NDT; j++) b[u][j] = ld_stream<NTS>(d.aps[j] + i);
@@ -813,8 +811,9 @@ struct SkipGuard {
     ~SkipGuard() { set_apply_skip(prev); }
 };
 
-static int launch_multidot(int g, int nd, const DevState *st, int it, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB) {
-#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, partsB)
+static int launch_multidot(int g, int nd, const DevState *st, int it, const cplx *ar, const DirPtrs &d, int base, int64_t n, double *partsB,
+                           const RowMap &rm) {
+#define MD(NDT, U) KLAUNCH((multidot_kernel<NDT, U>), g, st, it, ar, d, base, n, rm, partsB)
     switch (nd) {
         case 1: MD(1, 2); break;
         case 2: MD(2, 2); break;
@@ -1087,6 +1086,13 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     int check_every = p.check_every > 0 ? p.check_every : 10;
     const cplx *rcur = alias0 ? rhs : s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
     // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
+    // row -> workgroup map of the dot-product kernels (gcr_dev.h): depends on how far the operator's rows reach
+    int64_t reach = 0;
+    {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        if (b0 && b0->kind == OP_CSR) reach = b0->csr.reach;
+    }
+    const RowMap rmap = make_row_map(n, g, reach);
     bool fuse_ok = false;
     if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !p.left_precond) {
         const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
@@ -1157,7 +1163,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             const cplx *vecs[ND];
             for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < nf ? j : 0];
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
-            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist));
+            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist, rmap));
             ch0 = 1;
         } else {
             MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
@@ -1173,7 +1179,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 int sl = ch * ND + (j < nd ? j : 0);
                 d.ps[j] = s->ps[sl]; d.aps[j] = s->aps[sl]; d.slot[j] = sl;
             }
-            MGCR_TRY(launch_multidot(g, nd, cst, it, (const cplx *)s->ar, d, ch * ND, n, s->partsB));
+            MGCR_TRY(launch_multidot(g, nd, cst, it, (const cplx *)s->ar, d, ch * ND, n, s->partsB, rmap));
         }
         MGCR_TRY(mark());
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};

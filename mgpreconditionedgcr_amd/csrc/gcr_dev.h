@@ -44,6 +44,46 @@ struct LeanCoef {
 };
 
 
+// Row -> (workgroup, thread, trip) map shared by multidot_kernel (gcr.hip) and step_apply_kernel (gcr_fused.hip), so
+// that either yields the same partial sums.  Banded (grids that are a multiple of 8 workgroups): the rows are cut
+// into 8 contiguous bands, one per XCD; the `per` logical workgroups of a band sweep it together, per * RED_THREADS
+// rows per trip.  Every XCD then walks consecutive planes of a stencil operand over time and finds the previous
+// ones in ITS L2 — with a plain grid-stride the 8 XCDs work on 8 adjacent slices per trip and each slice's
+// neighbours are fetched by three L2s (measured at 256^3: 1.73 GB of HBM traffic for an 0.84 GB launch).
+// Not banded (small grids): plain grid-stride.
+struct RowMap {
+    int64_t band;  // rows per band (multiple of RED_THREADS); 0 = not banded
+    int per;       // logical workgroups per band
+};
+// `reach` = how far a row's gathers go (CsrDev::reach; 0 = unknown).  Banding pays when that is a sizeable part of
+// what one XCD covers per trip of a plain grid-stride (Poisson 256^3: 65536 of 65536 rows — 1 170 against 1 130 it/s);
+// when the neighbours mostly stay inside the XCD's slice anyway (128^3: 16384 of 65536) the single sweep front of
+// the plain map is faster (9.8 k against 9.4 k it/s).
+inline RowMap make_row_map(int64_t n, int g, int64_t reach) {
+    RowMap m{0, 0};
+    const int64_t slice = (int64_t)g * RED_THREADS / 8;
+    const bool wide = reach > 0 ? 2 * reach >= slice : n >= ((int64_t)1 << 23);
+    if (g >= 64 && g % 8 == 0 && wide) {
+        m.per = g / 8;
+        m.band = ((n + 7) / 8 + RED_THREADS - 1) / RED_THREADS * RED_THREADS;
+    }
+    return m;
+}
+// first row, one-past-last row and step of logical workgroup lb's thread
+__device__ __forceinline__ void row_range(const RowMap &m, int lb, int nlogical, int64_t n, int64_t *first, int64_t *end, int64_t *step) {
+    if (m.band) {
+        const int64_t xb = lb / m.per;
+        *first = xb * m.band + (int64_t)(lb % m.per) * RED_THREADS + threadIdx.x;
+        const int64_t e = (xb + 1) * m.band;
+        *end = e < n ? e : n;
+        *step = (int64_t)m.per * RED_THREADS;
+    } else {
+        *first = (int64_t)lb * RED_THREADS + threadIdx.x;
+        *end = n;
+        *step = (int64_t)nlogical * RED_THREADS;
+    }
+}
+
 // x += alpha p_slot, recorded in terms of P0 and D_1..D_slot (one thread)
 __device__ __forceinline__ void lean_pending_update(LeanCoef *lc, int slot, cplx alpha) {
     if (slot == 0) {

@@ -4,7 +4,7 @@
 // not read back from HBM and the SpMV's dependent id -> table -> gather chain overlaps with the Aps_j
 // streams (Poisson 128^3: 36.8 us against 21.9 + 22.6 us for the two kernels).
 //
-// Same launch shape as gcr.hip's multidot kernel (grid-stride over RED_THREADS-wide workgroups,
+// Same launch shape as gcr.hip's multidot kernel (RED_THREADS-wide workgroups, rows dealt by the shared RowMap,
 // per-thread accumulation in ascending row order, block_sum_bcast) and the same per-row arithmetic as the
 // SpMV kernels (spmv_dev.h): Ar AND the partial sums have the bits the separate kernels produce
 // (tests/test_gpu_parity.py::test_fused_apply_and_dots_same_bits).  Workgroups are renumbered so that
@@ -18,7 +18,9 @@
 // LDS to serve the +-1 / +-n neighbours: slower still (two barriers per trip); temporal instead of
 // non-temporal loads of the Aps_j so that build_* finds them in the Infinity Cache: no gain; one contiguous
 // chunk of rows per workgroup instead of grid-stride (x then crosses XCD bands less: 123 instead of 134 MB
-// of HBM traffic per launch by PMC): 9 % slower — 512 separate 16-KiB-wide fronts instead of one sweep.
+// of HBM traffic per launch by PMC): 9 % slower — 512 separate 16-KiB-wide fronts instead of one sweep.  What
+// does pay, for operators whose rows reach far (256^3), is one band per XCD swept by its workgroups together:
+// RowMap in gcr_dev.h.
 #include "internal.h"
 #include "reduce.h"
 #include "spmv_dev.h"
@@ -32,8 +34,8 @@ struct DotVecs {
 
 template <int MODE, int WT, int NDT>
 __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
-                                                                 DotVecs d, int64_t n, int nlogical, double *__restrict__ parts,
-                                                                 const int *__restrict__ skip, int skip_it) {
+                                                                 DotVecs d, int64_t n, int nlogical, RowMap rm,
+                                                                 double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
     __shared__ double lds[2 * NDT * 17];
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     if (skip && skip[0] < skip[1] + skip_it) return;
@@ -42,19 +44,19 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
     const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (lb >= nlogical) return;
     const int32_t W = WT ? WT : m.W;
-    // grid-stride over logical workgroups (= multidot_kernel's row -> (workgroup, thread, trip) map)
-    const int64_t stride = (int64_t)nlogical * RED_THREADS;
-    int64_t i = (int64_t)lb * RED_THREADS + threadIdx.x;
+    // rows of this logical workgroup's threads: RowMap (gcr_dev.h), the map multidot_kernel uses
+    int64_t i, end, stride;
+    row_range(rm, lb, nlogical, n, &i, &end, &stride);
     int32_t t0 = 0;
-    if (MODE != 0 && i < n) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    if (MODE != 0 && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
     PatLds pl{nullptr, nullptr, nullptr};
     if (MODE == 1) pl = stage_patterns(m, step_smem);
     double v[2 * NDT];
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
-    for (; i < n; i += stride) {
+    for (; i < end; i += stride) {
         int32_t t0_next = 0;
-        if (MODE != 0 && i + stride < n) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
+        if (MODE != 0 && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
         const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
         const cplx yi = m.shift ? csub(x[i], cmul(m.k, sum)) : sum;
         y[i] = yi;
@@ -103,10 +105,10 @@ bool csr_fusable(const CsrDev &A, const DistCsr *dist) {
 
 template <int MODE, int WT>
 static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *x, cplx *y, const DotVecs &d, int64_t n,
-                      int g, double *parts, SkipRef sk) {
+                      int g, double *parts, SkipRef sk, const RowMap &rm) {
 #define SK(NDT)                                                                                                          \
     hipLaunchKernelGGL((step_apply_kernel<MODE, WT, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
-                       g, parts, sk.p, sk.it)
+                       g, rm, parts, sk.p, sk.it)
     switch (nd) {
         case 1: SK(1); break;
         case 2: SK(2); break;
@@ -123,7 +125,7 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
 // y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= ND, laid out like gcr.hip's partsB;
 // dist: A is this rank's row block, the halo exchange of x is enqueued first
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
-                   DistCsr *dist) {
+                   DistCsr *dist, const RowMap &rm) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
     MGCR_CHECK(nd >= 1 && nd <= ND, MGCR_ERR_INVALID, "csr_step_apply: 1..8 vectors");
     RowMat m = row_mat(A, shift, k);
@@ -142,8 +144,8 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
     const SkipRef sk = get_apply_skip();
 #define ST_W(MODE)                                                                              \
     do {                                                                                        \
-        if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk); \
-        else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk);          \
+        if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm); \
+        else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm);          \
     } while (0)
     if (A.pat_mode == 1) ST_W(1);
     else if (A.pat_mode == 2) ST_W(2);

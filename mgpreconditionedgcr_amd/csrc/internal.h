@@ -90,6 +90,7 @@ struct CsrDev {
     int32_t *pat_off = nullptr;   // [npat][W]
     double *pat_re = nullptr, *pat_im = nullptr;  // [npat][W], mode 1
     bool pat_real = false;        // mode 1: every imaginary part is zero
+    int64_t reach = 0;            // max |column - row| over the pattern table (0: unknown) — how far a row's gathers go
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]
@@ -149,8 +150,9 @@ bool set_fuse_enabled(bool on);
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr, const cplx *w = nullptr);
 // SpMV fused with <y, v_j> partials (gcr_fused.hip); parts laid out like gcr.hip's partsB, red_grid(nrow) partials each
 bool csr_fusable(const CsrDev &A, const DistCsr *dist);
+struct RowMap;  // gcr_dev.h
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
-                   DistCsr *dist);
+                   DistCsr *dist, const RowMap &rm);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
                       const double *h_blocks, BcsrDev *out);
 void bcsr_free(BcsrDev *b);

@@ -324,6 +324,11 @@ static int pat_try(CsrDev &A, bool *ok) {
         if (rc != MGCR_OK) set_error("pattern dictionary kernels failed");
         return done(rc);
     }
+    {   // how far the gathers of a row reach (decides the row -> workgroup map of the GCR step kernels, gcr_dev.h)
+        std::vector<int32_t> h_off((size_t)npat * A.W);
+        if (hipMemcpy(h_off.data(), off, sizeof(int32_t) * h_off.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int32_t o : h_off) A.reach = std::max<int64_t>(A.reach, o < 0 ? -(int64_t)o : (int64_t)o);
+    }
     A.pat_mode = VALS ? 1 : 2;
     A.npat = npat;
     A.pat_id = pid; A.pat_off = off; A.pat_re = re; A.pat_im = im;
