@@ -114,8 +114,14 @@ def main():
             gcr = GCR(A, GCR_Param(0, 5, 20, 0.0, False, check_every=20))
             timed_solve(mg, gcr, rhs, x)
             x.set_zero()
-            gcr = GCR(A, GCR_Param(0, 5, iters, 0.0, False, check_every=iters, profile_spmv=True))
-            dt = timed_solve(mg, gcr, rhs, x)
+            prm = GCR_Param(0, 5, iters, 0.0, False, check_every=iters)
+            gcr = GCR(A, prm)
+            timed_solve(mg, gcr, rhs, x)          # allocates the work vectors
+            x.set_zero()
+            dt = timed_solve(mg, gcr, rhs, x)     # the timed solve: no events in the loop
+            x.set_zero()
+            prm.profile_spmv = True
+            timed_solve(mg, gcr, rhs, x)          # a third one with hipEvents between the phases
             ph, na, fu = (ctypes.c_double * 3)(), ctypes.c_int32(), ctypes.c_int32()
             mg.lib().mgcr_gcr_last_profile(ph, ctypes.byref(na), ctypes.byref(fu))
             ms = ctypes.c_double(ph[1] / max(na.value, 1))   # operator apply (+ beta dots when fused)
