@@ -101,14 +101,17 @@ int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width
  * holding column offsets and values, 2 row-pattern dictionary for the columns + value slab;
  * *n_patterns = dictionary size (0 for format 0) */
 int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
-/* Implementation switches (all default on; each also has an environment variable read at first use).
+/* Implementation switches (default on unless noted; each also has an environment variable read at first use).
  * They select between code paths that compute the same thing; tests use them to compare the paths.
  *   "pattern_storage" ($MGCR_PATTERNS): try the row-pattern dictionary for every Sparse of >= 2^15 rows
  *                      created while it is on;
  *   "lean_cycles"     ($MGCR_LEAN): restart-mode GCR keeps residuals instead of search directions inside
  *                      a restart cycle (same r, Ap and scalars; x differs by rounding);
  *   "fused_apply"     ($MGCR_FUSE): GCR on a Sparse / DiracOp runs the SpMV and the beta dot
- *                      products of its result as one kernel (same bits as the two kernels).
+ *                      products of its result as one kernel (same bits as the two kernels);
+ *   "graph_replay"    ($MGCR_GRAPH, default OFF): restart cycles of systems of <= 2^18 rows are captured in a
+ *                      hipGraph once and replayed (same kernels, same results; measured slower than eager
+ *                      launches since the iteration shrank to 3 kernels, see gcr.hip).
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);
 

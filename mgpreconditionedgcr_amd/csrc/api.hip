@@ -137,6 +137,7 @@ int mgcr_set_option(const char *name, int value, int *previous) {
     if (!strcmp(name, "pattern_storage")) prev = set_patterns_enabled(value != 0);
     else if (!strcmp(name, "lean_cycles")) prev = set_lean_enabled(value != 0);
     else if (!strcmp(name, "fused_apply")) prev = set_fuse_enabled(value != 0);
+    else if (!strcmp(name, "graph_replay")) prev = set_graph_enabled(value != 0);
     else { set_error("mgcr_set_option: unknown option '%s'", name); return MGCR_ERR_INVALID; }
     if (previous) *previous = prev ? 1 : 0;
     return MGCR_OK;

@@ -99,9 +99,16 @@ struct GcrState {
 
 constexpr int64_t GRAPH_MAX_ROWS = 1 << 18;
 
+static int g_graph = -1;
 static bool graphs_enabled() {
-    static const bool on = !(getenv("MGCR_GRAPH") && atoi(getenv("MGCR_GRAPH")) == 0);
-    return on;
+    // opt-in (MGCR_GRAPH=1 / mgcr_set_option("graph_replay")): see the measurements at the capture site in gcr_run
+    if (g_graph < 0) g_graph = getenv("MGCR_GRAPH") && atoi(getenv("MGCR_GRAPH")) != 0;
+    return g_graph != 0;
+}
+bool set_graph_enabled(bool on) {
+    bool prev = graphs_enabled();
+    g_graph = on ? 1 : 0;
+    return prev;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1230,11 +1237,13 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         return MGCR_OK;
     };
 
-    // hipGraph: in restart mode every cycle of R iterations is the same launch sequence with the same
-    // arguments (iteration numbers are base-relative, base lives on the device), so one cycle is
-    // captured once and replayed.  Measured on MI355X: +11 % iterations/s on the 3072-row sample
-    // (launch-bound: 4 kernels of a few microseconds per iteration), -1.8 % at 128^3 where the eager
-    // launches are already hidden behind 15-100 us kernels — hence the size gate.
+    // hipGraph (opt-in, MGCR_GRAPH=1): in restart mode every cycle of R iterations is the same launch sequence with the
+    // same arguments (iteration numbers are base-relative, base lives on the device), so one cycle can be captured once
+    // and replayed.  Measured on MI355X: +11 % iterations/s on the 3072-row sample while an iteration was 4 launches;
+    // since it shrank to 3 (fused apply + dots) replay no longer pays at any size — eager launches run 1-4 % FASTER
+    // from 512 to 1.4 M rows (e.g. 64^3: 33.6 k against 32.3 k it/s), equal on the sample: the loop is bound by the
+    // GPU-side dependency between consecutive short kernels (~8 us each), not by the host's launch cost.  Hence off
+    // by default, and gated to <= 2^18 rows when on.
     const int R = s->restart;
     bool use_graph = graphs_enabled() && n <= GRAPH_MAX_ROWS && defer && !multi && !p.left_precond && !p.right_precond &&
                      !p.profile_spmv && max_it >= 2 * R && R <= s->storage;

@@ -145,6 +145,7 @@ void csr_free(CsrDev *c);
 bool set_patterns_enabled(bool on);
 bool set_lean_enabled(bool on);
 bool set_fuse_enabled(bool on);
+bool set_graph_enabled(bool on);
 // y = A x   or (shift) y = w - k*(A x) with w = x unless given (w = b, k = 1: the residual b - A x in one pass);
 // dist != nullptr: row block with halo exchange
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr, const cplx *w = nullptr);

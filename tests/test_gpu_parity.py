@@ -457,6 +457,27 @@ def test_fused_apply_and_dots_same_bits(fmt, mode):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+def test_graph_replay_same_results():
+    """Restart cycles captured in a hipGraph and replayed (opt-in) enqueue the same kernels with the same
+    arguments: history and x are bit-identical to the eager launches, for lean cycles of 5 and 10 slots."""
+    n1 = 20
+    n, ncol, rowptr, col, val = problems.poisson3d_csr(n1)
+    A = Sparse(n, ncol, rowptr, col, val * (1.0 + 0.25j))
+    b = Field((n,), problems.rhs_grid(n, 2))
+    for restart in (5, 10):
+        out = []
+        for on in (1, 0):
+            prev = mg.set_option("graph_replay", on)
+            try:
+                g = GCR(A, GCR_Param(0, restart, 73, 1e-30, False, check_every=7))
+                x = Field((n,)).set_zero()
+                g.solve(b, x)
+            finally:
+                mg.set_option("graph_replay", prev)
+            out.append((g.last_history.copy(), x.to_numpy()))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_gcr_vs_oracle_random_nonhermitian():
     """Seeded diagonally dominant complex matrix, every mode, against the CPU oracle."""
     rng = np.random.default_rng(42)
