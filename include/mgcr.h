@@ -68,6 +68,9 @@ int mgcr_add_scaled(mgcr_vec_t out, mgcr_vec_t a, const double alpha_ri[2], mgcr
 int mgcr_axpy(const double alpha_ri[2], mgcr_vec_t x, mgcr_vec_t y); /* y += alpha*x  (+=  :288-297) */
 int mgcr_scale(mgcr_vec_t v, const double alpha_ri[2]);            /* operator*          :245-253 */
 int mgcr_normalise(mgcr_vec_t v);                                  /* normalise          :237-243 */
+/* gamma5 :310-339  out[index with spinor 0<->2, 1<->3] = in[index]; `inner` = product of the mesh dimensions after the
+ * (4-entry) spinor dimension */
+int mgcr_vec_gamma5(mgcr_vec_t in, mgcr_vec_t out, int64_t inner);
 
 /* ---- Operators: src/Operator.h, src/HierarchicalSparse.h ---------------------------------- */
 /* Sparse<long> (CSR, int64 indices as the reference stores them, src/Operator.h:56-101).  The

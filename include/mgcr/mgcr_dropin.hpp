@@ -186,17 +186,13 @@ public:
     void normalise() { to_device(); mgcr_detail::ok(mgcr_normalise(h), "normalise"); dev_only(); }
     Field gamma5(int spinor_index) const {  // :310-339: output[index with spinor 0<->2, 1<->3] = field[i]
         Field o(mesh);
-        to_host();
-        o.host.assign(host.size(), std::complex<double>(0., 0.));
         const num_type *d = mesh.get_dims();
-        for (num_type i = 0; i < field_size(); i++) {
-            num_type *idx = mesh.alloc_loc_ind(i);
-            static const num_type perm[4] = {2, 3, 0, 1};
-            idx[spinor_index] = perm[idx[spinor_index]];
-            o.host[(size_t)Mesh<num_type>::ind_loc(idx, d, mesh.get_ndim())] = host[(size_t)i];
-            delete[] idx;
-        }
-        o.host_valid = true; o.dev_valid = false;
+        if (d[spinor_index] != 4) { std::fprintf(stderr, "gamma5: the spinor dimension must have 4 entries\n"); std::abort(); }
+        long long inner = 1;
+        for (int k = spinor_index + 1; k < (int)mesh.get_ndim(); k++) inner *= (long long)d[k];
+        to_device();
+        mgcr_detail::ok(mgcr_vec_gamma5(h, o.h, inner), "gamma5");
+        o.dev_only();
         return o;
     }
     // device handle (synchronised); used by the operator wrappers

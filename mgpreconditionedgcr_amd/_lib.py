@@ -67,6 +67,7 @@ _SIGS = {
     "mgcr_axpy": (C.c_int, [_dp, _vp, _vp]),
     "mgcr_scale": (C.c_int, [_vp, _dp]),
     "mgcr_normalise": (C.c_int, [_vp]),
+    "mgcr_vec_gamma5": (C.c_int, [_vp, _vp, C.c_int64]),
     "mgcr_csr_create": (C.c_int, [C.c_int64, C.c_int64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "mgcr_dirac_create": (C.c_int, [_vp, _dp, C.POINTER(_vp)]),
     "mgcr_dirac_set_k": (C.c_int, [_vp, _dp]),

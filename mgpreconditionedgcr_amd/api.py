@@ -135,6 +135,15 @@ class Field:
         check(_lib.lib().mgcr_normalise(self.h))
         return self
 
+    def gamma5(self, spinor_index=4):  # src/Fields.h:310-339
+        """New Field with the spinor components swapped 0<->2, 1<->3 (on the device)."""
+        if self.dims[spinor_index] != 4:
+            raise ValueError("gamma5: dimension %d of the mesh has %d entries, not 4" % (spinor_index, self.dims[spinor_index]))
+        inner = int(np.prod(self.dims[spinor_index + 1:], dtype=np.int64))
+        out = Field(self.dims)
+        check(_lib.lib().mgcr_vec_gamma5(self.h, out.h, inner))
+        return out
+
     def __del__(self):
         try:
             if getattr(self, "h", None):
@@ -328,28 +337,24 @@ class Mesh:
 
 
 def gamma5(field_values, dims, spinor_index=4):
-    """Field::gamma5 (src/Fields.h:310-339): output[index with spinor 0<->2, 1<->3] = field[i]."""
-    v = np.asarray(field_values, c128).reshape(dims)
-    out = np.empty_like(v)
-    perm = [2, 3, 0, 1]
-    for s_ in range(4):
-        dst = [slice(None)] * len(dims)
-        src = [slice(None)] * len(dims)
-        dst[spinor_index] = perm[s_]
-        src[spinor_index] = s_
-        out[tuple(dst)] = v[tuple(src)]
-    return out.reshape(-1)
+    """Field::gamma5 (src/Fields.h:310-339) of host values: output[index with spinor 0<->2, 1<->3] = field[i]
+    (computed on the device: Field.gamma5)."""
+    return Field(tuple(dims), np.asarray(field_values, c128).reshape(-1)).gamma5(spinor_index).to_numpy()
+
+
+def _vec_double_fields(fields, spinor_index):
+    plus, minus = [], []
+    for v in fields:
+        g = v.gamma5(spinor_index)
+        plus.append((v + g) * 0.5)
+        minus.append((v - g) * 0.5)
+    return plus + minus
 
 
 def vec_double(vecs, dims, spinor_index=4):
-    """MG::vec_double (src/MG.h:316-345): [v+ ..., v- ...] with v+- = (v +- gamma5 v) * 0.5."""
-    plus, minus = [], []
-    for v in vecs:
-        v = np.asarray(v, c128).reshape(-1)
-        g = gamma5(v, dims, spinor_index)
-        plus.append((v + g) * 0.5)
-        minus.append((v - g) * 0.5)
-    return np.array(plus + minus)
+    """MG::vec_double (src/MG.h:316-345): [v+ ..., v- ...] with v+- = (v +- gamma5 v) * 0.5, on the device."""
+    fields = [Field(tuple(dims), np.asarray(v, c128).reshape(-1)) for v in vecs]
+    return np.array([f.to_numpy() for f in _vec_double_fields(fields, spinor_index)])
 
 
 class MG_Param:
@@ -407,17 +412,17 @@ class MG(Operator):
             x.set_zero()
             gcr.solve(b, x)
             b.assign(x).normalise()
-        vecs = [b.to_numpy()]
+        vecs = [b.copy()]
         for count in range(1, prm.n_eigen):
             x.set_zero()
-            gcr.solve(Field(dims, vecs[-1]), x)
-            t = x.to_numpy()
-            for v in vecs:
-                t = t - v * np.vdot(v, t)
-            vecs.append(t / np.linalg.norm(t))
+            gcr.solve(vecs[-1], x)
+            t = x.copy()
+            for v in vecs:       # Gram-Schmidt against the vectors found so far (src/MG.h:112-118), Field algebra on the device
+                t = t - v * v.dot(t)
+            vecs.append(t.normalise())
         if any(prm.spinor):
-            return vec_double(vecs, dims, prm.spinor.index(True))
-        return np.array(vecs)
+            vecs = _vec_double_fields(vecs, prm.spinor.index(True))
+        return np.array([v.to_numpy() for v in vecs])
 
     def initialise(self, M):  # src/MG.h:131-285
         _lib.init()

@@ -56,6 +56,15 @@ __global__ void __launch_bounds__(RED_THREADS) scale_kernel(cplx *v, cplx alpha,
     GRID_STRIDE(i, n) v[i] = cmul(alpha, v[i]);
 }
 
+// Field::gamma5 (src/Fields.h:310-339): out[index with spinor 0<->2, 1<->3] = in[index]; the spinor dimension has 4
+// entries and `inner` = the product of the dimensions after it (row-major index algebra of src/Mesh.h:156-165)
+__global__ void __launch_bounds__(RED_THREADS) gamma5_kernel(cplx *__restrict__ out, const cplx *__restrict__ in, int64_t n, int64_t inner) {
+    GRID_STRIDE(i, n) {
+        const int64_t s = (i / inner) & 3;  // spinor index of element i
+        out[i + ((s ^ 2) - s) * inner] = in[i];
+    }
+}
+
 // partial sums of conj(a_i) b_i  ->  parts[0][blk] (re), parts[1][blk] (im)
 __global__ void __launch_bounds__(RED_THREADS) dot_partials_kernel(const cplx *__restrict__ a, const cplx *__restrict__ b,
                                                                   int64_t n, double *__restrict__ parts) {
@@ -132,6 +141,11 @@ int k_fill_rhs(cplx *dst, int64_t n, uint64_t seed, int64_t offset) {
 int k_add_scaled(cplx *out, const cplx *a, cplx alpha, const cplx *b, int64_t n) {
     if (n == 0) return MGCR_OK;
     LAUNCH(add_scaled_kernel, red_grid(n), out, a, alpha, b, n);
+    return MGCR_OK;
+}
+int k_gamma5(cplx *out, const cplx *in, int64_t n, int64_t inner) {
+    if (n == 0) return MGCR_OK;
+    LAUNCH(gamma5_kernel, red_grid(n), out, in, n, inner);
     return MGCR_OK;
 }
 int k_scale(cplx *v, cplx alpha, int64_t n) {

@@ -255,6 +255,14 @@ int mgcr_scale(mgcr_vec_t v, const double alpha_ri[2]) {
     return k_scale(v->d, make_double2(alpha_ri[0], alpha_ri[1]), v->n);
 }
 
+int mgcr_vec_gamma5(mgcr_vec_t in, mgcr_vec_t out, int64_t inner) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(in && out && in != out && in->n == out->n, MGCR_ERR_INVALID, "mgcr_vec_gamma5: two distinct fields of one size");
+    MGCR_CHECK(inner >= 1 && in->n % (4 * inner) == 0, MGCR_ERR_INVALID, "mgcr_vec_gamma5: the spinor dimension must have 4 entries");
+    LOCK();
+    return k_gamma5(out->d, in->d, in->n, inner);
+}
+
 int mgcr_normalise(mgcr_vec_t v) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(v, MGCR_ERR_INVALID, "mgcr_normalise: null argument");

@@ -132,6 +132,7 @@ int k_set_constant(cplx *dst, cplx c, int64_t n);
 int k_fill_rhs(cplx *dst, int64_t n, uint64_t seed, int64_t offset);
 int k_add_scaled(cplx *out, const cplx *a, cplx alpha, const cplx *b, int64_t n);  // out = a + alpha*b
 int k_scale(cplx *v, cplx alpha, int64_t n);
+int k_gamma5(cplx *out, const cplx *in, int64_t n, int64_t inner);
 // generic reductions into a partial slab, then fold to `out` (device, nscal cplx) by a 1-block kernel
 int k_dot_partials(const cplx *a, const cplx *b, int64_t n, double *parts /*[2][RED_MAX_BLOCKS]*/, int *nblk);
 int k_fold(const double *parts, int nblk, int nscal, double *out_dev);

@@ -196,3 +196,27 @@ def test_device_setup_bit_identical_to_oracle(kind, sample_matrix_path, mg_gold)
         dense = _dense(Ac, nc, lambda op, e: op(Field((nc,), e)).to_numpy())
         dense_o = _dense(Mo.level_op(l), nc, lambda op, e: op(e))
         assert np.array_equal(dense, dense_o)
+
+
+def test_gamma5_and_vec_double_on_device():
+    """Field::gamma5 (src/Fields.h:310-339) and MG::vec_double (src/MG.h:316-345) run on the device; against
+    the index formulation of the reference written with numpy slices — pure data movement and (v +- g) * 0.5,
+    hence identical bits."""
+    rng = np.random.default_rng(3)
+    for dims, s_ in (((4, 4, 4, 4, 4, 3), 4), ((3, 4, 5), 1), ((4,), 0), ((2, 2, 4), 2)):
+        n = int(np.prod(dims))
+        v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        ref = np.empty(dims, np.complex128)
+        perm = [2, 3, 0, 1]
+        for a in range(4):
+            dst, src = [slice(None)] * len(dims), [slice(None)] * len(dims)
+            dst[s_], src[s_] = perm[a], a
+            ref[tuple(dst)] = v.reshape(dims)[tuple(src)]
+        ref = ref.reshape(-1)
+        assert np.array_equal(Field(dims, v).gamma5(s_).to_numpy(), ref)
+        assert np.array_equal(mg.gamma5(v, dims, s_), ref)
+        d = vec_double([v], dims, s_)
+        assert d.shape == (2, n)
+        assert np.array_equal(d[0], (v + ref) * 0.5) and np.array_equal(d[1], (v - ref) * 0.5)
+    with pytest.raises(ValueError):
+        Field((3, 3)).gamma5(1)
