@@ -35,8 +35,10 @@ def load(d, counter):
 def phase_of(name):
     if name.startswith("xr_update_kernel"):
         return "xr"
-    if name.startswith(("step_apply_kernel", "pat_spmv", "ell_spmv", "multidot_kernel", "csr_tail")):
+    if name.startswith(("step_apply_kernel", "multidot_kernel")):
         return "apply_dots"
+    if name.startswith(("pat_spmv", "ell_spmv", "csr_tail")):
+        return "spmv"   # stand-alone applies (set-up, bench.py's replay / cold-cache loops)
     if name.startswith(("build_lean_kernel", "build_close_kernel", "build_kernel")):
         return "build"
     return None
