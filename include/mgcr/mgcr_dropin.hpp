@@ -487,6 +487,9 @@ public:
     bool spinor[6] = {false, false, false, false, true, false};
     int n_level = 1;
     double damping = 1.0;  // the reference hard-codes 0.1 (src/MG.h:426)
+    // extension: use these near-null vectors instead of computing n_eigen of them by inverse iteration
+    // (e.g. the constant vector: piecewise-constant aggregation for Poisson-like operators)
+    const std::vector<Field<num_type>> *null_vectors = nullptr;
     MG_Param() = default;
     MG_Param(Mesh<num_type> m, num_type subblock, int eigenvecs, GCR_Param<num_type> *eigen_param, Operator<num_type> *solver_coarse,
              Operator<num_type> *solver_smooth, int levels, Operator<num_type> *solver_l, Operator<num_type> *solver_r)
@@ -585,7 +588,7 @@ public:
         m = M;
         this->dim = M->get_dim();
         std::printf("Compute global eigenvectors...\n");
-        std::vector<Field<num_type>> vecs = near_null(M);
+        std::vector<Field<num_type>> vecs = param->null_vectors ? *param->null_vectors : near_null(M);
         const int nd = param->mesh.get_ndim();
         int spinor_index = -1;
         for (int d = 0; d < nd && d < 6; d++) if (param->spinor[d]) spinor_index = d;
