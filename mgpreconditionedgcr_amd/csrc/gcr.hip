@@ -222,10 +222,10 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
         *den_slot = den;
         if (DEFER) {
             st->npend = slot + 1;
-            if (LEAN) lean_pending_update(lc, slot, alpha);
-            else alphas[slot] = alpha;
+            if (!LEAN) alphas[slot] = alpha;
         }
     }
+    if (DEFER && LEAN && blockIdx.x == 0 && (int)threadIdx.x < LND) lean_pending_update(lc, slot, alpha, (int)threadIdx.x);
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
         if (!DEFER) x[i] = cadd(x[i], cmul(alpha, p[i]));
@@ -452,17 +452,22 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     __syncthreads();
     // closing (restart > 8: the cycle-closing step is close_x_kernel + this kernel with NDT = restart, writing
     // Ap_0' over slot 0 in place): no table row — the next cycle starts a new table
-    if (!closing && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!closing && blockIdx.x == 0 && (int)threadIdx.x <= NDT) {
+        // one thread per column of the new table row (thread 0: t_k, thread k: the unit diagonal), so that the
+        // loads of a column are independent and the whole row costs one memory round trip, not k^2 / 2 of them —
+        // this sits on the critical path of the short kernels of small systems
         constexpr int k = NDT;
-        cplx tk = make_double2(0., 0.);
-        for (int j = 0; j < k; j++) tk = csub(tk, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
-        lc->t[k] = tk;
-        for (int m = 1; m < k; m++) {
-            cplx a = make_double2(0., 0.);
+        const int m = threadIdx.x;
+        cplx a = make_double2(0., 0.);
+        if (m == 0) {
+            for (int j = 0; j < k; j++) a = csub(a, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
+            lc->t[k] = a;
+        } else if (m < k) {
             for (int j = m; j < k; j++) a = csub(a, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * LND + m]));
             lc->T[k * LND + m] = a;
+        } else {
+            lc->T[k * LND + k] = make_double2(1., 0.);
         }
-        lc->T[k * LND + k] = make_double2(1., 0.);
     }
     cplx beta[NDT];
 #pragma unroll

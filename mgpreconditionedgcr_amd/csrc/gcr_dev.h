@@ -84,14 +84,14 @@ __device__ __forceinline__ void row_range(const RowMap &m, int lb, int nlogical,
     }
 }
 
-// x += alpha p_slot, recorded in terms of P0 and D_1..D_slot (one thread)
-__device__ __forceinline__ void lean_pending_update(LeanCoef *lc, int slot, cplx alpha) {
+// x += alpha p_slot, recorded in terms of P0 and D_1..D_slot: thread m < LND updates coefficient m
+__device__ __forceinline__ void lean_pending_update(LeanCoef *lc, int slot, cplx alpha, int m) {
     if (slot == 0) {
-        lc->cx[0] = alpha;
-        for (int m = 1; m < LND; m++) lc->cx[m] = make_double2(0., 0.);
-    } else {
+        lc->cx[m] = m == 0 ? alpha : make_double2(0., 0.);
+    } else if (m == 0) {
         lc->cx[0] = cadd(lc->cx[0], cmul(alpha, lc->t[slot]));
-        for (int m = 1; m <= slot; m++) lc->cx[m] = cadd(lc->cx[m], cmul(alpha, lc->T[slot * LND + m]));
+    } else if (m <= slot) {
+        lc->cx[m] = cadd(lc->cx[m], cmul(alpha, lc->T[slot * LND + m]));
     }
 }
 
