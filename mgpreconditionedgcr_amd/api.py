@@ -254,6 +254,18 @@ class HierarchicalSparse(Operator):
         self.bs = bs
 
 
+class Dense(HierarchicalSparse):
+    """Dense<num_type>(matrix, dim) (src/Operator.h:125-129,159-173): row-major dim x dim complex matrix; its
+    operator() accumulates each row in column order.  Stored as a block-CSR operator of one block."""
+
+    def __init__(self, matrix, dim=None):
+        m = np.ascontiguousarray(matrix, c128)
+        dim = int(dim) if dim is not None else int(round(np.sqrt(m.size)))
+        if dim * dim != m.size:
+            raise MgcrError(1, "Dense: matrix must hold dim*dim entries")
+        super().__init__(1, 1, [0], [0], m.reshape(1, dim, dim))
+
+
 class GCR_Param:
     """GCR_Param(trunc, re, max_it, tau, verb, solver_l, solver_r) (src/SolverParam.h:21-35,85-99)."""
 

@@ -22,7 +22,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 mg = pytest.importorskip("mgpreconditionedgcr_amd")
-from mgpreconditionedgcr_amd import (DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MgcrError,  # noqa: E402
+from mgpreconditionedgcr_amd import (Dense, DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MgcrError,  # noqa: E402
                                      Sparse, problems, read_data)
 from oracle import oracle as orc  # noqa: E402  (checker only)
 
@@ -476,6 +476,20 @@ def test_graph_replay_same_results():
                 mg.set_option("graph_replay", prev)
             out.append((g.last_history.copy(), x.to_numpy()))
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("dim", [1, 4, 20, 64, 100])
+def test_dense_operator_vs_oracle(dim):
+    """Dense::operator() (src/Operator.h:159-173): every row accumulated in column order — the bits of the
+    oracle's restatement (a block-CSR operator of one block)."""
+    rng = np.random.default_rng(dim)
+    m = rng.standard_normal((dim, dim)) + 1j * rng.standard_normal((dim, dim))
+    x = problems.rhs_grid(dim, 3)
+    ref = orc.bcsr_from_triplets(1, 1, dim, [0], [0], m.reshape(1, dim, dim))(x)
+    y = Dense(m, dim)(Field((dim,), x)).to_numpy()
+    assert np.array_equal(y, ref)
+    # and the plain definition, to rounding
+    assert np.abs(y - m @ x).max() <= 1e-13 * max(np.abs(m @ x).max(), 1.0) * dim
 
 
 def test_gcr_vs_oracle_random_nonhermitian():
