@@ -347,6 +347,58 @@ class Mesh:
     def loc_ind(self, loc):  # alloc_loc_ind src/Mesh.h:368-398
         return tuple(int(v) for v in np.unravel_index(loc, self.dims))
 
+    # ---- aggregates (src/Mesh.h:236-324): the reference's 4 blocked ("spacetime") dimensions --------------
+    def blocking(self, subblock_dim, blocked_dimensions):
+        """Mesh::blocking (src/Mesh.h:236-298): block_map[block][offset] = location of a site in the row-major
+        spacetime lattice (the blocked dimensions only), blocks and in-block offsets row-major as well.  Integer
+        index algebra on the host, as in the reference; the device set-up (csrc/mg_setup.hip:agg_kernel) forms
+        the same aggregates directly from the row index (tests/test_gpu_mg.py::test_mesh_blocking_matches_device_aggregates)."""
+        blocked = [bool(b) for b in blocked_dimensions][:len(self.dims)]
+        idx = [d for d, b in enumerate(blocked) if b]
+        if len(idx) != 4:
+            raise ValueError("Mesh::blocking blocks exactly 4 dimensions (got %d)" % len(idx))
+        sub = int(subblock_dim)
+        st_dims = [self.dims[d] for d in idx]
+        if any(v % sub for v in st_dims):
+            raise ValueError("Dimension not exactly divisible by block size!")
+        self.sub_dim = sub
+        self.blocked_ind = idx
+        self.block_dim = [v // sub for v in st_dims]
+        coords = np.indices(st_dims).reshape(4, -1)                      # x, y, z, w of every site, row-major
+        loc = np.ravel_multi_index(tuple(coords), st_dims)
+        block = np.ravel_multi_index(tuple(coords // sub), self.block_dim)
+        off = np.ravel_multi_index(tuple(coords % sub), [sub] * 4)
+        self.block_map = np.empty((self.get_nblocks(), self.get_block_size()), np.int64)
+        self.block_map[block, off] = loc
+        return self
+
+    def get_nblocks(self):
+        return int(np.prod(self.block_dim))
+
+    def get_block_dim(self):
+        return list(self.block_dim)
+
+    def get_block_size(self):
+        return self.sub_dim ** 4
+
+    def get_block_map(self, block_idx):
+        return self.block_map[int(block_idx)]
+
+    def alloc_full_index(self, spacetime_loc, spinor, colour, spacetime_dimensions, spinor_dimension):
+        """Mesh::alloc_full_index (src/Mesh.h:300-324): spacetime location + spinor + colour -> N-D index."""
+        st_dims = [self.dims[d] for d in range(len(self.dims)) if spacetime_dimensions[d]]
+        st = np.unravel_index(int(spacetime_loc), st_dims)
+        out, c = [], 0
+        for d in range(len(self.dims)):
+            if spacetime_dimensions[d]:
+                out.append(int(st[c]))
+                c += 1
+            elif spinor_dimension[d]:
+                out.append(int(spinor))
+            else:
+                out.append(int(colour))
+        return tuple(out)
+
 
 def gamma5(field_values, dims, spinor_index=4):
     """Field::gamma5 (src/Fields.h:310-339) of host values: output[index with spinor 0<->2, 1<->3] = field[i]

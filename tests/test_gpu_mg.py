@@ -220,3 +220,26 @@ def test_gamma5_and_vec_double_on_device():
         assert np.array_equal(d[0], (v + ref) * 0.5) and np.array_equal(d[1], (v - ref) * 0.5)
     with pytest.raises(ValueError):
         Field((3, 3)).gamma5(1)
+
+
+def test_mesh_blocking_matches_device_aggregates(sample_matrix_path, mg_gold):
+    """Mesh::blocking / get_block_map / alloc_full_index (src/Mesh.h:236-324), the host index algebra of the
+    reference, against the aggregate map the device set-up builds from the row index alone: every site of block
+    b, with every spinor and colour, lands in aggregate b."""
+    D = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path))
+    vecs = vec_double([mg_gold["eigvec0"], mg_gold["eigvec1"]], DIMS, 4)
+    prm = MG_Param(Mesh(DIMS), 2, 2, None, GCR(GCR_Param(0, 10, 10, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1,
+                   None, None, null_vectors=vecs)
+    M = MG(DiracOp(D, 0.1), prm)
+    _, agg = M.prolongator(0)
+    mesh = Mesh(DIMS).blocking(2, prm.spacetime)
+    assert mesh.get_nblocks() == 16 and mesh.get_block_dim() == [2, 2, 2, 2] and mesh.get_block_size() == 16
+    seen = np.zeros(agg.size, bool)
+    for b in range(mesh.get_nblocks()):
+        for site in mesh.get_block_map(b):
+            for sp in range(4):
+                for co in range(3):
+                    row = mesh.ind_loc(mesh.alloc_full_index(site, sp, co, prm.spacetime, prm.spinor))
+                    assert agg[row] == b
+                    seen[row] = True
+    assert seen.all()
