@@ -60,12 +60,14 @@ def main():
     from mgpreconditionedgcr_amd import Comm, Plan, problems
     comm = Comm.host(dist)
     results = {}
-    if mode == "mg":
+    if mode in ("mg", "mg-large"):
         # distributed 3-level aggregation MG as flexible right preconditioner (BASELINE config 4 shape, small)
         import mgpreconditionedgcr_amd as mg
         from mgpreconditionedgcr_amd import DistSparse, Field, GCR, GCR_Param, MG, MG_Param, Mesh
         mg.init(0)
-        n, planes = 8, 8                      # every rank owns 8 planes of an (8*world) x 8 x 8 grid
+        # every rank owns `planes` planes of a (planes*world) x n x n grid; "mg-large": local blocks of >= 2^15 rows,
+        # i.e. row-pattern storage, the fused apply and the aliased smoother start on a distributed operator
+        n, planes = (8, 8) if mode == "mg" else (48, 16)
         N, ncol, rowptr, col, val = problems.poisson3d_csr(n, rank * planes, (rank + 1) * planes, ni=world * planes)
         A = DistSparse(comm, ncol, rank * N, rowptr, col, val)
         dims = (planes, n, n)                 # LOCAL mesh of this rank's row block

@@ -88,15 +88,15 @@ print("RCCL_OK")
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_mg_gcr_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "mg"), (3, "mg"), (2, "mg-large")])
+def test_distributed_mg_gcr_matches_single_process(tmp_path, world, mode):
     """BASELINE config 4 in miniature: slab-partitioned Poisson, 3-level aggregation MG built
     collectively (Galerkin across the slab boundaries, distributed coarse operators), flexible
     outer GCR — against the single-process MG-GCR of the same global problem."""
     from mgpreconditionedgcr_amd import MG, MG_Param, Mesh
     mg.init()
-    res = run_workers("mg", world, tmp_path, timeout=500)
-    n, planes = 8, 8
+    res = run_workers(mode, world, tmp_path, timeout=500)
+    n, planes = (8, 8) if mode == "mg" else (48, 16)
     ni = world * planes
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n, 0, ni, ni=ni)
     A = Sparse(N, ncol, rowptr, col, val)
