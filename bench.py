@@ -228,10 +228,12 @@ def main():
     #   apply   matrix (pattern ids + tables, or slab) + r read + Ar written + lim Aps_j read (+ Ar re-read
     #           by the separate multidot kernel when the fused kernel is not used)
     #   build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
-    lim_avg = (R + 1) / 2.0
-    b_phase = [3.0 * V,
-               stored["matrix_bytes"] + 16 * ncol + 16 * N + lim_avg * V + (0 if fused.value else V),
-               (sum(3 + l for l in range(1, R)) + 2 * R + 6) * V / float(R)]
+    # exact for the K iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored
+    # directions, k = 1..R, and k = R closes the cycle
+    lims = [((k - 1) % R) + 1 for k in range(1, max(n_it.value, 1) + 1)]
+    b_apply = [stored["matrix_bytes"] + 16 * ncol + 16 * N + l * V + (0 if fused.value else V) + (V if l > 8 else 0) for l in lims]
+    b_build = [(2 * R + 6) * V if l == R else (3 + l) * V for l in lims]
+    b_phase = [3.0 * V, sum(b_apply) / len(lims), sum(b_build) / len(lims)]
     names = ["xr_update_kernel (alpha, residual ring, |r|^2)",
              "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value else "SpMV + multidot_kernel",
              "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
@@ -248,7 +250,7 @@ def main():
         except Exception:
             traffic = None
     b_spmv_survey = spmv_algorithmic_bytes(nnz, N, ncol)
-    mean_lim = (R + 1) / 2.0
+    mean_lim = sum(lims) / float(len(lims))
     iter_bytes_survey = b_spmv_survey + (13 + 3 * mean_lim) * V   # SURVEY.md §8(d) accounting
     iter_bytes_ours = sum(b_phase)                                # what this implementation moves
 
