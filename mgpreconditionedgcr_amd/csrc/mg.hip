@@ -119,12 +119,14 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
 // RANK's row block (e.g. its slab of planes) and the call is collective.
 static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
     const Op *base0 = A->kind == OP_DIRAC ? A->base : A;
-    const CsrDev &A0 = base0->csr;
-    MGCR_CHECK(base0->dist || A0.nrow == A0.ncol, MGCR_ERR_INVALID, "mgcr_mg_create: operator must be square");
+    const bool blockop = base0->kind == OP_BCSR;  // HierarchicalSparse as the fine operator (e.g. aggregates of block rows)
+    const int64_t nrow0 = blockop ? (int64_t)base0->bcsr.nbrow * base0->bcsr.bs : base0->csr.nrow;
+    const int64_t ncol0 = blockop ? (int64_t)base0->bcsr.nbcol * base0->bcsr.bs : base0->csr.ncol;
+    MGCR_CHECK(base0->dist || nrow0 == ncol0, MGCR_ERR_INVALID, "mgcr_mg_create: operator must be square");
     int64_t n = 1;
     int nblocked = 0;
     for (int d = 0; d < p->ndim; d++) { n *= p->dims[d]; nblocked += p->blocked[d] ? 1 : 0; }
-    MGCR_CHECK(n == A0.nrow, MGCR_ERR_INVALID, "mgcr_mg_create: mesh has %lld points, operator has %lld rows", (long long)n, (long long)A0.nrow);
+    MGCR_CHECK(n == nrow0, MGCR_ERR_INVALID, "mgcr_mg_create: mesh has %lld points, operator has %lld rows", (long long)n, (long long)nrow0);
     MGCR_CHECK(nblocked >= 1 && nblocked <= 4, MGCR_ERR_INVALID, "mgcr_mg_create: 1..4 dimensions can be blocked");
     MgState *m = new MgState();
     m->damping = p->damping;
@@ -185,8 +187,8 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
 }
 
 int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
-    MGCR_CHECK(A && (A->kind == OP_CSR || A->kind == OP_DIRAC), MGCR_ERR_UNSUPPORTED,
-               "mgcr_mg_create: the fine operator must be a Sparse or a DiracOp");
+    MGCR_CHECK(A && (A->kind == OP_CSR || A->kind == OP_DIRAC || A->kind == OP_BCSR), MGCR_ERR_UNSUPPORTED,
+               "mgcr_mg_create: the fine operator must be a Sparse, a DiracOp or a HierarchicalSparse");
     MGCR_CHECK(p->ndim >= 1 && p->ndim <= 8 && p->n_vec >= 1 && p->vecs_ri && p->n_level >= 1 && p->n_level <= 6,
                MGCR_ERR_INVALID, "mgcr_mg_create: bad parameters");
     return mg_create_device(A, p, out);

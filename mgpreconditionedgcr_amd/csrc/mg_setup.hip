@@ -139,22 +139,22 @@ __global__ void gs_kernel(int64_t nagg, int ne, const int32_t *__restrict__ aptr
     }
 }
 
-constexpr int MAXNB = 64;
+constexpr int MAXNB_FIRST = 64, MAXNB_LAST = 4096;  // neighbour-list capacity per aggregate: grown x4 on overflow
 
 // neighbour aggregates of every aggregate (ascending, itself included for a shifted operator)
 __global__ void gal_count_kernel(int64_t nagg, RowSrc src, int shift, const int32_t *__restrict__ agg,
                                  const int32_t *__restrict__ aptr, const int32_t *__restrict__ amem,
-                                 int32_t *__restrict__ cnt, int32_t *__restrict__ nbr, int *__restrict__ overflow) {
+                                 int32_t *__restrict__ cnt, int32_t *__restrict__ nbr, int *__restrict__ overflow, int maxnb) {
     int64_t ap = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ap >= nagg) return;
-    int32_t *mine = nbr + ap * MAXNB;
+    int32_t *mine = nbr + ap * maxnb;
     int32_t nn = 0;
     bool over = false;
     auto add = [&](int32_t a) {
         int32_t lo = 0;
         while (lo < nn && mine[lo] < a) lo++;
         if (lo < nn && mine[lo] == a) return;
-        if (nn == MAXNB) { over = true; return; }
+        if (nn == maxnb) { over = true; return; }
         for (int32_t q = nn; q > lo; q--) mine[q] = mine[q - 1];
         mine[lo] = a;
         nn++;
@@ -167,12 +167,12 @@ __global__ void gal_count_kernel(int64_t nagg, RowSrc src, int shift, const int3
 }
 
 __global__ void gal_index_kernel(int64_t nagg, const int32_t *__restrict__ browptr, const int32_t *__restrict__ nbr,
-                                 int32_t *__restrict__ brow, int32_t *__restrict__ bcol) {
+                                 int32_t *__restrict__ brow, int32_t *__restrict__ bcol, int maxnb) {
     int64_t ap = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ap >= nagg) return;
     for (int32_t b = browptr[ap]; b < browptr[ap + 1]; b++) {
         brow[b] = (int32_t)ap;
-        bcol[b] = nbr[ap * MAXNB + (b - browptr[ap])];
+        bcol[b] = nbr[ap * maxnb + (b - browptr[ap])];
     }
 }
 
@@ -263,7 +263,7 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
             S *= dims[d];
         }
     }
-    MGCR_CHECK(nagg * ne < ((int64_t)1 << 31) && nagg * MAXNB < ((int64_t)1 << 40), MGCR_ERR_UNSUPPORTED, "coarse level too large");
+    MGCR_CHECK(nagg * ne < ((int64_t)1 << 31), MGCR_ERR_UNSUPPORTED, "coarse level too large");
     MGCR_TRY(dmalloc(d_agg, (size_t)n));
     MGCR_TRY(dmalloc(d_aptr, (size_t)nagg + 1));
     MGCR_TRY(dmalloc(d_amem, (size_t)n));
@@ -325,19 +325,30 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     int32_t *d_cnt = nullptr, *d_nbr = nullptr;
     int *d_over = nullptr;
     MGCR_TRY(dmalloc(&d_cnt, (size_t)nagg));
-    MGCR_TRY(dmalloc(&d_nbr, (size_t)nagg * MAXNB));
     MGCR_TRY(dmalloc(&d_over, 1));
-    MGCR_HIP(hipMemsetAsync(d_over, 0, sizeof(int), st));
-    hipLaunchKernelGGL(gal_count_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, src, shift ? 1 : 0, g_agg,
-                       (const int32_t *)*d_aptr, (const int32_t *)*d_amem, d_cnt, d_nbr, d_over);
-    MGCR_HIP(hipGetLastError());
     std::vector<int32_t> cnt((size_t)nagg);
-    int over = 0;
-    MGCR_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int32_t) * (size_t)nagg, hipMemcpyDeviceToHost, st));
-    MGCR_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, st));
-    MGCR_HIP(hipStreamSynchronize(st));
+    int maxnb = MAXNB_FIRST;
+    for (;;) {  // lattice operators couple an aggregate to a few dozen others; unstructured block operators to hundreds
+        MGCR_TRY(dmalloc(&d_nbr, (size_t)nagg * maxnb));
+        MGCR_HIP(hipMemsetAsync(d_over, 0, sizeof(int), st));
+        hipLaunchKernelGGL(gal_count_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, src, shift ? 1 : 0, g_agg,
+                           (const int32_t *)*d_aptr, (const int32_t *)*d_amem, d_cnt, d_nbr, d_over, maxnb);
+        MGCR_HIP(hipGetLastError());
+        int over = 0;
+        MGCR_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int32_t) * (size_t)nagg, hipMemcpyDeviceToHost, st));
+        MGCR_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, st));
+        MGCR_HIP(hipStreamSynchronize(st));
+        if (!over) break;
+        hipFree(d_nbr);
+        d_nbr = nullptr;
+        if (maxnb >= MAXNB_LAST) {
+            hipFree(d_cnt); hipFree(d_over);
+            set_error("an aggregate couples to more than %d aggregates", MAXNB_LAST);
+            return MGCR_ERR_UNSUPPORTED;
+        }
+        maxnb *= 4;
+    }
     hipFree(d_cnt); hipFree(d_over);
-    if (over) { hipFree(d_nbr); set_error("an aggregate couples to more than %d aggregates", MAXNB); return MGCR_ERR_UNSUPPORTED; }
     std::vector<int32_t> browptr((size_t)nagg + 1, 0);
     for (int64_t a = 0; a < nagg; a++) {
         int64_t nx = (int64_t)browptr[(size_t)a] + cnt[(size_t)a];
@@ -355,7 +366,7 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     MGCR_TRY(dmalloc(&d_t, (size_t)nblk * ne));
     MGCR_HIP(hipMemcpyAsync(d_browptr, browptr.data(), sizeof(int32_t) * ((size_t)nagg + 1), hipMemcpyHostToDevice, st));
     MGCR_HIP(hipMemsetAsync(d_blocks, 0, sizeof(cplx) * (size_t)nblk * ne * ne, st));
-    hipLaunchKernelGGL(gal_index_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, (const int32_t *)d_browptr, (const int32_t *)d_nbr, d_brow, d_bcol);
+    hipLaunchKernelGGL(gal_index_kernel, dim3(g256(nagg)), dim3(256), 0, st, nagg, (const int32_t *)d_browptr, (const int32_t *)d_nbr, d_brow, d_bcol, maxnb);
     hipLaunchKernelGGL(gal_fill_kernel, dim3(g256(nblk)), dim3(256), 0, st, nblk, src, shift ? 1 : 0, A->k, ne, g_agg,
                        (const int32_t *)*d_aptr, (const int32_t *)*d_amem, g_pv, (const int32_t *)d_brow,
                        (const int32_t *)d_bcol, d_blocks, d_t);

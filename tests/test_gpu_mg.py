@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 mg = pytest.importorskip("mgpreconditionedgcr_amd")
-from mgpreconditionedgcr_amd import (DiracOp, Field, GCR, GCR_Param, MG, MG_Param, Mesh, Sparse,  # noqa: E402
+from mgpreconditionedgcr_amd import (DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MG, MG_Param, Mesh, Sparse,  # noqa: E402
                                      problems, read_data, vec_double)
 from oracle import oracle as orc  # noqa: E402
 
@@ -243,3 +243,59 @@ def test_mesh_blocking_matches_device_aggregates(sample_matrix_path, mg_gold):
                     assert agg[row] == b
                     seen[row] = True
     assert seen.all()
+
+
+def test_mg_on_a_hierarchical_sparse_operator():
+    """The fine operator may be a HierarchicalSparse (BASELINE config 5's unstructured block operator): aggregates of
+    `sub` consecutive block rows (mesh = block rows x block size, only the first dimension blocked).  Against the
+    oracle's hierarchy built from the same matrix written out as scalar CSR in block order: bit for bit."""
+    rng = np.random.default_rng(21)
+    nb, bs, ne = 16, 3, 2
+    per_row = rng.integers(2, 5, nb)
+    rows = np.repeat(np.arange(nb, dtype=np.int32), per_row)
+    cols = np.empty(rows.size, np.int32)
+    first = np.concatenate([[0], np.cumsum(per_row)[:-1]])
+    for r in range(nb):   # unique block columns per block row, the diagonal block among them
+        others = rng.choice([c for c in range(nb) if c != r], size=per_row[r] - 1, replace=False)
+        cols[first[r]:first[r] + per_row[r]] = np.sort(np.concatenate([[r], others]))
+    blocks = (rng.standard_normal((rows.size, bs, bs)) + 1j * rng.standard_normal((rows.size, bs, bs))) * 0.1
+    diag = np.flatnonzero(rows == cols)
+    blocks[diag] += np.eye(bs)[None] * 3.0
+    H = HierarchicalSparse(nb, nb, rows, cols, blocks)
+    N = nb * bs
+    # the same matrix as scalar CSR, entries in block order (block by block, columns ascending inside a block)
+    rp, ci, va = [0], [], []
+    for br in range(nb):
+        sel = np.flatnonzero(rows == br)
+        for r in range(bs):
+            for l in sel:
+                ci += [int(cols[l]) * bs + c for c in range(bs)]
+                va += [blocks[l, r, c] for c in range(bs)]
+            rp.append(len(ci))
+    rp, ci, va = np.array(rp, np.int64), np.array(ci, np.int64), np.array(va, np.complex128)
+    x = problems.rhs_grid(N, 1)
+    # (the block operator adds each block's row sum to the accumulator, src/HierarchicalSparse.h:144: same numbers, other rounding)
+    assert np.abs(H(Field((N,), x)).to_numpy() - orc.csr(N, N, rp, ci, va)(x)).max() <= 1e-14 * 10
+    vecs = rng.standard_normal((ne, N)) + 1j * rng.standard_normal((ne, N))
+    dims, blocked = (nb, bs), (1, 0)
+    smo, coo = orc.gcr_param(restart=10, max_iter=2, tol=1e-30), orc.gcr_param(restart=10, max_iter=30, tol=1e-3)
+    Mo = orc.MG(orc.csr(N, N, rp, ci, va), rp, ci, va, dims, blocked, 2, vecs, 2, smo, coo)
+    prm = MG_Param(Mesh(dims), 2, ne, None, GCR(GCR_Param(0, 10, 30, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1,
+                   None, None, spacetime=[True, False], null_vectors=vecs)
+    M = MG(H, prm)
+    pv, agg = M.prolongator(0)
+    pvo, aggo = Mo.prolongator(0)
+    assert np.array_equal(agg, aggo) and np.array_equal(pv, pvo)
+    nc = M.level_info(1)["dim"]
+    assert nc == Mo.level_dim(1) == (nb // 2) * ne
+    Ac, Aco = M.level_operator(1), Mo.level_op(1)
+    for c in range(nc):
+        e = np.zeros(nc, np.complex128)
+        e[c] = 1.0
+        assert np.array_equal(Ac(Field((nc,), e)).to_numpy(), Aco(e))
+    y = M(Field(dims, x)).to_numpy()
+    assert np.abs(y - Mo(x)).max() <= 1e-9 * np.abs(Mo(x)).max()
+    outer = GCR(H, GCR_Param(0, 5, 60, 1e-10, False, None, M, flexible=True))
+    xs = Field(dims).set_zero()
+    outer.solve(Field(dims, x), xs)
+    assert outer.last_converged and ((Field(dims, x) - H(xs)).norm() / np.linalg.norm(x)) <= 2e-10
