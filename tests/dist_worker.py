@@ -47,6 +47,24 @@ def problem(kind):
     return N, newptr, ncol_arr, nval, 1
 
 
+def unstructured_blocks(nb=24, bs=3, seed=5):
+    """Config 5 in miniature: random block operator (2-5 blocks per block row, dominant diagonal blocks) written out
+    as scalar CSR; every block row couples to block rows anywhere, i.e. to every rank of a row-block partition."""
+    rng = np.random.default_rng(seed)
+    rp, ci, va = [0], [], []
+    for br in range(nb):
+        others = rng.choice([c for c in range(nb) if c != br], size=int(rng.integers(1, 5)), replace=False)
+        bcols = np.sort(np.concatenate([[br], others]))
+        blk = {int(c): (rng.standard_normal((bs, bs)) + 1j * rng.standard_normal((bs, bs))) * 0.1 for c in bcols}
+        blk[br] = blk[br] + np.eye(bs) * 3.0
+        for r in range(bs):
+            for c in bcols:
+                ci += [int(c) * bs + k for k in range(bs)]
+                va += list(blk[int(c)][r])
+            rp.append(len(ci))
+    return nb, bs, np.array(rp, np.int64), np.array(ci, np.int64), np.array(va, np.complex128)
+
+
 def local_block(rowptr, col, val, r0, r1):
     lp = rowptr[r0:r1 + 1] - rowptr[r0]
     return lp, col[rowptr[r0]:rowptr[r1]], val[rowptr[r0]:rowptr[r1]]
@@ -60,6 +78,34 @@ def main():
     from mgpreconditionedgcr_amd import Comm, Plan, problems
     comm = Comm.host(dist)
     results = {}
+    if mode == "mg-unstructured":
+        # distributed MG-GCR on the unstructured block operator: block rows dealt to the ranks, aggregates of 2
+        # consecutive block rows, 2 given near-null vectors; the halo lists reach every other rank
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistSparse, Field, GCR, GCR_Param, MG, MG_Param, Mesh
+        mg.init(0)
+        nb, bs, rowptr, col, val = unstructured_blocks()
+        N = nb * bs
+        per = nb // world
+        r0, r1 = rank * per * bs, (rank + 1) * per * bs
+        lp, lc, lv = local_block(rowptr, col, val, r0, r1)
+        A = DistSparse(comm, N, r0, lp, lc, lv)
+        dims = (per, bs)
+        vecs = np.random.default_rng(9).standard_normal((2, N)) + 1j * np.random.default_rng(10).standard_normal((2, N))
+        prm = MG_Param(Mesh(dims), 2, 2, None, GCR(GCR_Param(0, 10, 30, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                       1, None, None, spacetime=[True, False], null_vectors=vecs[:, r0:r1])
+        M = MG(A, prm)
+        b = problems.rhs_grid(N, 3)[r0:r1]
+        y = M(Field(dims, b)).to_numpy()
+        outer = GCR(A, GCR_Param(0, 5, 60, 1e-10, False, None, M, flexible=True, check_every=3))
+        x = Field(dims).set_zero()
+        outer.solve(Field(dims, b), x)
+        results["mg"] = dict(y=y, x=x.to_numpy(), hist=outer.last_history, its=outer.last_iterations, conv=outer.last_converged,
+                             levels=[M.level_info(l) for l in range(2)])
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode in ("mg", "mg-large"):
         # distributed 3-level aggregation MG as flexible right preconditioner (BASELINE config 4 shape, small)
         import mgpreconditionedgcr_amd as mg
