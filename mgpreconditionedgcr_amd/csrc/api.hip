@@ -32,12 +32,14 @@ int mgcr_dirac_create(mgcr_op_t csr, const double k_ri[2], mgcr_op_t *out) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(csr && k_ri && out, MGCR_ERR_INVALID, "mgcr_dirac_create: null argument");
     MGCR_CHECK(csr->kind == OP_CSR, MGCR_ERR_INVALID, "mgcr_dirac_create: DiracOp wraps a Sparse (CSR) operator");
-    MGCR_CHECK(csr->csr.nrow == csr->csr.ncol, MGCR_ERR_INVALID, "mgcr_dirac_create: matrix must be square");
+    // (the row block of a distributed Sparse has its halo columns appended: square means dim == nrow there)
+    MGCR_CHECK(csr->dist ? csr->dim == csr->nrow : csr->csr.nrow == csr->csr.ncol, MGCR_ERR_INVALID, "mgcr_dirac_create: matrix must be square");
     LOCK();
     mgcr_op_s *op = new mgcr_op_s();
     op->kind = OP_DIRAC;
     op->dim = csr->dim;
     op->nrow = csr->nrow;
+    op->comm = csr->comm;
     op->base = csr;
     op->k = make_double2(k_ri[0], k_ri[1]);
     *out = op;

@@ -89,7 +89,9 @@ def main():
         per = nb // world
         r0, r1 = rank * per * bs, (rank + 1) * per * bs
         lp, lc, lv = local_block(rowptr, col, val, r0, r1)
-        A = DistSparse(comm, N, r0, lp, lc, lv)
+        from mgpreconditionedgcr_amd import DiracOp
+        A0 = DistSparse(comm, N, r0, lp, lc, lv)
+        A = DiracOp(A0, 0.05 - 0.02j)           # the shifted form 1 - k D on a distributed D
         dims = (per, bs)
         vecs = np.random.default_rng(9).standard_normal((2, N)) + 1j * np.random.default_rng(10).standard_normal((2, N))
         prm = MG_Param(Mesh(dims), 2, 2, None, GCR(GCR_Param(0, 10, 30, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),

@@ -133,7 +133,9 @@ def test_distributed_mg_on_unstructured_blocks(tmp_path, world):
     res = run_workers("mg-unstructured", world, tmp_path, timeout=500)
     nb, bs, rowptr, col, val = unstructured_blocks()
     N = nb * bs
-    A = Sparse(N, N, rowptr, col, val)
+    from mgpreconditionedgcr_amd import DiracOp
+    A0 = Sparse(N, N, rowptr, col, val)
+    A = DiracOp(A0, 0.05 - 0.02j)
     dims = (nb, bs)
     vecs = np.random.default_rng(9).standard_normal((2, N)) + 1j * np.random.default_rng(10).standard_normal((2, N))
     prm = MG_Param(Mesh(dims), 2, 2, None, GCR(GCR_Param(0, 10, 30, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
