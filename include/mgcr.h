@@ -221,6 +221,9 @@ typedef int (*mgcr_exchange_cb)(void *user, int32_t npeers, const int32_t *peers
 int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgcr_exchange_cb exchange, void *user,
                           mgcr_comm_t *out);
 int mgcr_comm_destroy(mgcr_comm_t comm);
+/* in-place sum over the ranks of `count` host doubles (set-up-time scalars: global dot products of distributed
+ * Fields, sizes); collective */
+int mgcr_comm_allreduce_sum(mgcr_comm_t comm, double *buf, int32_t count);
 /* measurement aid (bench.py, N > 1): average microseconds of one in-place device all-reduce of `count` doubles,
  * issued `reps` times back to back on the library stream (collective: every rank must call it) */
 int mgcr_comm_bench_allreduce(mgcr_comm_t comm, int32_t count, int32_t reps, double *us_avg);

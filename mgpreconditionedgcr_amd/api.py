@@ -228,6 +228,7 @@ class DiracOp(Operator):
         check(_lib.lib().mgcr_dirac_create(mat.h, _ri(k_factor), C.byref(h)))
         self.h = h
         self._keep.append(mat)
+        self.comm, self.row0 = getattr(mat, "comm", None), getattr(mat, "row0", 0)
 
     def set_k(self, new_k):  # src/Operator.h:116
         check(_lib.lib().mgcr_dirac_set_k(self.h, _ri(new_k)))
@@ -470,20 +471,28 @@ class MG(Operator):
         dims = prm.mesh.dims
         gp = prm.eigenvector_precomp_param
         gcr = GCR(M, GCR_Param(gp.truncation, gp.restart, gp.max_iter, gp.tol, False))
-        b = Field(dims).fill_rhs(9)
+        comm = getattr(M, "comm", None)   # distributed operator: dot products and norms are global
+
+        def gdot(a, b_):
+            return comm.dot(a, b_) if comm is not None else a.dot(b_)
+
+        def gnormalise(f):
+            return f * (1.0 / np.sqrt(gdot(f, f).real)) if comm is not None else f.normalise()
+
+        b = Field(dims).fill_rhs(9, global_offset=getattr(M, "row0", 0))
         x = Field(dims)
         for _ in range(10):
             x.set_zero()
             gcr.solve(b, x)
-            b.assign(x).normalise()
+            b = gnormalise(b.assign(x))
         vecs = [b.copy()]
         for count in range(1, prm.n_eigen):
             x.set_zero()
             gcr.solve(vecs[-1], x)
             t = x.copy()
             for v in vecs:       # Gram-Schmidt against the vectors found so far (src/MG.h:112-118), Field algebra on the device
-                t = t - v * v.dot(t)
-            vecs.append(t.normalise())
+                t = t - v * gdot(v, t)
+            vecs.append(gnormalise(t))
         if any(prm.spinor):
             vecs = _vec_double_fields(vecs, prm.spinor.index(True))
         return np.array([v.to_numpy() for v in vecs])

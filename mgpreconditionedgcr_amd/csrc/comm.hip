@@ -547,6 +547,11 @@ int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgc
     return MGCR_OK;
 }
 
+int mgcr_comm_allreduce_sum(mgcr_comm_t c, double *buf, int32_t count) {
+    MGCR_CHECK(c && buf && count > 0, MGCR_ERR_INVALID, "mgcr_comm_allreduce_sum: bad argument");
+    return comm_allreduce_host(c, buf, count);
+}
+
 int mgcr_comm_bench_allreduce(mgcr_comm_t c, int32_t count, int32_t reps, double *us_avg) {
     MGCR_CHECK(c && count > 0 && count <= 64 && reps > 0 && us_avg, MGCR_ERR_INVALID, "mgcr_comm_bench_allreduce: bad argument");
     MGCR_TRY(require_ctx());

@@ -83,6 +83,18 @@ class Comm:
         check(_lib.lib().mgcr_comm_create_host(rank, size, ar, ex, None, C.byref(h)))
         return cls(h, rank, size, keep=(ar, ex))
 
+    def allreduce_sum(self, values):
+        """In-place-style sum over the ranks of a few host doubles (collective); returns the summed array."""
+        buf = np.ascontiguousarray(values, np.float64).copy()
+        check(_lib.lib().mgcr_comm_allreduce_sum(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size))
+        return buf
+
+    def dot(self, a, b):
+        """Global <a, b> (conj on a) of two Fields distributed over this communicator."""
+        d = a.dot(b)
+        s = self.allreduce_sum([d.real, d.imag])
+        return complex(s[0], s[1])
+
     def __del__(self):
         try:
             if getattr(self, "h", None):
@@ -145,4 +157,6 @@ class DistSparse(Operator):
                                           col_global.ctypes.data, val.ctypes.data, C.byref(h)))
         self.h = h
         self._keep.append(comm)
+        self.row0 = int(row0)
+        self.comm = comm   # Fields this operator applies to are distributed over it (global dot products: Comm.dot)
         self._nnz = int(rowptr[-1])

@@ -108,6 +108,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if mode == "nullvec":
+        # MG::Arnoldi (src/MG.h:90-122) on a distributed operator: the inverse iteration's norms and the Gram-Schmidt
+        # dot products must be GLOBAL (Comm.dot), and the start vector the same global vector on every world size
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistSparse, GCR, GCR_Param, MG, MG_Param, Mesh
+        mg.init(0)
+        n, planes = 8, 8
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n, rank * planes, (rank + 1) * planes, ni=world * planes)
+        A = DistSparse(comm, ncol, rank * N, rowptr, col, val)
+        prm = MG_Param(Mesh((planes, n, n)), 2, 2, GCR_Param(0, 10, 400, 1e-12, False), GCR(GCR_Param(0, 10, 50, 1e-2, False)),
+                       GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1, None, None)
+        results["vecs"] = MG(None, prm).near_null_vectors(A)
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode in ("mg", "mg-large"):
         # distributed 3-level aggregation MG as flexible right preconditioner (BASELINE config 4 shape, small)
         import mgpreconditionedgcr_amd as mg

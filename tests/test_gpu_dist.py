@@ -88,6 +88,26 @@ print("RCCL_OK")
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_near_null_vectors(tmp_path, world):
+    """MG_Param without given null vectors on a distributed operator: the inverse iteration (src/MG.h:90-122) runs with
+    global norms and dot products and finds the vectors the single-process run finds (to solver tolerance)."""
+    from mgpreconditionedgcr_amd import MG, MG_Param, Mesh
+    mg.init()
+    res = run_workers("nullvec", world, tmp_path, timeout=400)
+    n, planes = 8, 8
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, 0, world * planes, ni=world * planes)
+    A = Sparse(N, ncol, rowptr, col, val)
+    prm = MG_Param(Mesh((world * planes, n, n)), 2, 2, GCR_Param(0, 10, 400, 1e-12, False), GCR(GCR_Param(0, 10, 50, 1e-2, False)),
+                   GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1, None, None)
+    ref = MG(None, prm).near_null_vectors(A)
+    got = np.concatenate([res[r]["vecs"] for r in range(world)], axis=1)
+    assert got.shape == ref.shape == (2, N)
+    gram = got.conj() @ got.T
+    assert np.abs(gram - np.eye(2)).max() < 1e-12          # orthonormal GLOBALLY
+    assert np.abs(got - ref).max() < 1e-8 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("world,mode", [(2, "mg"), (3, "mg"), (2, "mg-large")])
 def test_distributed_mg_gcr_matches_single_process(tmp_path, world, mode):
     """BASELINE config 4 in miniature: slab-partitioned Poisson, 3-level aggregation MG built
