@@ -299,6 +299,8 @@ def main():
             mg.lib().mgcr_comm_bench_allreduce(comm.h, cnt, 50, ctypes.byref(us))
             comm_us["allreduce_%d_doubles_us" % cnt] = us.value
         out["comm"] = comm_us
+        out["comm"]["allreduce_kind"] = comm.allreduce_kind
+        out["comm"]["halo_kind"] = A.halo_kind
         out["comm"]["spmv_with_halo_exchange_ms_replay"] = spmv_ms_replay
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -224,6 +224,14 @@ int mgcr_comm_destroy(mgcr_comm_t comm);
 /* in-place sum over the ranks of `count` host doubles (set-up-time scalars: global dot products of distributed
  * Fields, sizes); collective */
 int mgcr_comm_allreduce_sum(mgcr_comm_t comm, double *buf, int32_t count);
+/* how the per-iteration scalars are summed over the ranks: 0 host callbacks, 1 RCCL all-reduce, 2 peer-write
+ * mailboxes (one kernel folds and exchanges; chosen by a self-test when the first distributed operator is created,
+ * MGCR_PEER_ALLREDUCE=0 disables) */
+int mgcr_comm_allreduce_kind(mgcr_comm_t comm, int32_t *kind);
+/* how a distributed Sparse (mgcr_dcsr_create) exchanges its halo before an apply: 0 host callbacks, 1 RCCL send/recv
+ * group, 2 peer-write (one kernel stores the boundary rows into the neighbours' receive slots and waits for theirs;
+ * self-tested at creation, MGCR_PEER_HALO=0 disables) */
+int mgcr_op_halo_kind(mgcr_op_t op, int32_t *kind);
 /* measurement aid (bench.py, N > 1): average microseconds of one in-place device all-reduce of `count` doubles,
  * issued `reps` times back to back on the library stream (collective: every rank must call it) */
 int mgcr_comm_bench_allreduce(mgcr_comm_t comm, int32_t count, int32_t reps, double *us_avg);

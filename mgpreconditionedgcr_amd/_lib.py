@@ -98,6 +98,8 @@ _SIGS = {
     "mgcr_comm_create_host": (C.c_int, [C.c_int, C.c_int, ALLREDUCE_CB, EXCHANGE_CB, _vp, C.POINTER(_vp)]),
     "mgcr_comm_destroy": (C.c_int, [_vp]),
     "mgcr_comm_allreduce_sum": (C.c_int, [_vp, _dp, C.c_int32]),
+    "mgcr_comm_allreduce_kind": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "mgcr_op_halo_kind": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "mgcr_comm_bench_allreduce": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
     "mgcr_plan_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, C.POINTER(_vp)]),
     "mgcr_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -133,6 +133,14 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns) {
     return MGCR_OK;
 }
 
+int mgcr_op_halo_kind(mgcr_op_t op, int32_t *kind) {
+    MGCR_CHECK(op && kind, MGCR_ERR_INVALID, "mgcr_op_halo_kind: null argument");
+    const Op *o = op->kind == OP_DIRAC ? op->base : op;
+    MGCR_CHECK(o->dist, MGCR_ERR_UNSUPPORTED, "mgcr_op_halo_kind: not a distributed Sparse");
+    *kind = dist_halo_kind(o->dist);
+    return MGCR_OK;
+}
+
 int mgcr_set_option(const char *name, int value, int *previous) {
     MGCR_CHECK(name, MGCR_ERR_INVALID, "null option name");
     bool prev;

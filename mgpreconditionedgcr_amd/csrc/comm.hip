@@ -87,6 +87,12 @@ struct Comm {
     double *d_stage = nullptr;
     size_t d_stage_cap = 0;
     double *h_pin = nullptr;  // pinned, for the host-staged transport's scalar all-reduces
+    // peer-write all-reduce of the per-iteration scalars (below): mailboxes mapped into every rank
+    bool pw_tried = false, pw_on = false;
+    uint64_t *pw_mbox = nullptr;             // this rank's mailbox (uncached device memory, shared by hipIpc)
+    uint64_t *pw_peer[PW_MAX_RANKS] = {};    // pw_peer[r]: rank r's mailbox as mapped here (own one for r == rank)
+    uint32_t pw_seq = 0;                     // sequence number of the last all-reduce (never 0 on the wire)
+    int *pw_err = nullptr;                   // pinned host word the kernel sets when a wait timed out
 };
 
 static int comm_device_ready(Comm *c) {
@@ -105,6 +111,197 @@ static int stage_reserve(Comm *c, size_t doubles) {
     c->d_stage = nullptr;
     MGCR_HIP(hipMalloc((void **)&c->d_stage, sizeof(double) * doubles));
     c->d_stage_cap = doubles;
+    return MGCR_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Peer-write all-reduce for the scalars of a GCR step (4, then 1 + 2*lim doubles).
+//
+// An RCCL all-reduce of a few doubles costs its launch plus a ring/tree protocol, twice per iteration on
+// the critical path between dependent kernels.  Here the kernel that folds the workgroup partials (one
+// wave per scalar, blas1.hip fold_kernel) also exchanges them: lane j stores the wave's sum straight into
+// rank j's mailbox over xGMI and polls its own mailbox for rank j's sum; the wave then adds the values in
+// RANK ORDER, so every rank obtains the same bits.  No further launch, no second pass.
+//
+// Wire format (the "LL" idea: data and flag travel in ONE 8-byte store, which the fabric never tears, so
+// no ordering between separate stores is needed): a double goes as two words {lo32 | seq<<32},
+// {hi32 | seq<<32}; the receiver spins until both words carry the expected sequence number.  Mailboxes
+// are zero-initialised and seq is never 0.  Two slots (seq & 1): a rank finishes all-reduce s only after
+// every peer has SENT s, i.e. after every peer finished s-1, so nobody can still be reading the slot that
+// s+1 overwrites.  Mailboxes are uncached (fine-grained) device memory shared with hipIpc handles — the
+// allocation class RCCL itself uses for its peer buffers.
+//
+// The path validates itself when the communicator's first distributed operator is created (a few
+// all-reduces with known answers, every wait bounded by a wall-clock limit); if any rank fails to map a
+// mailbox, times out or sees a wrong sum, ALL ranks fall back to RCCL (or the host transport).
+// MGCR_PEER_ALLREDUCE=0 turns it off.
+// ------------------------------------------------------------------------------------------------
+struct PwPeers {
+    uint64_t *mb[PW_MAX_RANKS];
+};
+constexpr int PW_MAX_SCALARS = 64;
+constexpr size_t PW_MBOX_WORDS = (size_t)2 * PW_MAX_RANKS * PW_MAX_SCALARS * 2;
+constexpr long long PW_TIMEOUT_TICKS = 300000000LL;  // wall_clock64 runs at 100 MHz: 3 s
+
+__global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ pa, int na, const double *__restrict__ pb, int nb,
+                                                     double *__restrict__ out, int nblk, PwPeers peers, int rank, int nranks,
+                                                     uint32_t seq, int *err) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    double acc;
+    if (nblk > 0) {  // fold scalar k exactly as fold_kernel does
+        const double *src = k < na ? pa + (size_t)k * RED_MAX_BLOCKS : pb + (size_t)(k - na) * RED_MAX_BLOCKS;
+        acc = 0.;
+        for (int w = 0; w < RED_THREADS / 64; w++) {
+            const int t = w * 64 + lane;
+            double s = wave_sum(t < nblk ? src[t] : 0.);
+            if (lane == 0) acc += s;
+        }
+    } else {
+        acc = out[k];  // already folded: all-reduce in place
+    }
+    acc = __shfl(acc, 0, 64);
+    const size_t slot = (size_t)(seq & 1u) * PW_MAX_RANKS;
+    double val = acc;
+    if (lane < nranks && lane != rank) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+        uint64_t *dst = peers.mb[lane] + ((slot + (size_t)rank) * PW_MAX_SCALARS + (size_t)k) * 2;
+        __hip_atomic_store(dst, (bits & 0xffffffffull) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, (bits >> 32) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint64_t *src = peers.mb[rank] + ((slot + (size_t)lane) * PW_MAX_SCALARS + (size_t)k) * 2;
+        unsigned long long w0 = 0, w1 = 0;
+        const long long t0 = wall_clock64();
+        bool ok = false;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+            for (;;) {
+                w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((uint32_t)(w0 >> 32) == seq && (uint32_t)(w1 >> 32) == seq) { ok = true; break; }
+                if (wall_clock64() - t0 > PW_TIMEOUT_TICKS) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (ok) {
+            val = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+        } else {  // a peer never arrived: flag it (the host turns it into MGCR_ERR_COMM) and poison the result
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            val = __longlong_as_double(0x7ff8000000000000LL);
+        }
+    }
+    double tot = 0.;
+    for (int r = 0; r < nranks; r++) tot += __shfl(val, r, 64);  // rank order: the same bits on every rank
+    if (lane == 0) out[k] = tot;
+}
+
+static uint32_t pw_next_seq(Comm *c) {
+    c->pw_seq++;
+    if (c->pw_seq == 0) c->pw_seq = 1;
+    return c->pw_seq;
+}
+
+static int pw_launch(Comm *c, const double *pa, int na, const double *pb, int nb, double *out, int nblk) {
+    PwPeers peers;
+    for (int r = 0; r < PW_MAX_RANKS; r++) peers.mb[r] = c->pw_peer[r < c->nranks ? r : c->rank];
+    hipLaunchKernelGGL(fold_pw_kernel, dim3(na + nb), dim3(64), 0, ctx().stream, pa, na, pb, nb, out, nblk, peers, c->rank, c->nranks,
+                       pw_next_seq(c), c->pw_err);
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
+static int comm_allreduce_host(Comm *c, double *buf, int64_t count);
+
+static void pw_release(Comm *c) {
+    for (int r = 0; r < c->nranks && r < PW_MAX_RANKS; r++)
+        if (r != c->rank && c->pw_peer[r]) hipIpcCloseMemHandle(c->pw_peer[r]);
+    for (int r = 0; r < PW_MAX_RANKS; r++) c->pw_peer[r] = nullptr;
+    if (c->pw_mbox) hipFree(c->pw_mbox);
+    c->pw_mbox = nullptr;
+    if (c->pw_err) hipHostFree(c->pw_err);
+    c->pw_err = nullptr;
+    c->pw_on = false;
+}
+
+// Collective (every rank of the communicator calls it at the same point): map the mailboxes, run the
+// self-test, agree on the outcome.  Never fails the caller: on any problem the communicator simply keeps
+// its RCCL / host all-reduce.
+static int comm_pw_setup(Comm *c) {
+    if (c->pw_tried) return MGCR_OK;
+    c->pw_tried = true;
+    if (c->nranks < 2 || c->nranks > PW_MAX_RANKS) return MGCR_OK;
+    if (getenv("MGCR_PEER_ALLREDUCE") && atoi(getenv("MGCR_PEER_ALLREDUCE")) == 0) return MGCR_OK;
+    MGCR_TRY(comm_device_ready(c));
+    const int nr = c->nranks;
+    bool ok = true;
+    hipIpcMemHandle_t mine;
+    memset(&mine, 0, sizeof(mine));
+    // own mailbox: uncached device memory, zeroed BEFORE anybody can learn its handle
+    if (hipExtMallocWithFlags((void **)&c->pw_mbox, PW_MBOX_WORDS * sizeof(uint64_t), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        c->pw_mbox = nullptr;
+        ok = false;
+    }
+    if (ok && hipHostMalloc((void **)&c->pw_err, sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); c->pw_err = nullptr; ok = false; }
+    if (ok) {
+        *c->pw_err = 0;
+        ok = hipMemset(c->pw_mbox, 0, PW_MBOX_WORDS * sizeof(uint64_t)) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipIpcGetMemHandle(&mine, c->pw_mbox) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    // all-gather of the handles (one double per byte: the set-up all-reduce sums doubles) + "I am fine" count
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+    std::vector<double> g((size_t)nr * 64 + 1, 0.);
+    if (ok) {
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(&mine);
+        for (int i = 0; i < 64; i++) g[(size_t)c->rank * 64 + i] = (double)b[i];
+        g[(size_t)nr * 64] = 1.;
+    }
+    MGCR_TRY(comm_allreduce_host(c, g.data(), (int64_t)g.size()));
+    bool all = (int)g[(size_t)nr * 64] == nr;
+    bool mapped = all;
+    if (all) {
+        for (int r = 0; r < nr && mapped; r++) {
+            if (r == c->rank) { c->pw_peer[r] = c->pw_mbox; continue; }
+            hipIpcMemHandle_t h;
+            unsigned char *b = reinterpret_cast<unsigned char *>(&h);
+            for (int i = 0; i < 64; i++) b[i] = (unsigned char)g[(size_t)r * 64 + i];
+            void *ptr = nullptr;
+            if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); mapped = false; break; }
+            c->pw_peer[r] = (uint64_t *)ptr;
+        }
+    }
+    double flag = mapped ? 0. : 1.;
+    MGCR_TRY(comm_allreduce_host(c, &flag, 1));   // nobody writes into a mailbox before everybody has mapped all of them
+    bool good = all && flag == 0.;
+    if (good) {
+        // self-test: PW_TEST rounds over PW_TEST_N scalars with known sums, through the production kernel
+        constexpr int PW_TEST = 6, PW_TEST_N = 33;
+        double *d = nullptr;
+        good = hipMalloc((void **)&d, sizeof(double) * PW_TEST_N) == hipSuccess;
+        std::vector<double> h((size_t)PW_TEST_N);
+        for (int t = 0; t < PW_TEST && good; t++) {
+            for (int k = 0; k < PW_TEST_N; k++) h[(size_t)k] = 1.0 / (double)(1 + c->rank + 3 * k + 7 * t);
+            good = hipMemcpy(d, h.data(), sizeof(double) * PW_TEST_N, hipMemcpyHostToDevice) == hipSuccess;
+            if (good) good = pw_launch(c, nullptr, PW_TEST_N, nullptr, 0, d, 0) == MGCR_OK;
+            if (good) good = hipStreamSynchronize(ctx().stream) == hipSuccess && hipMemcpy(h.data(), d, sizeof(double) * PW_TEST_N, hipMemcpyDeviceToHost) == hipSuccess;
+            for (int k = 0; k < PW_TEST_N && good; k++) {
+                double want = 0.;
+                for (int r = 0; r < nr; r++) want += 1.0 / (double)(1 + r + 3 * k + 7 * t);
+                good = h[(size_t)k] == want;
+            }
+            if (good) good = *(volatile int *)c->pw_err == 0;
+        }
+        if (!good) (void)hipGetLastError();
+        if (d) hipFree(d);
+    }
+    flag = good ? 0. : 1.;
+    MGCR_TRY(comm_allreduce_host(c, &flag, 1));
+    if (flag == 0.) {
+        c->pw_on = true;
+    } else {
+        hipDeviceSynchronize();
+        pw_release(c);
+        (void)hipGetLastError();
+    }
     return MGCR_OK;
 }
 
@@ -294,6 +491,14 @@ struct DistCsr {
     std::vector<int64_t> send_off, send_cnt;
     std::vector<int64_t> send_contig;  // >= 0: the peer's rows are the contiguous range starting here (no packing)
     std::vector<double> h_send, h_recv;  // host staging (callback transport)
+    // peer-write halo exchange (below): receive slots mapped into the neighbours
+    bool pw_on = false;
+    unsigned char *pw_rx = nullptr;        // own: [2 slots][n_halo] cplx, then [2][PW_MAX_RANKS] flag words (uncached, hipIpc)
+    std::vector<unsigned char *> pw_peer_rx;  // per peer: its pw_rx as mapped here
+    struct HaloPwPeer *pw_tab = nullptr;   // device table, one entry per peer
+    int *pw_ticket = nullptr;              // device: workgroups of the running exchange that have stored their rows
+    uint32_t pw_seq = 0;
+    unsigned pw_grid_x = 1;
 };
 
 static bool halo_overlap() {
@@ -310,11 +515,215 @@ __global__ void __launch_bounds__(256) pack_kernel(int64_t n, const int32_t *__r
     if (i < n) out[i] = x[idx[i]];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Peer-write halo exchange.  With RCCL one exchange is an ncclSend/ncclRecv group: a kernel launch plus
+// its handshake on the critical path of every operator apply, for a payload of one grid plane
+// (262 KB at 128^3).  Here ONE kernel does it: its workgroups store this rank's boundary rows straight
+// into the neighbours' receive slots over xGMI (plain 16-byte stores into uncached, hipIpc-mapped memory),
+// fence, and take a ticket; the last workgroup then publishes the sequence number in every neighbour's
+// flag word (release, system scope) and waits — bounded — for the neighbours' flags in its own.  When the
+// kernel retires the halo has arrived, and the apply kernel reads it in place from the receive slot.
+// Two slots (seq & 1): a neighbour publishes s+1 only after its apply s has run (stream order), and this
+// rank starts s+2 only after it has seen the neighbour's s+1, so the slot that s+2 overwrites is free.
+// The peer lists are symmetric (A lists B iff B lists A: one's send is the other's receive).
+// Validated by a self-test at dist_csr_create (global row numbers through both slots); on any failure
+// all ranks keep the RCCL / host exchange.  MGCR_PEER_HALO=0 turns it off.
+// ------------------------------------------------------------------------------------------------
+struct HaloPwPeer {
+    cplx *dst[2];                 // where this rank's rows land in the peer's receive slots
+    uint64_t *flag_remote[2];     // the peer's flag word for this rank
+    const uint64_t *flag_local[2];  // this rank's flag word for the peer
+    int64_t send_off, send_cnt;   // this rank's send list for the peer (send_idx)
+};
+
+__global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restrict__ tab, int npeer, const int32_t *__restrict__ idx,
+                                                      const cplx *__restrict__ x, uint32_t seq, int *ticket, int *err) {
+    const int p = blockIdx.y, slot = (int)(seq & 1u);
+    const HaloPwPeer pe = tab[p];
+    cplx *dst = pe.dst[slot];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pe.send_cnt; i += (int64_t)gridDim.x * 256)
+        dst[i] = x[idx[pe.send_off + i]];
+    __threadfence_system();   // this thread's remote stores have landed
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1;
+    __syncthreads();
+    if (!last) return;
+    // every workgroup's rows are in place: publish, then wait for the neighbours
+    if ((int)threadIdx.x < npeer) {
+        const HaloPwPeer q = tab[threadIdx.x];
+        __hip_atomic_store(q.flag_remote[slot], (uint64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        bool ok = false;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+            for (;;) {
+                if (__hip_atomic_load(q.flag_local[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (uint64_t)seq) { ok = true; break; }
+                if (wall_clock64() - t0 > PW_TIMEOUT_TICKS) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) halo_test_fill_kernel(cplx *x, int64_t n, int64_t row0, double im) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = make_double2((double)(row0 + i), im);
+}
+
+static size_t halo_pw_slot_bytes(const DistCsr *d) { return (d->plan->halo_gid.size() * sizeof(cplx) + 255) / 256 * 256; }
+
+static const cplx *halo_pw_slot(const DistCsr *d, uint32_t seq) {
+    return reinterpret_cast<const cplx *>(d->pw_rx + (size_t)(seq & 1u) * halo_pw_slot_bytes(d));
+}
+
+static int halo_pw_launch(DistCsr *d, const cplx *x) {
+    Comm *c = d->comm;
+    d->pw_seq++;
+    if (d->pw_seq == 0) d->pw_seq = 1;
+    const int np = (int)d->plan->peers.size();
+    hipLaunchKernelGGL(halo_pw_kernel, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
+                       (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err);
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
+static void halo_pw_release(DistCsr *d) {
+    for (unsigned char *q : d->pw_peer_rx)
+        if (q) hipIpcCloseMemHandle(q);
+    d->pw_peer_rx.clear();
+    if (d->pw_rx) hipFree(d->pw_rx);
+    if (d->pw_tab) hipFree(d->pw_tab);
+    if (d->pw_ticket) hipFree(d->pw_ticket);
+    d->pw_rx = nullptr; d->pw_tab = nullptr; d->pw_ticket = nullptr;
+    d->pw_on = false;
+}
+
+// Collective over the communicator, called by dist_csr_create once the send lists are on the device.
+// Never fails the caller for a transport reason: on any problem every rank keeps the RCCL / host exchange.
+static int halo_pw_setup(DistCsr *d) {
+    Comm *c = d->comm;
+    Plan *P = d->plan;
+    if (!c->pw_on) return MGCR_OK;   // same mechanism as the peer-write all-reduce: only where that one validated
+    if (getenv("MGCR_PEER_HALO") && atoi(getenv("MGCR_PEER_HALO")) == 0) return MGCR_OK;
+    const int nr = c->nranks, np = (int)P->peers.size();
+    const size_t nh = P->halo_gid.size(), slot_bytes = halo_pw_slot_bytes(d);
+    const size_t flag_off = 2 * slot_bytes, total = flag_off + 2 * PW_MAX_RANKS * sizeof(uint64_t);
+    bool ok = true;
+    hipIpcMemHandle_t mine;
+    memset(&mine, 0, sizeof(mine));
+    if (hipExtMallocWithFlags((void **)&d->pw_rx, total, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); d->pw_rx = nullptr; ok = false; }
+    if (ok) ok = hipMemset(d->pw_rx, 0, total) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipIpcGetMemHandle(&mine, d->pw_rx) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&d->pw_ticket, sizeof(int)) == hipSuccess && hipMemset(d->pw_ticket, 0, sizeof(int)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    std::vector<double> g((size_t)nr * 64 + 1, 0.);
+    if (ok) {
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(&mine);
+        for (int i = 0; i < 64; i++) g[(size_t)c->rank * 64 + i] = (double)b[i];
+        g[(size_t)nr * 64] = 1.;
+    }
+    MGCR_TRY(comm_allreduce_host(c, g.data(), (int64_t)g.size()));
+    bool good = (int)g[(size_t)nr * 64] == nr;
+    // where my rows start in each neighbour's halo segment
+    std::vector<double> my_off((size_t)np), their_off((size_t)np, 0.);
+    {
+        std::vector<const double *> sp((size_t)np);
+        std::vector<double *> rp((size_t)np);
+        std::vector<int64_t> one((size_t)np, 1);
+        for (int p = 0; p < np; p++) { my_off[(size_t)p] = (double)P->recv_off[(size_t)p]; sp[(size_t)p] = &my_off[(size_t)p]; rp[(size_t)p] = &their_off[(size_t)p]; }
+        MGCR_TRY(comm_exchange_host(c, np, P->peers.data(), sp.data(), one.data(), rp.data(), one.data()));
+    }
+    bool mapped = good;
+    std::vector<HaloPwPeer> tab((size_t)np);
+    int64_t max_cnt = 0;
+    if (good) {
+        d->pw_peer_rx.assign((size_t)np, nullptr);
+        for (int p = 0; p < np && mapped; p++) {
+            const int r = P->peers[(size_t)p];
+            hipIpcMemHandle_t h;
+            unsigned char *b = reinterpret_cast<unsigned char *>(&h);
+            for (int i = 0; i < 64; i++) b[i] = (unsigned char)g[(size_t)r * 64 + i];
+            void *ptr = nullptr;
+            if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); mapped = false; break; }
+            d->pw_peer_rx[(size_t)p] = (unsigned char *)ptr;
+            // the peer's slot size follows from ITS halo length, which this rank does not know: the peer's flag block
+            // therefore sits at a place both sides can compute — see flag_base below
+        }
+    }
+    // the flag block's offset inside a peer's buffer depends on the peer's halo length: exchange it too
+    std::vector<double> my_flag((size_t)np, (double)flag_off), their_flag((size_t)np, 0.), my_slot((size_t)np, (double)slot_bytes), their_slot((size_t)np, 0.);
+    {
+        std::vector<const double *> sp((size_t)np);
+        std::vector<double *> rp((size_t)np);
+        std::vector<int64_t> one((size_t)np, 1);
+        for (int p = 0; p < np; p++) { sp[(size_t)p] = &my_flag[(size_t)p]; rp[(size_t)p] = &their_flag[(size_t)p]; }
+        MGCR_TRY(comm_exchange_host(c, np, P->peers.data(), sp.data(), one.data(), rp.data(), one.data()));
+        for (int p = 0; p < np; p++) { sp[(size_t)p] = &my_slot[(size_t)p]; rp[(size_t)p] = &their_slot[(size_t)p]; }
+        MGCR_TRY(comm_exchange_host(c, np, P->peers.data(), sp.data(), one.data(), rp.data(), one.data()));
+    }
+    if (mapped) {
+        for (int p = 0; p < np; p++) {
+            const int r = P->peers[(size_t)p];
+            unsigned char *rb = d->pw_peer_rx[(size_t)p];
+            HaloPwPeer &e = tab[(size_t)p];
+            for (int sl = 0; sl < 2; sl++) {
+                e.dst[sl] = reinterpret_cast<cplx *>(rb + (size_t)sl * (size_t)their_slot[(size_t)p]) + (int64_t)their_off[(size_t)p];
+                e.flag_remote[sl] = reinterpret_cast<uint64_t *>(rb + (size_t)their_flag[(size_t)p]) + (size_t)sl * PW_MAX_RANKS + (size_t)c->rank;
+                e.flag_local[sl] = reinterpret_cast<const uint64_t *>(d->pw_rx + flag_off) + (size_t)sl * PW_MAX_RANKS + (size_t)r;
+            }
+            e.send_off = d->send_off[(size_t)p];
+            e.send_cnt = d->send_cnt[(size_t)p];
+            max_cnt = std::max(max_cnt, e.send_cnt);
+        }
+        d->pw_grid_x = (unsigned)std::min<int64_t>(std::max<int64_t>((max_cnt + 255) / 256, 1), 1024);
+        mapped = np == 0 || (hipMalloc((void **)&d->pw_tab, sizeof(HaloPwPeer) * (size_t)np) == hipSuccess &&
+                             hipMemcpy(d->pw_tab, tab.data(), sizeof(HaloPwPeer) * (size_t)np, hipMemcpyHostToDevice) == hipSuccess);
+        if (!mapped) (void)hipGetLastError();
+    }
+    double flag = mapped ? 0. : 1.;
+    MGCR_TRY(comm_allreduce_host(c, &flag, 1));   // nobody stores into a slot before everybody has mapped its neighbours
+    good = good && flag == 0.;
+    if (good && np > 0) {
+        // self-test through both slots: x holds the global row numbers, the halo must then hold halo_gid
+        cplx *xt = nullptr;
+        good = hipMalloc((void **)&xt, sizeof(cplx) * (size_t)std::max<int64_t>(P->nloc, 1)) == hipSuccess;
+        std::vector<cplx> got(nh);
+        for (int t = 0; t < 2 && good; t++) {
+            const double im = 0.5 + t;
+            if (P->nloc) hipLaunchKernelGGL(halo_test_fill_kernel, dim3((unsigned)((P->nloc + 255) / 256)), dim3(256), 0, ctx().stream, xt, P->nloc, P->row0, im);
+            good = halo_pw_launch(d, xt) == MGCR_OK && hipStreamSynchronize(ctx().stream) == hipSuccess;
+            if (good && nh) good = hipMemcpy(got.data(), halo_pw_slot(d, d->pw_seq), sizeof(cplx) * nh, hipMemcpyDeviceToHost) == hipSuccess;
+            for (size_t j = 0; j < nh && good; j++) good = got[j].x == (double)P->halo_gid[j] && got[j].y == im;
+            if (good) good = *(volatile int *)c->pw_err == 0;
+        }
+        if (!good) (void)hipGetLastError();
+        if (xt) hipFree(xt);
+    }
+    flag = good ? 0. : 1.;
+    MGCR_TRY(comm_allreduce_host(c, &flag, 1));
+    if (flag == 0.) {
+        d->pw_on = np > 0;
+        if (!d->pw_on) halo_pw_release(d);
+    } else {
+        hipDeviceSynchronize();
+        *(volatile int *)c->pw_err = 0;
+        halo_pw_release(d);
+        (void)hipGetLastError();
+    }
+    return MGCR_OK;
+}
+
+// the halo segment the exchange begun last delivers into (call after dist_halo_begin)
+const cplx *dist_halo_ptr(DistCsr *d) { return d->pw_on ? halo_pw_slot(d, d->pw_seq) : d->xh; }
+
 int dist_halo_begin(DistCsr *d, const cplx *x) {
     Comm *c = d->comm;
     Plan *P = d->plan;
     const int np = (int)P->peers.size();
     if (np == 0) return MGCR_OK;
+    if (d->pw_on) return halo_pw_launch(d, x);
     hipStream_t main = ctx().stream;
     int64_t tot_send = d->send_off.empty() ? 0 : d->send_off.back() + d->send_cnt.back();
     // pack the non-contiguous send lists
@@ -378,7 +787,7 @@ int dist_halo_end(DistCsr *d) {
 }
 
 void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *interior_end) {
-    *xh = d->xh;
+    *xh = dist_halo_ptr(d);
     *interior_begin = d->plan->interior_begin;
     *interior_end = d->plan->interior_end;
 }
@@ -420,6 +829,7 @@ int dist_exchange_rows_host(DistCsr *d, const double *own, int w, double *halo) 
 
 void dist_free(DistCsr *d) {
     if (!d) return;
+    halo_pw_release(d);
     hipFree(d->xh); hipFree(d->sendbuf); hipFree(d->send_idx);
     delete d->plan;
     delete d;
@@ -440,6 +850,7 @@ bool comm_collectives(Comm *c) {
 int comm_allreduce_dev(Comm *c, double *dbuf, int count) {
     if (!c || !comm_collectives(c)) return MGCR_OK;
     hipStream_t st = ctx().stream;
+    if (c->pw_on && count <= PW_MAX_SCALARS) return pw_launch(c, nullptr, count, nullptr, 0, dbuf, 0);
     if (c->is_rccl) {
         MGCR_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, c->nccl, st));
         return MGCR_OK;
@@ -453,6 +864,27 @@ int comm_allreduce_dev(Comm *c, double *dbuf, int count) {
     MGCR_HIP(hipStreamSynchronize(st));  // h_pin is reused by the next call
     return MGCR_OK;
 }
+
+// out[0..na) = sum over ranks of the folded partials pa, out[na..na+nb) likewise of pb (slabs of RED_MAX_BLOCKS per
+// scalar, nblk workgroup partials each; blas1.hip k_fold2): one kernel when the peer-write all-reduce is up
+int comm_fold_allreduce(Comm *c, const double *pa, int na, const double *pb, int nb, double *out, int nblk) {
+    if (c && c->pw_on && comm_collectives(c) && na + nb <= PW_MAX_SCALARS) return pw_launch(c, pa, na, pb, nb, out, nblk);
+    MGCR_TRY(k_fold2(pa, na, out, pb, nb, out + na, nblk));
+    return comm_allreduce_dev(c, out, na + nb);
+}
+
+// did a peer-write wait time out since the last check?  (called where a distributed solve hands back to the host)
+int comm_check(Comm *c) {
+    if (c && c->pw_err && *(volatile int *)c->pw_err != 0) {
+        *(volatile int *)c->pw_err = 0;
+        set_error("peer-write all-reduce: a rank did not arrive within the time limit; the communicator is no longer usable");
+        return MGCR_ERR_COMM;
+    }
+    return MGCR_OK;
+}
+
+int dist_halo_kind(DistCsr *d) { return d->pw_on ? 2 : d->comm->is_rccl ? 1 : 0; }
+int comm_allreduce_kind(Comm *c) { return c->pw_on ? 2 : c->is_rccl ? 1 : 0; }
 
 int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col,
                     const double *val_ri, Op *op) {
@@ -490,6 +922,8 @@ int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const
         return MGCR_ERR_ALLOC;
     }
     rc = comm_device_ready(c);
+    if (rc == MGCR_OK) rc = comm_pw_setup(c);
+    if (rc == MGCR_OK) rc = halo_pw_setup(d);
     if (rc != MGCR_OK) { csr_free(&op->csr); dist_free(d); return rc; }
     op->dist = d;
     op->comm = c;
@@ -552,9 +986,16 @@ int mgcr_comm_allreduce_sum(mgcr_comm_t c, double *buf, int32_t count) {
     return comm_allreduce_host(c, buf, count);
 }
 
+int mgcr_comm_allreduce_kind(mgcr_comm_t c, int32_t *kind) {
+    MGCR_CHECK(c && kind, MGCR_ERR_INVALID, "mgcr_comm_allreduce_kind: null argument");
+    *kind = comm_allreduce_kind(c);
+    return MGCR_OK;
+}
+
 int mgcr_comm_bench_allreduce(mgcr_comm_t c, int32_t count, int32_t reps, double *us_avg) {
     MGCR_CHECK(c && count > 0 && count <= 64 && reps > 0 && us_avg, MGCR_ERR_INVALID, "mgcr_comm_bench_allreduce: bad argument");
     MGCR_TRY(require_ctx());
+    MGCR_TRY(comm_pw_setup(c));
     Context &cx = ctx();
     double *d = nullptr;
     MGCR_HIP(hipMalloc((void **)&d, sizeof(double) * 64));
@@ -577,6 +1018,7 @@ int mgcr_comm_destroy(mgcr_comm_t c) {
         hipStreamSynchronize(ctx().stream);
         if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
     }
+    pw_release(c);
     if (c->is_rccl && c->nccl) rccl().CommDestroy(c->nccl);
     if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     if (c->ev_ready) hipEventDestroy(c->ev_ready);

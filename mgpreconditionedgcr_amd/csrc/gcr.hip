@@ -1083,10 +1083,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
     RedRef refA = {s->partsA, g, RED_MAX_BLOCKS}, refR = {s->partsR, g, RED_MAX_BLOCKS};
     if (multi) {
-        MGCR_TRY(k_fold2(s->partsN, 1, s->dN, s->partsR, 1, s->dN + 1, g));
-        MGCR_TRY(comm_allreduce_dev(comm, s->dN, 2));
-        MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
-        MGCR_TRY(comm_allreduce_dev(comm, s->dA, 4));
+        MGCR_TRY(comm_fold_allreduce(comm, s->partsN, 1, s->partsR, 1, s->dN, g));
+        MGCR_TRY(comm_fold_allreduce(comm, s->partsA, 4, nullptr, 0, s->dA, g));
         KLAUNCH(init_kernel, 1, s->st, (const double *)s->dN, 1, 1, (const double *)(s->dN + 1), 1, 1, s->hist);
         refA = {s->dA, 1, 1};
         refR = {s->dRB, 1, 1};
@@ -1196,8 +1194,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         MGCR_TRY(mark());
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
         if (multi) {  // one all-reduce for |r|^2 and all beta numerators of the step
-            MGCR_TRY(k_fold2(s->partsR, 1, s->dRB, s->partsB, 2 * lim, s->dRB + 1, g));
-            MGCR_TRY(comm_allreduce_dev(comm, s->dRB, 1 + 2 * lim));
+            MGCR_TRY(comm_fold_allreduce(comm, s->partsR, 1, s->partsB, 2 * lim, s->dRB, g));
             refB = {s->dRB + 1, 1, 1};
         }
         if (lean) {
@@ -1233,8 +1230,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             MGCR_TRY(launch_build(a));
         }
         if (multi) {
-            MGCR_TRY(k_fold(s->partsA, g, 4, s->dA));
-            MGCR_TRY(comm_allreduce_dev(comm, s->dA, 4));
+            MGCR_TRY(comm_fold_allreduce(comm, s->partsA, 4, nullptr, 0, s->dA, g));
         }
         MGCR_TRY(mark());
         iter_count = ic_next;
@@ -1311,7 +1307,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         g_prof_fused = fuse_ok;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
-    return gcr_finish(s, hist, hist_cap, n_iter, converged);
+    const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);
+    if (multi) MGCR_TRY(comm_check(comm));   // a peer-write wait that timed out poisoned the scalars with NaN
+    return frc;
 }
 
 // x = init_rand(2) in the reference (src/GCR.h:63-68); here the caller-provided x0 or zero

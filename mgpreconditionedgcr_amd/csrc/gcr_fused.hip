@@ -135,6 +135,7 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         m.n_own = (int32_t)A.nrow;
         MGCR_TRY(dist_halo_begin(dist, x));
         MGCR_TRY(dist_halo_end(dist));
+        m.xh = dist_halo_ptr(dist);
     }
     DotVecs d;
     for (int j = 0; j < ND; j++) d.v[j] = vecs[j < nd ? j : 0];

@@ -174,6 +174,8 @@ SkipRef get_apply_skip();
 int dist_halo_begin(DistCsr *d, const cplx *x);
 int dist_halo_end(DistCsr *d);
 bool dist_halo_overlaps();  // MGCR_HALO_OVERLAP: exchange on the communication stream, overlapped with interior rows
+const cplx *dist_halo_ptr(DistCsr *d);  // halo segment of the exchange begun last (peer-write: alternates between two slots)
+int dist_halo_kind(DistCsr *d);
 void dist_info(DistCsr *d, const cplx **xh, int64_t *interior_begin, int64_t *interior_end);
 void dist_free(DistCsr *d);
 Comm *dist_comm(DistCsr *d);
@@ -185,6 +187,9 @@ int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const
 int comm_nranks(Comm *c);
 bool comm_collectives(Comm *c);
 int comm_allreduce_dev(Comm *c, double *dbuf, int count);
+int comm_fold_allreduce(Comm *c, const double *pa, int na, const double *pb, int nb, double *out, int nblk);
+int comm_check(Comm *c);
+constexpr int PW_MAX_RANKS = 16;  // peer-write all-reduce (comm.hip): one lane per rank
 
 // ---- mg.hip ----------------------------------------------------------------------------------
 int mg_create(Op *A, const mgcr_mg_param *p, MgState **out);

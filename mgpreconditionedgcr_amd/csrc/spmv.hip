@@ -784,6 +784,7 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
         dist_info(dist, &xh, &ib, &ie);
         n_own = (int32_t)A.nrow;
         MGCR_TRY(dist_halo_begin(dist, x));
+        xh = dist_halo_ptr(dist);
         MGCR_TRY(ell_rows<SHIFT>(A, ib, ie - ib, x, xh, n_own, y, k, w));
         MGCR_TRY(dist_halo_end(dist));
         MGCR_TRY(ell_rows<SHIFT>(A, 0, ib, x, xh, n_own, y, k, w));

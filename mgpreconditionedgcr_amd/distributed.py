@@ -83,6 +83,14 @@ class Comm:
         check(_lib.lib().mgcr_comm_create_host(rank, size, ar, ex, None, C.byref(h)))
         return cls(h, rank, size, keep=(ar, ex))
 
+    @property
+    def allreduce_kind(self):
+        """How a solve sums its per-iteration scalars over the ranks: "host", "rccl" or "peer-write"
+        (decided by a self-test when the first distributed operator is created on this communicator)."""
+        k = C.c_int32()
+        check(_lib.lib().mgcr_comm_allreduce_kind(self.h, C.byref(k)))
+        return ("host", "rccl", "peer-write")[k.value]
+
     def allreduce_sum(self, values):
         """In-place-style sum over the ranks of a few host doubles (collective); returns the summed array."""
         buf = np.ascontiguousarray(values, np.float64).copy()
@@ -160,3 +168,10 @@ class DistSparse(Operator):
         self.row0 = int(row0)
         self.comm = comm   # Fields this operator applies to are distributed over it (global dot products: Comm.dot)
         self._nnz = int(rowptr[-1])
+
+    @property
+    def halo_kind(self):
+        """How the halo travels before an apply: "host", "rccl" or "peer-write" (self-tested at creation)."""
+        k = C.c_int32()
+        check(_lib.lib().mgcr_op_halo_kind(self.h, C.byref(k)))
+        return ("host", "rccl", "peer-write")[k.value]

@@ -144,7 +144,7 @@ def main():
         x = Field(dims).set_zero()
         outer.solve(Field(dims, b), x)
         results["mg"] = dict(y=y, x=x.to_numpy(), hist=outer.last_history, its=outer.last_iterations,
-                             conv=outer.last_converged, levels=[M.level_info(l) for l in range(3)])
+                             conv=outer.last_converged, levels=[M.level_info(l) for l in range(3)], allreduce=comm.allreduce_kind)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -199,7 +199,13 @@ def main():
             xt = Field((r1 - r0,)).set_zero()
             g2.solve(b, xt)
             results[kind] = dict(y=y, r0=r0, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations,
-                                 hist_trunc=g2.last_history, x_trunc=xt.to_numpy(), format=A.storage_format()[0])
+                                 hist_trunc=g2.last_history, x_trunc=xt.to_numpy(), format=A.storage_format()[0],
+                                 allreduce=comm.allreduce_kind, halo=A.halo_kind)
+            if kind == "poisson":
+                import ctypes
+                us = ctypes.c_double()
+                mg.lib().mgcr_comm_bench_allreduce(comm.h, 11, 200, ctypes.byref(us))
+                results[kind]["allreduce_us"] = us.value
     np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -28,6 +28,14 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
         N, rowptr, col, val, gran = problem(kind)
         A = Sparse(N, N, rowptr, col, val)
         assert res[0][kind]["format"] == (1 if kind == "poisson48" else 0)
+        # the per-iteration scalars went through the peer-write mailboxes (self-test passed on every rank), unless
+        # the run asked for the transport's own all-reduce
+        want = "host" if os.environ.get("MGCR_PEER_ALLREDUCE") == "0" else "peer-write"
+        assert all(res[r][kind]["allreduce"] == want for r in range(world)), [res[r][kind]["allreduce"] for r in range(world)]
+        want_h = "host" if os.environ.get("MGCR_PEER_HALO") == "0" or want == "host" else "peer-write"
+        assert all(res[r][kind]["halo"] == want_h for r in range(world)), [res[r][kind]["halo"] for r in range(world)]
+        if kind == "poisson":
+            print("all-reduce of 11 doubles, %d ranks on one GPU, %s: %.1f us" % (world, want, res[0][kind]["allreduce_us"]))
         x = problems.rhs_grid(N, 5)
         y = A(Field((N,), x)).to_numpy()
         got = np.concatenate([res[r][kind]["y"] for r in range(world)])
