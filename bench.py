@@ -141,7 +141,21 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from mgpreconditionedgcr_amd import Comm, DistSparse
-        comm = Comm.host(dist) if host_transport else Comm.rccl(dist)
+        rccl_note = None
+        if host_transport:
+            comm = Comm.host(dist)
+        else:
+            # RCCL communicator; should its creation fail on any rank, every rank falls back to the host-staged
+            # transport so that the run still yields a (flagged) line instead of nothing
+            try:
+                comm, err = Comm.rccl(dist), None
+            except Exception as e:  # noqa: BLE001
+                comm, err = None, repr(e)
+            bad = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+            dist.all_reduce(bad)
+            if int(bad[0]):
+                rccl_note = "RCCL communicator creation failed on %d rank(s) (%s): host-staged transport" % (int(bad[0]), err)
+                comm = Comm.host(dist)
         # weak scaling: the grid grows along i, every GPU owns n planes (= the N=1 problem)
         N, ncol, rowptr, col, val = problems.poisson3d_csr(n, rank * n, (rank + 1) * n, ni=world * n)
         nnz = int(rowptr[-1])
@@ -267,7 +281,7 @@ def main():
                    "stored_matrix_bytes": stored["matrix_bytes"], "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],
                    "partition": "1 GPU" if world == 1 else "slab x%d (grid %dx%dx%d), %s" % (
                        world, world * n, n, n, "host-staged transport (bring-up, not a result)" if host_transport
-                       else "RCCL halo exchange + all-reduce")},
+                       else (rccl_note or "RCCL communicator; halo: %s, all-reduce: %s" % (A.halo_kind, comm.allreduce_kind)))},
         "phases": {keys[k]: {"kernel": names[k], "us_per_iteration": ph_us[k], "bytes_per_launch": b_phase[k],
                              "GBps": b_phase[k] / (ph_us[k] * 1e-6) / 1e9 if ph_us[k] > 0 else None} for k in range(3)},
         "phases_timed": "in situ: hipEvents between the phases of each of the %d iterations of a GCR solve" % n_it.value,
