@@ -142,11 +142,14 @@ struct PwPeers {
 };
 constexpr int PW_MAX_SCALARS = 64;
 constexpr size_t PW_MBOX_WORDS = (size_t)2 * PW_MAX_RANKS * PW_MAX_SCALARS * 2;
-constexpr long long PW_TIMEOUT_TICKS = 300000000LL;  // wall_clock64 runs at 100 MHz: 3 s
+// wall_clock64 runs at 100 MHz.  Self-tests (ranks just synchronised by a set-up collective): 3 s.  Production: 20 s — the
+// ranks of one solve may arrive skewed (one of them still reading a file), but a wave must never spin anywhere near the
+// driver's compute-queue watchdog (60 s).
+constexpr long long PW_TIMEOUT_TEST = 300000000LL, PW_TIMEOUT_RUN = 2000000000LL;
 
 __global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ pa, int na, const double *__restrict__ pb, int nb,
                                                      double *__restrict__ out, int nblk, PwPeers peers, int rank, int nranks,
-                                                     uint32_t seq, int *err) {
+                                                     uint32_t seq, int *err, long long timeout) {
     const int k = blockIdx.x, lane = threadIdx.x;
     double acc;
     if (nblk > 0) {  // fold scalar k exactly as fold_kernel does
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ 
                 w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((uint32_t)(w0 >> 32) == seq && (uint32_t)(w1 >> 32) == seq) { ok = true; break; }
-                if (wall_clock64() - t0 > PW_TIMEOUT_TICKS) break;
+                if (wall_clock64() - t0 > timeout) break;
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -203,7 +206,7 @@ static int pw_launch(Comm *c, const double *pa, int na, const double *pb, int nb
     PwPeers peers;
     for (int r = 0; r < PW_MAX_RANKS; r++) peers.mb[r] = c->pw_peer[r < c->nranks ? r : c->rank];
     hipLaunchKernelGGL(fold_pw_kernel, dim3(na + nb), dim3(64), 0, ctx().stream, pa, na, pb, nb, out, nblk, peers, c->rank, c->nranks,
-                       pw_next_seq(c), c->pw_err);
+                       pw_next_seq(c), c->pw_err, c->pw_on ? PW_TIMEOUT_RUN : PW_TIMEOUT_TEST);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -538,7 +541,7 @@ struct HaloPwPeer {
 };
 
 __global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restrict__ tab, int npeer, const int32_t *__restrict__ idx,
-                                                      const cplx *__restrict__ x, uint32_t seq, int *ticket, int *err) {
+                                                      const cplx *__restrict__ x, uint32_t seq, int *ticket, int *err, long long timeout) {
     const int p = blockIdx.y, slot = (int)(seq & 1u);
     const HaloPwPeer pe = tab[p];
     cplx *dst = pe.dst[slot];
@@ -559,7 +562,7 @@ __global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restri
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
             for (;;) {
                 if (__hip_atomic_load(q.flag_local[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (uint64_t)seq) { ok = true; break; }
-                if (wall_clock64() - t0 > PW_TIMEOUT_TICKS) break;
+                if (wall_clock64() - t0 > timeout) break;
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -585,7 +588,7 @@ static int halo_pw_launch(DistCsr *d, const cplx *x) {
     if (d->pw_seq == 0) d->pw_seq = 1;
     const int np = (int)d->plan->peers.size();
     hipLaunchKernelGGL(halo_pw_kernel, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
-                       (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err);
+                       (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, d->pw_on ? PW_TIMEOUT_RUN : PW_TIMEOUT_TEST);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }

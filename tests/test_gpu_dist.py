@@ -20,6 +20,14 @@ from tests.dist_worker import problem  # noqa: E402
 from oracle import oracle as orc  # noqa: E402  (checker only)
 
 
+def test_distributed_gcr_with_transport_collectives(tmp_path, monkeypatch):
+    """Same comparison with the peer-write kernels switched off: scalars and halos travel through the transport's own
+    all-reduce / exchange (here the host callbacks; on a multi-GPU node RCCL) — the fallback every rank takes when the
+    peer-write self-test fails anywhere."""
+    monkeypatch.setenv("MGCR_PEER_ALLREDUCE", "0")
+    test_distributed_gcr_matches_single_process(tmp_path, 2)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_gcr_matches_single_process(tmp_path, world):
     mg.init()
