@@ -272,6 +272,9 @@ def main():
         "metric": "gcr_iterations_per_sec", "value": it_per_s * world, "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "value_definition": "iterations/s of ONE solve on one GPU" if world == 1 else
+                            "iterations/s of the ONE distributed solve (%.1f) x n_gpus: every iteration sweeps n_gpus shards of "
+                            "%d^3 rows, the weak-scaling aggregate (shard-iterations per second)" % (it_per_s, n),
         "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, complex fp64, x0=0, "
                                "RHS splitmix64 seed 0" % (n, args.restart),
                    "rows": N, "nnz": nnz, "complex": True,

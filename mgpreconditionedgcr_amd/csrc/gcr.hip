@@ -452,6 +452,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     __syncthreads();
     // closing (restart > 8: the cycle-closing step is close_x_kernel + this kernel with NDT = restart, writing
     // Ap_0' over slot 0 in place): no table row — the next cycle starts a new table
+    if constexpr (NDT < LND)   // NDT == LND only ever runs as the closing step of a restart-16 cycle
     if (!closing && blockIdx.x == 0 && (int)threadIdx.x <= NDT) {
         // one thread per column of the new table row (thread 0: t_k, thread k: the unit diagonal), so that the
         // loads of a column are independent and the whole row costs one memory round trip, not k^2 / 2 of them —
