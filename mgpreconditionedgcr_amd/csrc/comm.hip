@@ -145,7 +145,16 @@ constexpr size_t PW_MBOX_WORDS = (size_t)2 * PW_MAX_RANKS * PW_MAX_SCALARS * 2;
 // wall_clock64 runs at 100 MHz.  Self-tests (ranks just synchronised by a set-up collective): 3 s.  Production: 20 s — the
 // ranks of one solve may arrive skewed (one of them still reading a file), but a wave must never spin anywhere near the
 // driver's compute-queue watchdog (60 s).
-constexpr long long PW_TIMEOUT_TEST = 300000000LL, PW_TIMEOUT_RUN = 2000000000LL;
+constexpr long long PW_TIMEOUT_TEST = 300000000LL;
+static long long pw_timeout_run() {  // MGCR_PEER_TIMEOUT_MS (tests shorten it), clamped to 1 ms .. 30 s
+    static const long long ticks = [] {
+        long long ms = 20000;
+        if (const char *e = getenv("MGCR_PEER_TIMEOUT_MS")) ms = atoll(e);
+        ms = ms < 1 ? 1 : ms > 30000 ? 30000 : ms;
+        return ms * 100000LL;
+    }();
+    return ticks;
+}
 
 __global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ pa, int na, const double *__restrict__ pb, int nb,
                                                      double *__restrict__ out, int nblk, PwPeers peers, int rank, int nranks,
@@ -206,7 +215,7 @@ static int pw_launch(Comm *c, const double *pa, int na, const double *pb, int nb
     PwPeers peers;
     for (int r = 0; r < PW_MAX_RANKS; r++) peers.mb[r] = c->pw_peer[r < c->nranks ? r : c->rank];
     hipLaunchKernelGGL(fold_pw_kernel, dim3(na + nb), dim3(64), 0, ctx().stream, pa, na, pb, nb, out, nblk, peers, c->rank, c->nranks,
-                       pw_next_seq(c), c->pw_err, c->pw_on ? PW_TIMEOUT_RUN : PW_TIMEOUT_TEST);
+                       pw_next_seq(c), c->pw_err, c->pw_on ? pw_timeout_run() : PW_TIMEOUT_TEST);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -588,7 +597,7 @@ static int halo_pw_launch(DistCsr *d, const cplx *x) {
     if (d->pw_seq == 0) d->pw_seq = 1;
     const int np = (int)d->plan->peers.size();
     hipLaunchKernelGGL(halo_pw_kernel, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
-                       (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, d->pw_on ? PW_TIMEOUT_RUN : PW_TIMEOUT_TEST);
+                       (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, d->pw_on ? pw_timeout_run() : PW_TIMEOUT_TEST);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -1012,6 +1021,7 @@ int mgcr_comm_bench_allreduce(mgcr_comm_t c, int32_t count, int32_t reps, double
     hipEventElapsedTime(&ms, cx.ev0, cx.ev1);
     hipFree(d);
     *us_avg = 1e3 * (double)ms / reps;
+    if (rc == MGCR_OK) rc = comm_check(c);
     return rc;
 }
 

@@ -108,6 +108,32 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if mode == "pw-timeout":
+        # a rank that never arrives: the peer-write wait must give up after its time limit and surface MGCR_ERR_COMM
+        # (never spin on the GPU forever); MGCR_PEER_TIMEOUT_MS is shortened by the test
+        import ctypes
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistSparse
+        mg.init(0)
+        N, rowptr, col, val, gran = problem("poisson")
+        offs = split_rows(N // gran, world)
+        r0, r1 = offs[rank] * gran, offs[rank + 1] * gran
+        lp, lc, lv = local_block(rowptr, col, val, r0, r1)
+        A = DistSparse(comm, N, r0, lp, lc, lv)        # collective: self-tests pass here
+        results["kind"] = comm.allreduce_kind
+        us = ctypes.c_double()
+        rc = 0
+        if rank == 0 and results["kind"] == "peer-write":   # rank 1 stays away from this all-reduce
+            import time
+            t0 = time.time()
+            rc = mg.lib().mgcr_comm_bench_allreduce(comm.h, 4, 1, ctypes.byref(us))
+            results["seconds"] = time.time() - t0
+            results["error"] = mg.lib().mgcr_last_error().decode()
+        results["rc"] = rc
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        os._exit(0)   # the communicator is unusable after the timeout: skip its destructors
     if mode == "nullvec":
         # MG::Arnoldi (src/MG.h:90-122) on a distributed operator: the inverse iteration's norms and the Gram-Schmidt
         # dot products must be GLOBAL (Comm.dot), and the start vector the same global vector on every world size

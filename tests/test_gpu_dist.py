@@ -109,6 +109,18 @@ print("RCCL_OK")
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
+def test_peer_write_wait_times_out_cleanly(tmp_path, monkeypatch):
+    """A rank that never joins an all-reduce: the waiting kernel gives up after its time limit (here 300 ms) and the
+    call returns MGCR_ERR_COMM — no wave spins on the GPU without bound."""
+    monkeypatch.setenv("MGCR_PEER_TIMEOUT_MS", "300")
+    res = run_workers("pw-timeout", 2, tmp_path, timeout=300)
+    if res[0]["kind"] != "peer-write":
+        pytest.skip("peer-write path not available here (%s)" % res[0]["kind"])
+    assert res[0]["rc"] != 0 and "did not arrive" in res[0]["error"], res[0]
+    assert res[0]["seconds"] < 30.0
+    assert res[1]["rc"] == 0
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_near_null_vectors(tmp_path, world):
     """MG_Param without given null vectors on a distributed operator: the inverse iteration (src/MG.h:90-122) runs with
