@@ -419,6 +419,18 @@ __device__ __forceinline__ void close_step(DevState *st, int it, double rr, doub
     if (clear_pending) st->npend = 0;
 }
 
+// Bookkeeping of a step without the direction build (src/GCR.h:270-274,288): the LAST iteration a solve can run
+// (count == max_iter) still updates x and r and records |r|, but the next search direction the reference goes on to
+// build (src/GCR.h:236-287: M r, A r, the beta dots, p, Ap) is never used — gcr_run stops after this kernel.
+__global__ void __launch_bounds__(RED_THREADS) finish_step_kernel(DevState *st, int it, const double *__restrict__ partsR, int nblkR,
+                                                                  int strideR, double *__restrict__ hist, int hist_cap) {
+    __shared__ double lds[17];
+    if (st->stop_at < st->base + it) return;
+    double rr[1];
+    fold_partials<1>(partsR, nblkR, strideR, rr, lds);
+    if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, false);
+}
+
 // LEAN, inside a restart cycle: direction k = NDT is started from D_k (the residual, or M r) and only
 // its image is formed:  Ap_k = Ar - sum_{j<k} beta_j Ap_j  (same order as build_kernel), with the
 // <r,Ap_k>, <Ap_k,Ap_k> partials; workgroup 0 extends the coefficient table by row k:
@@ -1094,6 +1106,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
 
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
+    // the literal r = M(r) of src/GCR.h:236-238 changes the residual that is recorded: that mode keeps the full last step
+    const bool skip_tail = !p.right_precond || flex;
     int check_every = p.check_every > 0 ? p.check_every : 10;
     const cplx *rcur = alias0 ? rhs : s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
     // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
@@ -1113,7 +1127,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     bool done = false;
     std::vector<hipEvent_t> prof_events;
     // one iteration, enqueued on the library stream; `it` = iteration number relative to DevState::base
-    auto one_iteration = [&](int it) -> int {
+    auto one_iteration = [&](int it, bool last = false) -> int {
         iter_count++;
         set_apply_skip(SkipRef{&s->st->stop_at, it});
         auto mark = [&]() -> int {
@@ -1163,6 +1177,22 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             dir = s->r;
             KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, it);
         }
+        }
+        if (last && skip_tail) {
+            // nothing after this iteration: no preconditioner apply, no A r, no beta dots, no direction build — only the
+            // step's bookkeeping (the x updates still pending are applied by flush_x_kernel below)
+            MGCR_TRY(mark());
+            MGCR_TRY(mark());
+            RedRef fr = refR;
+            if (multi) {
+                MGCR_TRY(comm_fold_allreduce(comm, s->partsR, 1, nullptr, 0, s->dRB, g));
+                fr = {s->dRB, 1, 1};
+            }
+            KLAUNCH(finish_step_kernel, 1, s->st, it, fr.p, fr.nblk, fr.stride, s->hist, s->hist_cap);
+            MGCR_TRY(mark());
+            iter_count = ic_next;
+            cur = nxt;
+            return MGCR_OK;
         }
         MGCR_TRY(mark());
         const int nchunk = (lim + ND - 1) / ND;
@@ -1276,7 +1306,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         } else {
             global++;
             rel++;
-            MGCR_TRY(one_iteration(rel));
+            MGCR_TRY(one_iteration(rel, global == max_it));
         }
         if (!nested && (global / check_every != last_check || global == max_it)) {
             last_check = global / check_every;

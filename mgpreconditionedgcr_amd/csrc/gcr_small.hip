@@ -144,6 +144,13 @@ __global__ void __launch_bounds__(SMALL_THREADS) gcr_small_kernel(SmallArgs a) {
             }
         }
         block_sum_bcast<1>(rr1, lds);  // (its barriers also publish r for the gather below)
+        if (global == max_it) {
+            // last iteration the solve can run: the direction the reference goes on to build (src/GCR.h:236-287) is
+            // never used — record the step and stop (gcr.hip: finish_step_kernel)
+            if (tid == 0 && global < a.hist_cap) a.hist[global] = sqrt(rr1[0]) / sqrt(bnorm2);
+            if (!((rr1[0] / bnorm2) > a.tol2)) stop = global;
+            break;
+        }
         // Ar = A r; <Ar, Aps_j>                             (src/GCR.h:242,258)
         const int lim = a.storage < iter_count ? a.storage : iter_count;
         double vb[2 * SMALL_MAX_DIRS];
