@@ -99,6 +99,10 @@ struct GcrState {
 
 constexpr int64_t GRAPH_MAX_ROWS = 1 << 18;
 
+static bool fuse_init_enabled() {
+    static const bool on = !(getenv("MGCR_FUSE_INIT") && atoi(getenv("MGCR_FUSE_INIT")) == 0);
+    return on;
+}
 static int g_graph = -1;
 static bool graphs_enabled() {
     // opt-in (MGCR_GRAPH=1 / mgcr_set_option("graph_replay")): see the measurements at the capture site in gcr_run
@@ -1058,6 +1062,19 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool alias_p0 = lean && !flex && p.max_iter >= 1 && p.max_iter < p.restart;
     const bool alias0 = alias_p0 && !p.use_x0;
     const cplx *p0 = alias0 ? rhs : alias_p0 ? (const cplx *)s->r : (const cplx *)s->ps[0];
+    // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
+    // row -> workgroup map of the dot-product kernels (gcr_dev.h): depends on how far the operator's rows reach
+    int64_t reach = 0;
+    {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        if (b0 && b0->kind == OP_CSR) reach = b0->csr.reach;
+    }
+    const RowMap rmap = make_row_map(n, g, reach);
+    bool fuse_ok = false;
+    if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !p.left_precond) {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        fuse_ok = b0->kind == OP_CSR && csr_fusable(b0->csr, b0->dist) && b0->csr.nrow == n;
+    }
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
         MGCR_TRY(op_residual_raw(s->A, x, rhs, s->r, n));
@@ -1071,7 +1088,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     } else if (!alias_p0) {
         MGCR_TRY(k_copy(s->ps[0], s->r, n));
     }
-    MGCR_TRY(op_apply_raw(s->A, p0, s->aps[0], n));
+    // step 0 of a smoother-like solve on a fusable Sparse / DiracOp: Ap_0 and its dot products in one pass (gcr_fused.hip)
+    const bool fuse_init = fuse_ok && alias_p0 && fuse_init_enabled();
+    if (!fuse_init) MGCR_TRY(op_apply_raw(s->A, p0, s->aps[0], n));
     if (!flex) {  // literal hooks, src/GCR.h:197-204 (after p and Ap were formed)
         if (p.right_precond) { MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
         if (p.left_precond) { MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
@@ -1084,7 +1103,11 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     MGCR_CHECK(!multi || (!p.left_precond && (!p.right_precond || flex)), MGCR_ERR_UNSUPPORTED,
                "on a distributed operator only flexible right preconditioning is available (set flexible = 1)");
     const DevState *cst = s->st;
-    if (alias0) {
+    if (fuse_init) {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        MGCR_TRY(csr_init_apply(b0->csr, p0, s->aps[0], s->A->kind == OP_DIRAC, s->A->k, alias0 ? (const cplx *)nullptr : rhs, s->partsA,
+                                s->partsR, s->partsN, b0->dist, rmap));
+    } else if (alias0) {
         KLAUNCH(init3_partials_kernel, g, rhs, (const cplx *)s->aps[0], n, s->partsN, s->partsR, s->partsA, cst, 0);
     } else if (alias_p0) {
         KLAUNCH(norm_partials_kernel, g, rhs, n, s->partsN, cst, 0);
@@ -1110,19 +1133,6 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool skip_tail = !p.right_precond || flex;
     int check_every = p.check_every > 0 ? p.check_every : 10;
     const cplx *rcur = alias0 ? rhs : s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
-    // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
-    // row -> workgroup map of the dot-product kernels (gcr_dev.h): depends on how far the operator's rows reach
-    int64_t reach = 0;
-    {
-        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
-        if (b0 && b0->kind == OP_CSR) reach = b0->csr.reach;
-    }
-    const RowMap rmap = make_row_map(n, g, reach);
-    bool fuse_ok = false;
-    if ((s->A->kind == OP_CSR || s->A->kind == OP_DIRAC) && !p.left_precond) {
-        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
-        fuse_ok = b0->kind == OP_CSR && csr_fusable(b0->csr, b0->dist) && b0->csr.nrow == n;
-    }
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;

@@ -85,6 +85,60 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
     }
 }
 
+
+// Step 0 of a solve whose first direction is its start residual (lean smoothers, gcr.hip alias_p0): Ap_0 = A r_0
+// AND the partial sums of <r_0,Ap_0>, <Ap_0,Ap_0>, |r_0|^2 — and |b|^2 when b is not r_0 — in ONE pass, instead
+// of the operator apply followed by init3_partials_kernel (+ norm_partials_kernel): r_0 is the row's own x entry
+// and Ap_0 the row's result.  Same launch shape and row map as step_apply_kernel; while that map is the plain
+// grid-stride (gcr_dev.h: everything below 256^3) the sums have the order, hence the bits, of those two kernels.
+template <int MODE, int WT>
+__global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                                    const cplx *__restrict__ b, int64_t n, int nlogical, RowMap rm,
+                                                                    double *__restrict__ partsA, double *__restrict__ partsR,
+                                                                    double *__restrict__ partsN, const int *__restrict__ skip, int skip_it) {
+    __shared__ double lds[6 * 17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    const int per = (int)(gridDim.x >> 3);
+    const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (lb >= nlogical) return;
+    const int32_t W = WT ? WT : m.W;
+    int64_t i, end, stride;
+    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    int32_t t0 = 0;
+    if (MODE != 0 && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    PatLds pl{nullptr, nullptr, nullptr};
+    if (MODE == 1) pl = stage_patterns(m, step_smem);
+    double v[6] = {0., 0., 0., 0., 0., 0.};
+    for (; i < end; i += stride) {
+        int32_t t0_next = 0;
+        if (MODE != 0 && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
+        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
+        const cplx rv = x[i];
+        const cplx yi = m.shift ? csub(rv, cmul(m.k, sum)) : sum;
+        y[i] = yi;
+        v[4] += rv.x * rv.x + rv.y * rv.y;
+        const cplx t = cconj_mul(rv, yi);
+        v[0] += t.x; v[1] += t.y;
+        const cplx u = cconj_mul(yi, yi);
+        v[2] += u.x; v[3] += u.y;
+        if (b) {
+            const cplx bv = ld_stream<true>(b + i);
+            v[5] += bv.x * bv.x + bv.y * bv.y;
+        }
+        t0 = t0_next;
+    }
+    block_sum_bcast<6>(v, lds);
+    if (threadIdx.x < 4) {
+        double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
+        partsA[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    }
+    if (threadIdx.x == 4) {
+        partsR[lb] = v[4];
+        partsN[lb] = b ? v[5] : v[4];
+    }
+}
+
 static int g_fuse = -1;
 static bool fuse_enabled() {
     if (g_fuse < 0) g_fuse = !(getenv("MGCR_FUSE") && atoi(getenv("MGCR_FUSE")) == 0);
@@ -152,6 +206,34 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
     else if (A.pat_mode == 2) ST_W(2);
     else ST_W(0);
 #undef ST_W
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+
+
+// aps0 = A r0 (or r0 - k A r0) + the partials of <r0,aps0>, <aps0,aps0> (partsA), |r0|^2 (partsR) and |b|^2 (partsN;
+// b == nullptr: b IS r0); layouts of gcr.hip's init3_partials_kernel; dist as in csr_step_apply
+int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx k, const cplx *b, double *partsA, double *partsR,
+                   double *partsN, DistCsr *dist, const RowMap &rm) {
+    MGCR_CHECK(r0 != aps0, MGCR_ERR_INVALID, "SpMV cannot run in place");
+    RowMat m = row_mat(A, shift, k);
+    if (dist) {
+        m.n_own = (int32_t)A.nrow;
+        MGCR_TRY(dist_halo_begin(dist, r0));
+        MGCR_TRY(dist_halo_end(dist));
+        m.xh = dist_halo_ptr(dist);
+    }
+    const int g = red_grid(A.nrow);
+    const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
+    const size_t lds_bytes = row_mat_lds_bytes(A);
+    const SkipRef sk = get_apply_skip();
+#define IA(MODE, WT)                                                                                                            \
+    hipLaunchKernelGGL((init_apply_kernel<MODE, WT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r0, aps0, b, A.nrow, g, \
+                       rm, partsA, partsR, partsN, sk.p, sk.it)
+    if (A.pat_mode == 1) { if (A.W == 7) IA(1, 7); else IA(1, 0); }
+    else if (A.pat_mode == 2) { if (A.W == 7) IA(2, 7); else IA(2, 0); }
+    else { if (A.W == 7) IA(0, 7); else IA(0, 0); }
+#undef IA
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }

@@ -155,6 +155,8 @@ bool csr_fusable(const CsrDev &A, const DistCsr *dist);
 struct RowMap;  // gcr_dev.h
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
                    DistCsr *dist, const RowMap &rm);
+int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx k, const cplx *b, double *partsA, double *partsR,
+                   double *partsN, DistCsr *dist, const RowMap &rm);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
                       const double *h_blocks, BcsrDev *out);
 void bcsr_free(BcsrDev *b);

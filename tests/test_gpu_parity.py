@@ -455,6 +455,23 @@ def test_fused_apply_and_dots_same_bits(fmt, mode):
         out.append((g.last_history.copy(), x.to_numpy()))
     assert out[0][0].size > 5
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # smoother-shaped solves (fewer iterations than restart slots): step 0 — Ap_0 = A r_0 with <r_0,Ap_0>, <Ap_0,Ap_0>,
+    # |r_0|^2 and |b|^2 — is one kernel too (gcr_fused.hip init_apply_kernel), from x0 = 0 and from a given x0
+    if "restart" in mode:
+        x0 = problems.rhs_grid(n, 4) * 0.1
+        for use_x0 in (False, True):
+            out = []
+            for on in (1, 0):
+                prev = mg.set_option("fused_apply", on)
+                try:
+                    g = GCR(op, GCR_Param(0, 10, 3, 1e-30, False, use_x0=use_x0))
+                    x = Field((n,), x0) if use_x0 else Field((n,)).set_zero()
+                    g.solve(b, x)
+                finally:
+                    mg.set_option("fused_apply", prev)
+                out.append((g.last_history.copy(), x.to_numpy()))
+            assert out[0][0].size == 4
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
 def test_graph_replay_same_results():
