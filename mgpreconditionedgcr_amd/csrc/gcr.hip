@@ -73,6 +73,7 @@ struct GcrState {
     Op *A = nullptr;
     mgcr_gcr_param p{};
     int x0_mode = 1;
+    bool x_from_zero = false;  // next gcr_run: x0 = 0 and x's content is garbage (gcr_run_from_zero)
     int64_t n = 0;
     int storage = 0, restart = 0;
     std::vector<cplx *> ps, aps;
@@ -243,11 +244,11 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
 
 // applies the x updates still pending when the solve ends (never skipped)
 __global__ void __launch_bounds__(RED_THREADS) flush_x_kernel(DevState *__restrict__ st, const cplx *__restrict__ alphas, DirPtrs d0,
-                                                              cplx *__restrict__ x, int64_t n) {
+                                                              cplx *__restrict__ x, int64_t n, int assign) {
     const int np = st->npend;
-    if (np <= 0) return;
+    if (np <= 0) return;   // (also when an outer solver's stop predicate turned this whole solve into a no-op)
     GRID_STRIDE(i, n) {
-        cplx xv = x[i];
+        cplx xv = assign ? make_double2(0., 0.) : x[i];   // assign: x0 = 0 was never materialised (gcr_run: assign_x)
         for (int j = 0; j < np && j < LND; j++) xv = cadd(xv, cmul(alphas[j], d0.ps[j][i]));
         x[i] = xv;
     }
@@ -1036,9 +1037,12 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const int g = red_grid(n);
     const bool flex = p.flexible && p.right_precond;
     const SkipRef outer = get_apply_skip();  // outer solver's predicate: if that solve is over, this one is a no-op too
+    const bool from_zero = s->x_from_zero;   // gcr_run_from_zero: x has to be zeroed here, unless the solve only ever ASSIGNS x
+    s->x_from_zero = false;
 
     // small systems: the whole solve in one launch of one workgroup (gcr_small.hip)
     if (gcr_small_eligible(s->A, p, s->storage, n)) {
+        if (from_zero) MGCR_TRY(k_zero_apply(x, n));
         MGCR_TRY(ensure_slot(s, s->storage - 1));
         MGCR_TRY(gcr_small_run(s->A, p, s->storage, s->restart, rhs, x, s->r, s->ar, s->ps.data(), s->aps.data(), s->hist,
                                s->hist_cap, &s->st->stop_at));
@@ -1062,6 +1066,10 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool alias_p0 = lean && !flex && p.max_iter >= 1 && p.max_iter < p.restart;
     const bool alias0 = alias_p0 && !p.use_x0;
     const cplx *p0 = alias0 ? rhs : alias_p0 ? (const cplx *)s->r : (const cplx *)s->ps[0];
+    // From x0 = 0, a solve that never closes a restart cycle touches x exactly once: flush_x_kernel at the end adds the
+    // pending updates.  That kernel can just as well WRITE x = sum alpha_j p_j: no zeroing pass before, no read of x then.
+    const bool assign_x = from_zero && alias_p0 && !p.use_x0;
+    if (from_zero && !assign_x) MGCR_TRY(k_zero_apply(x, n));
     // operator apply fused with the beta dot products: Sparse / DiracOp in a one-thread-per-row layout
     // row -> workgroup map of the dot-product kernels (gcr_dev.h): depends on how far the operator's rows reach
     int64_t reach = 0;
@@ -1330,7 +1338,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         DirPtrs d0;
         for (int j = 0; j < LND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
         d0.ps[0] = p0;
-        KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n);
+        KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n, assign_x ? 1 : 0);
         hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);
         MGCR_HIP(hipGetLastError());
     }
@@ -1353,12 +1361,18 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     return frc;
 }
 
+// nested solve from x0 = 0 into an x whose content does not matter (smoothers, coarsest solve, GCR as a preconditioner)
+int gcr_run_from_zero(GcrState *s, const cplx *rhs, cplx *x) {
+    s->x_from_zero = true;
+    return gcr_run(s, rhs, x, true, nullptr, 0, nullptr, nullptr);
+}
+
 // x = init_rand(2) in the reference (src/GCR.h:63-68); here the caller-provided x0 or zero
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y) {
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
     const int64_t n = s->A->dim;
     if (s->x0_mode == 0 && s->x0) MGCR_TRY(k_copy_apply(y, s->x0, n));
-    else MGCR_TRY(k_zero_apply(y, n));
+    else return gcr_run_from_zero(s, f, y);
     return gcr_run(s, f, y, true, nullptr, 0, nullptr, nullptr);
 }
 

@@ -226,11 +226,9 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     MgLevel &L = m->lev[(size_t)l];
     const int nlev = (int)m->lev.size();
     if (l == nlev - 1) {
-        MGCR_TRY(k_zero_apply(x, L.n));
-        return gcr_run(L.coarse, b, x, true, nullptr, 0, nullptr, nullptr);
+        return gcr_run_from_zero(L.coarse, b, x);
     }
-    MGCR_TRY(k_zero_apply(x, L.n));
-    MGCR_TRY(gcr_run(L.pre, b, x, true, nullptr, 0, nullptr, nullptr));
+    MGCR_TRY(gcr_run_from_zero(L.pre, b, x));
     MGCR_TRY(op_residual_raw(L.A, x, b, L.r, L.n));  // one pass for a Sparse (b enters the SpMV epilogue)
     MgLevel &C = m->lev[(size_t)l + 1];
     MGCR_TRY(mg_restrict(m, l, L.r, C.b));
