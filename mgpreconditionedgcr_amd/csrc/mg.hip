@@ -42,9 +42,23 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
     int64_t a = c / ne;
     int k = (int)(c - a * ne);
     cplx s = make_double2(0., 0.);
-    for (int32_t m = aptr[a]; m < aptr[a + 1]; m++) {
-        int32_t i = amem[m];
-        s = cadd(s, cconj_mul(pv[(int64_t)i * ne + k], x[i]));
+    // members in batches of 8 (one 2^3 aggregate): the 8 index loads, then the 16 value loads, are issued together
+    // instead of one dependent index -> value chain per member; the sum keeps the members' order
+    const int32_t beg = aptr[a], end = aptr[a + 1];
+    for (int32_t m0 = beg; m0 < end; m0 += 8) {
+        int32_t idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) idx[u] = m0 + u < end ? amem[m0 + u] : -1;
+        cplx pvv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t i = idx[u] >= 0 ? idx[u] : 0;
+            pvv[u] = pv[i * ne + k];
+            xv[u] = x[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (idx[u] >= 0) s = cadd(s, cconj_mul(pvv[u], xv[u]));
     }
     xc[c] = s;
 }
