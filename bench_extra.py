@@ -173,14 +173,14 @@ def main():
             # What THIS implementation moves per V-cycle on the levels above the coarsest (row-pattern storage: 2 B per
             # row + table per matrix pass; a smoother = 2 sweeps of lean GCR(10) whose last sweep stops after the x/r
             # update): pre-smoother from x0 = 0: [A r0 + its dots: M + 2V] + [xr 3V] + [A r + dots: M + 3V] + [build 4V]
-            # + [xr 3V] + [x = sum: 3V] = 2M + 18V; residual M + 3V; restrict V + Vc; prolong+add Vc + 2V; post-smoother
+            # + [xr 3V] + [x = sum: 3V] = 2M + 18V; no residual pass (the smoother's recurrence residual is restricted); restrict V + Vc; prolong+add Vc + 2V; post-smoother
             # from x: [b - A x: M + 3V] + [A r0 + dots, |b|^2: M + 3V] + 3V + [M + 3V] + 4V + 3V + [x += : 4V] = 3M + 23V.
             # The survey model above counts the reference layout (20 B per non-zero) and full last sweeps instead.
             moved, nl = 0, n
             for l in range(args.levels):
                 Nl = nl ** 3
                 Vl, Vc, Mb = 16 * Nl, 16 * (nl // 2) ** 3, 2 * Nl
-                moved += 6 * Mb + 47 * Vl + 2 * Vc
+                moved += 5 * Mb + 44 * Vl + 2 * Vc
                 nl //= 2
             out["vcycle_bytes_moved_model_excl_coarsest"] = moved
             out["vcycle_GBps_moved_lower_bound"] = moved / (out["vcycle_ms"] * 1e-3) / 1e9   # the time includes the coarsest solve

@@ -73,6 +73,7 @@ struct GcrState {
     Op *A = nullptr;
     mgcr_gcr_param p{};
     int x0_mode = 1;
+    std::vector<const cplx *> r_after;  // r_after[k]: where step k of the last solve left its residual (empty: not tracked)
     bool x_from_zero = false;  // next gcr_run: x0 = 0 and x's content is garbage (gcr_run_from_zero)
     int64_t n = 0;
     int storage = 0, restart = 0;
@@ -1046,6 +1047,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         MGCR_TRY(ensure_slot(s, s->storage - 1));
         MGCR_TRY(gcr_small_run(s->A, p, s->storage, s->restart, rhs, x, s->r, s->ar, s->ps.data(), s->aps.data(), s->hist,
                                s->hist_cap, &s->st->stop_at));
+        s->r_after.assign((size_t)(p.max_iter > 0 ? p.max_iter : 1) + 1, (const cplx *)s->r);
         if (nested) return MGCR_OK;
         return gcr_finish(s, hist, hist_cap, n_iter, converged);
     }
@@ -1139,6 +1141,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
     // the literal r = M(r) of src/GCR.h:236-238 changes the residual that is recorded: that mode keeps the full last step
     const bool skip_tail = !p.right_precond || flex;
+    // where each step leaves the (true recurrence) residual — not with the literal hooks, which replace r by M r
+    s->r_after.clear();
+    if (!p.left_precond && (!p.right_precond || flex) && max_it <= LND) s->r_after.assign((size_t)max_it + 1, nullptr);
     int check_every = p.check_every > 0 ? p.check_every : 10;
     const cplx *rcur = alias0 ? rhs : s->r;  // lean: where the current residual lives (s->r at the start of every cycle)
     int iter_count = 0, cur = 0, global = 0;
@@ -1196,6 +1201,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             KLAUNCH(norm_partials_kernel, g, (const cplx *)s->r, n, s->partsR, cst, it);
         }
         }
+        if (!s->r_after.empty() && global < (int)s->r_after.size()) s->r_after[(size_t)global] = lean ? rcur : (const cplx *)s->r;
         if (last && skip_tail) {
             // nothing after this iteration: no preconditioner apply, no A r, no beta dots, no direction build — only the
             // step's bookkeeping (the x updates still pending are applied by flush_x_kernel below)
@@ -1297,6 +1303,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const int R = s->restart;
     bool use_graph = graphs_enabled() && n <= GRAPH_MAX_ROWS && defer && !multi && !p.left_precond && !p.right_precond &&
                      !p.profile_spmv && max_it >= 2 * R && R <= s->storage;
+    if (use_graph) s->r_after.clear();   // replayed cycles do not pass through the host-side step counter
     if (use_graph && (s->graph_exec == nullptr || s->graph_x != x || s->graph_R != R || s->graph_n != n)) {
         if (s->graph_exec) { hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
@@ -1359,6 +1366,17 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);
     if (multi) MGCR_TRY(comm_check(comm));   // a peer-write wait that timed out poisoned the scalars with NaN
     return frc;
+}
+
+// the residual of the solve that just ran on `s`, selected on the device by the number of steps it took
+bool gcr_last_residual(GcrState *s, ResidualSel *out) {
+    if (s->r_after.size() < 2 || s->r_after.size() > (size_t)LND + 1) return false;
+    for (size_t k = 1; k < s->r_after.size(); k++)
+        if (!s->r_after[k]) return false;
+    for (int k = 0; k <= LND; k++) out->r[k] = s->r_after[(size_t)k < s->r_after.size() ? (size_t)k : s->r_after.size() - 1];
+    out->r[0] = s->r_after[1];
+    out->st = s->st;
+    return true;
 }
 
 // nested solve from x0 = 0 into an x whose content does not matter (smoothers, coarsest solve, GCR as a preconditioner)

@@ -30,6 +30,14 @@ struct DevState {
     double tol2;
 };
 
+// Where a finished solve left its recurrence residual, by the number of steps it actually ran (a solve that
+// converged early skipped the later steps' kernels): r[k] = residual after step k, k = 1..LND.  Consumers read
+// r[st->iter] (mg.hip: the residual a V-cycle restricts after its pre-smoother, without recomputing b - A x).
+struct ResidualSel {
+    const cplx *r[LND + 1];
+    const DevState *st;
+};
+
 struct DirPtrs {  // the classic kernels use the first ND entries (one chunk), the lean ones up to LND
     const cplx *ps[LND];
     const cplx *aps[LND];

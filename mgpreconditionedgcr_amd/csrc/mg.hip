@@ -20,6 +20,7 @@
 
 #include "internal.h"
 #include "reduce.h"
+#include "gcr_dev.h"
 
 namespace mgcr {
 
@@ -35,10 +36,14 @@ typedef std::complex<double> hc;
 __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const int32_t *__restrict__ aptr,
                                                        const int32_t *__restrict__ amem, const cplx *__restrict__ pv,
                                                        const cplx *__restrict__ x, cplx *__restrict__ xc,
-                                                       const int *__restrict__ skip, int skip_it) {
+                                                       const int *__restrict__ skip, int skip_it, ResidualSel sel) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
+    if (sel.st) {   // x = the residual the smoother that just ran ended with: its slot depends on how many steps it took
+        int k = sel.st->iter;
+        x = sel.r[k < 0 ? 0 : k > LND ? LND : k];
+    }
     int64_t a = c / ne;
     int k = (int)(c - a * ne);
     cplx s = make_double2(0., 0.);
@@ -211,16 +216,16 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
 static unsigned g256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 int mg_restrict_raw(int64_t nc, int ne, const int32_t *aptr, const int32_t *amem, const cplx *pv, const cplx *x, cplx *xc) {
-    hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, ne, aptr, amem, pv, x, xc, (const int *)nullptr, 0);
+    hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, ne, aptr, amem, pv, x, xc, (const int *)nullptr, 0, ResidualSel{});
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
 
-int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc) {
+int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc, const ResidualSel *sel) {
     MgLevel &L = m->lev[(size_t)l];
     int64_t nc = L.nagg * L.ne;
     hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, L.ne, L.d_aptr, L.d_amem, L.d_pv, x, xc,
-                       get_apply_skip().p, get_apply_skip().it);
+                       get_apply_skip().p, get_apply_skip().it, sel ? *sel : ResidualSel{});
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -236,6 +241,11 @@ int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double dampi
 // Corrected cycle (report Algorithm 2; the structure of src/MG.h:405-430 with its defects fixed,
 // see DESIGN.md):  x = S(b) from x0 = 0;  r = b - A x;  b_c = R r;  x_c = cycle(l+1) | coarsest GCR
 // from x0 = 0;  x += damping * P x_c;  x = S(b, x0 = x).
+static bool recurrence_residual_enabled() {
+    static const bool on = !(getenv("MGCR_MG_RECURRENCE_RESIDUAL") && atoi(getenv("MGCR_MG_RECURRENCE_RESIDUAL")) == 0);
+    return on;
+}
+
 static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     MgLevel &L = m->lev[(size_t)l];
     const int nlev = (int)m->lev.size();
@@ -243,9 +253,17 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
         return gcr_run_from_zero(L.coarse, b, x);
     }
     MGCR_TRY(gcr_run_from_zero(L.pre, b, x));
-    MGCR_TRY(op_residual_raw(L.A, x, b, L.r, L.n));  // one pass for a Sparse (b enters the SpMV epilogue)
     MgLevel &C = m->lev[(size_t)l + 1];
-    MGCR_TRY(mg_restrict(m, l, L.r, C.b));
+    // The residual to restrict is the one the pre-smoother's recurrence ended with (r_k = r_{k-1} - alpha A p_{k-1}: b - A x
+    // up to rounding) — no further pass over A, x and b.  Solvers with the literal preconditioner hooks, or of more
+    // than 16 sweeps, do not offer it: b - A x is then recomputed (one pass for a Sparse, b enters the SpMV epilogue).
+    ResidualSel sel;
+    if (recurrence_residual_enabled() && gcr_last_residual(L.pre, &sel)) {
+        MGCR_TRY(mg_restrict(m, l, nullptr, C.b, &sel));
+    } else {
+        MGCR_TRY(op_residual_raw(L.A, x, b, L.r, L.n));
+        MGCR_TRY(mg_restrict(m, l, L.r, C.b, nullptr));
+    }
     MGCR_TRY(mg_cycle(m, l + 1, C.b, C.x));
     MGCR_TRY(mg_expand(m, l, C.x, x, true, m->damping));
     return gcr_run(L.post, b, x, true, nullptr, 0, nullptr, nullptr);
@@ -257,7 +275,7 @@ int mg_apply(MgState *m, const cplx *f, cplx *y) { return mg_cycle(m, 0, f, y); 
 
 using namespace mgcr;
 namespace mgcr {
-int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc);
+int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc, const ResidualSel *sel);
 int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping);
 }  // namespace mgcr
 
@@ -296,7 +314,7 @@ int mgcr_mg_restrict(mgcr_op_t mg, int32_t level, mgcr_vec_t fine, mgcr_vec_t co
     const MgLevel &L = mg->mg->lev[(size_t)level];
     MGCR_CHECK(fine->n == L.n && coarse->n == L.nagg * L.ne, MGCR_ERR_INVALID, "Lengths of two fields do not match!");
     LOCK();
-    return mg_restrict(mg->mg, level, fine->d, coarse->d);
+    return mg_restrict(mg->mg, level, fine->d, coarse->d, nullptr);
 }
 
 int mgcr_mg_expand(mgcr_op_t mg, int32_t level, mgcr_vec_t coarse, mgcr_vec_t fine) {

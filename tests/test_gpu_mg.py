@@ -71,6 +71,36 @@ def test_g9_pieces_vs_reference(sample_matrix_path, mg_gold):
     assert (lhs - rhs).norm() <= 1e-13 * lhs.norm()
 
 
+@pytest.mark.parametrize("n,sm_tol,sm_its", [(16, 0.9, 2), (16, 0.15, 4), (8, 0.9, 2), (16, 1e-30, 3)])
+def test_cycle_restricts_the_residual_the_smoother_ended_with(n, sm_tol, sm_its):
+    """The V-cycle restricts the pre-smoother's recurrence residual instead of recomputing b - A x (mg.hip).  Which
+    ring slot holds it depends on how many sweeps the smoother actually ran: with a loose smoother tolerance it stops
+    before max_iter and the later sweeps' kernels are skipped.  One cycle must still agree with the oracle, which forms
+    b - A x explicitly (n = 8: the coarse levels and, forced, the fine level take the one-workgroup solver)."""
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    b = problems.rhs_grid(N, 6)
+    ones = np.ones((1, N), np.complex128)
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    sm_o = orc.gcr_param(restart=10, max_iter=sm_its, tol=sm_tol)
+    co_o = orc.gcr_param(restart=10, max_iter=50, tol=1e-2)
+    Mo = orc.MG(Ao, rowptr, col, val, (n, n, n), (1, 1, 1), 2, ones, 2, sm_o, co_o)
+    # the smoother really does stop early in the cases that ask for it
+    _, _, its_sm, _ = orc.gcr_solve(Ao, sm_o, b)
+    assert (its_sm < sm_its) == (sm_tol > 1e-20), (its_sm, sm_its)
+    A = Sparse(N, ncol, rowptr, col, val)
+    prm = MG_Param(Mesh((n, n, n)), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, sm_its, sm_tol, False)),
+                   1, None, None, null_vectors=ones)
+    if n == 8:
+        mg.lib().mgcr_set_small_solve_rows(16384)
+    try:
+        M = MG(A, prm)
+        y = M(Field((n, n, n), b)).to_numpy()
+    finally:
+        mg.lib().mgcr_set_small_solve_rows(1024)
+    yo = Mo(b)
+    assert np.abs(y - yo).max() <= 1e-9 * np.abs(yo).max()
+
+
 @pytest.mark.parametrize("n,levels", [(16, 1), (16, 2), (32, 2)])
 def test_mg_gcr_poisson_vs_oracle(n, levels):
     """BASELINE config 3 shape at small size: piecewise-constant aggregation (2^3), Galerkin
