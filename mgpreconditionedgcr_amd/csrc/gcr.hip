@@ -74,6 +74,7 @@ struct GcrState {
     mgcr_gcr_param p{};
     int x0_mode = 1;
     std::vector<const cplx *> r_after;  // r_after[k]: where step k of the last solve left its residual (empty: not tracked)
+    bool discard_residual = false;  // nested solves whose caller only wants x (post-smoother, coarsest solve): see alpha_only_kernel
     bool x_from_zero = false;  // next gcr_run: x0 = 0 and x's content is garbage (gcr_run_from_zero)
     int64_t n = 0;
     int storage = 0, restart = 0;
@@ -423,6 +424,25 @@ __device__ __forceinline__ void close_step(DevState *st, int it, double rr, doub
     // continue while |r|^2/|b|^2 > tol^2 (src/GCR.h:288); NaN compares false -> stop, like the reference
     if (!((rr / st->bnorm2) > st->tol2)) st->stop_at = git;
     if (clear_pending) st->npend = 0;
+}
+
+// The last step of a nested solve whose caller only wants x (V-cycle post-smoother, coarsest solve): alpha and the
+// pending-x bookkeeping of xr_update_kernel<true, true>, without its pass over r and Ap — nobody reads that residual.
+__global__ void __launch_bounds__(RED_THREADS) alpha_only_kernel(DevState *st, int it, const double *__restrict__ partsA, int nblkA,
+                                                                 int strideA, cplx *__restrict__ den_slot, int slot,
+                                                                 LeanCoef *__restrict__ lc) {
+    __shared__ double lds[4 * 17];
+    if (st->stop_at < st->base + it) return;
+    double s[4];
+    fold_partials<4>(partsA, nblkA, strideA, s, lds);
+    const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
+    const cplx alpha = to_sgpr(cdiv(num, den));
+    if (threadIdx.x == 0) {
+        *den_slot = den;
+        st->npend = slot + 1;
+        st->iter = st->base + it;
+    }
+    if ((int)threadIdx.x < LND) lean_pending_update(lc, slot, alpha, (int)threadIdx.x);
 }
 
 // Bookkeeping of a step without the direction build (src/GCR.h:270-274,288): the LAST iteration a solve can run
@@ -1175,11 +1195,19 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             // the step that closes the cycle only needs it for its own build
             cplx *dslot = nxt >= 1 ? s->ps[nxt] : (flex ? s->z : s->r);
             cplx *r_out = flex ? s->r : dslot;
+            if (last && skip_tail && nested && s->discard_residual && !multi) {
+                KLAUNCH(alpha_only_kernel, 1, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc);
+                s->r_after.clear();
+                for (int k = 0; k < 3; k++) MGCR_TRY(mark());
+                iter_count = ic_next;
+                cur = nxt;
+                return MGCR_OK;
+            }
             KLAUNCH((xr_update_kernel<true, true>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)nullptr,
                     (const cplx *)s->aps[cur], x, rcur, r_out, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
             rcur = r_out;
             dir = r_out;
-            if (flex) {
+            if (flex && !(last && skip_tail)) {
                 MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, dslot, n));
                 dir = dslot;
             }
@@ -1191,10 +1219,10 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             KLAUNCH((xr_update_kernel<false, false>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)s->ps[cur],
                     (const cplx *)s->aps[cur], x, (const cplx *)s->r, s->r, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
         dir = s->r;
-        if (flex) {
+        if (flex && !(last && skip_tail)) {
             MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
             dir = s->z;
-        } else if (p.right_precond) {  // src/GCR.h:236-238
+        } else if (p.right_precond && !flex) {  // src/GCR.h:236-238
             MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n));
             std::swap(s->r, s->tmp);
             dir = s->r;
@@ -1367,6 +1395,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (multi) MGCR_TRY(comm_check(comm));   // a peer-write wait that timed out poisoned the scalars with NaN
     return frc;
 }
+
+void gcr_set_discard_residual(GcrState *s, bool on) { s->discard_residual = on; }
 
 // the residual of the solve that just ran on `s`, selected on the device by the number of steps it took
 bool gcr_last_residual(GcrState *s, ResidualSel *out) {

@@ -208,6 +208,7 @@ int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n);
 // runs the solve; `nested` = no host round trips (used when GCR is itself applied as an operator)
 struct ResidualSel;  // gcr_dev.h
 bool gcr_last_residual(GcrState *s, ResidualSel *out);
+void gcr_set_discard_residual(GcrState *s, bool on);  // nested solves whose caller never looks at the final residual
 int gcr_run_from_zero(GcrState *s, const cplx *rhs, cplx *x);  // nested, x0 = 0, x's content on entry is irrelevant
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter,
             int *converged);

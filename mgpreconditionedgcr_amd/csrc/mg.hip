@@ -180,6 +180,7 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         rc = gcr_state_create(L.A, &sp, 1, &L.pre);
         sp.use_x0 = 1;
         if (rc == MGCR_OK) rc = gcr_state_create(L.A, &sp, 1, &L.post);
+        if (rc == MGCR_OK) gcr_set_discard_residual(L.post, true);   // the cycle only takes x from its post-smoother
         if (rc != MGCR_OK) break;
         hipFree(d_vecs);
         d_vecs = d_next;
@@ -199,6 +200,7 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         mgcr_gcr_param cp = p->coarse;
         cp.verbose = 0; cp.left_precond = cp.right_precond = nullptr; cp.flexible = 0; cp.use_x0 = 0; cp.profile_spmv = 0;
         rc = gcr_state_create(Z.A, &cp, 1, &Z.coarse);
+        if (rc == MGCR_OK) gcr_set_discard_residual(Z.coarse, true);
     }
     if (rc != MGCR_OK) { mg_destroy(m); return rc; }
     *out = m;
