@@ -74,6 +74,9 @@ struct GcrState {
     mgcr_gcr_param p{};
     int x0_mode = 1;
     std::vector<const cplx *> r_after;  // r_after[k]: where step k of the last solve left its residual (empty: not tracked)
+    bool keep_pending = false;      // solves that only ever assign x (assign_x below) leave that to the caller: gcr_take_pending
+    bool has_pending = false;
+    PendingX pending{};
     bool discard_residual = false;  // nested solves whose caller only wants x (post-smoother, coarsest solve): see alpha_only_kernel
     bool x_from_zero = false;  // next gcr_run: x0 = 0 and x's content is garbage (gcr_run_from_zero)
     int64_t n = 0;
@@ -1058,6 +1061,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const int g = red_grid(n);
     const bool flex = p.flexible && p.right_precond;
     const SkipRef outer = get_apply_skip();  // outer solver's predicate: if that solve is over, this one is a no-op too
+    s->has_pending = false;
     const bool from_zero = s->x_from_zero;   // gcr_run_from_zero: x has to be zeroed here, unless the solve only ever ASSIGNS x
     s->x_from_zero = false;
 
@@ -1373,9 +1377,17 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         DirPtrs d0;
         for (int j = 0; j < LND; j++) { int sl = j < s->storage ? j : 0; d0.ps[j] = s->ps[sl]; d0.aps[j] = s->aps[sl]; d0.slot[j] = sl; }
         d0.ps[0] = p0;
+        if (assign_x && s->keep_pending && nested) {
+            // the caller writes x = sum coef_j v_j itself, together with whatever else it has to add (V-cycle: + P x_c)
+            for (int j = 0; j < LND; j++) s->pending.v[j] = d0.ps[j];
+            s->pending.coef = lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas;
+            s->pending.st = s->st;
+            s->has_pending = true;
+        } else {
         KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n, assign_x ? 1 : 0);
         hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);
         MGCR_HIP(hipGetLastError());
+        }
     }
     if (nested) return MGCR_OK;
     if (!prof_events.empty()) {
@@ -1397,6 +1409,22 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 }
 
 void gcr_set_discard_residual(GcrState *s, bool on) { s->discard_residual = on; }
+void gcr_set_keep_pending(GcrState *s, bool on) { s->keep_pending = on; }
+// x = sum coef_j v_j for a caller that took the pending update and then needs x after all
+int gcr_flush_pending(const PendingX &pd, cplx *x, int64_t n) {
+    DirPtrs d0;
+    for (int j = 0; j < LND; j++) { d0.ps[j] = pd.v[j]; d0.aps[j] = pd.v[j]; d0.slot[j] = j; }
+    hipLaunchKernelGGL(flush_x_kernel, dim3(red_grid(n)), dim3(RED_THREADS), 0, ctx().stream, const_cast<DevState *>(pd.st), pd.coef, d0, x, n, 1);
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
+// did the solve that just ran leave x unwritten (see keep_pending)?  Then *out says what x is.
+bool gcr_take_pending(GcrState *s, PendingX *out) {
+    if (!s->has_pending) return false;
+    *out = s->pending;
+    s->has_pending = false;
+    return true;
+}
 
 // the residual of the solve that just ran on `s`, selected on the device by the number of steps it took
 bool gcr_last_residual(GcrState *s, ResidualSel *out) {

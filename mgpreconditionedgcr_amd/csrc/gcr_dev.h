@@ -38,6 +38,14 @@ struct ResidualSel {
     const DevState *st;
 };
 
+// x updates a finished solve left pending on request (gcr_set_keep_pending): x = sum_{j < st->npend} coef[j] * v[j],
+// from x0 = 0.  The V-cycle adds its coarse-grid correction in the same pass (mg.hip expand_add_kernel).
+struct PendingX {
+    const cplx *v[LND];
+    const cplx *coef;
+    const DevState *st;
+};
+
 struct DirPtrs {  // the classic kernels use the first ND entries (one chunk), the lean ones up to LND
     const cplx *ps[LND];
     const cplx *aps[LND];

@@ -208,7 +208,11 @@ int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n);
 // runs the solve; `nested` = no host round trips (used when GCR is itself applied as an operator)
 struct ResidualSel;  // gcr_dev.h
 bool gcr_last_residual(GcrState *s, ResidualSel *out);
-void gcr_set_discard_residual(GcrState *s, bool on);  // nested solves whose caller never looks at the final residual
+void gcr_set_discard_residual(GcrState *s, bool on);
+struct PendingX;  // gcr_dev.h
+void gcr_set_keep_pending(GcrState *s, bool on);
+bool gcr_take_pending(GcrState *s, PendingX *out);
+int gcr_flush_pending(const PendingX &pd, cplx *x, int64_t n);  // nested solves whose caller never looks at the final residual
 int gcr_run_from_zero(GcrState *s, const cplx *rhs, cplx *x);  // nested, x0 = 0, x's content on entry is irrelevant
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter,
             int *converged);

@@ -69,16 +69,25 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
 }
 
 // x[i] = x[i] + damp * sum_k xc[agg[i]*ne+k] * pv[i][k]      (expand, src/MG.h:347-364, + src/MG.h:426)
+// pend.st != nullptr: the x to add to was never written — it is the pre-smoother's pending update
+// sum_j coef[j] v_j[i] from x0 = 0 (gcr.hip flush_x_kernel's sum, same order), formed here on the fly
 __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, const int32_t *__restrict__ agg,
                                                          const cplx *__restrict__ pv, const cplx *__restrict__ xc,
                                                          cplx *__restrict__ x, cplx damp, int add,
-                                                         const int *__restrict__ skip, int skip_it) {
+                                                         const int *__restrict__ skip, int skip_it, PendingX pend) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const cplx *c = xc + (int64_t)agg[i] * ne;
     cplx s = make_double2(0., 0.);
     for (int k = 0; k < ne; k++) s = cadd(s, cmul(c[k], pv[i * ne + k]));
+    if (pend.st) {
+        const int np = pend.st->npend;
+        cplx xv = make_double2(0., 0.);
+        for (int j = 0; j < np && j < LND; j++) xv = cadd(xv, cmul(pend.coef[j], pend.v[j][i]));
+        x[i] = cadd(xv, cmul(damp, s));
+        return;
+    }
     x[i] = add ? cadd(x[i], cmul(damp, s)) : s;
 }
 
@@ -178,6 +187,7 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         sp.verbose = 0; sp.left_precond = sp.right_precond = nullptr; sp.flexible = 0; sp.profile_spmv = 0;
         sp.use_x0 = 0;
         rc = gcr_state_create(L.A, &sp, 1, &L.pre);
+        if (rc == MGCR_OK) gcr_set_keep_pending(L.pre, true);   // mg_cycle writes the pre-smoother's x together with + P x_c
         sp.use_x0 = 1;
         if (rc == MGCR_OK) rc = gcr_state_create(L.A, &sp, 1, &L.post);
         if (rc == MGCR_OK) gcr_set_discard_residual(L.post, true);   // the cycle only takes x from its post-smoother
@@ -232,10 +242,10 @@ int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc, const ResidualSel *s
     return MGCR_OK;
 }
 
-int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping) {
+int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping, const PendingX *pend) {
     MgLevel &L = m->lev[(size_t)l];
     hipLaunchKernelGGL(expand_add_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, L.ne, L.d_agg, L.d_pv, xc, x,
-                       make_double2(damping, 0.), add ? 1 : 0, get_apply_skip().p, get_apply_skip().it);
+                       make_double2(damping, 0.), add ? 1 : 0, get_apply_skip().p, get_apply_skip().it, pend ? *pend : PendingX{});
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -255,6 +265,10 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
         return gcr_run_from_zero(L.coarse, b, x);
     }
     MGCR_TRY(gcr_run_from_zero(L.pre, b, x));
+    // a lean pre-smoother leaves its x unwritten (x = sum of two or three scaled vectors it still holds): the
+    // prolongation kernel below forms it on the fly while adding the coarse-grid correction — x is written once
+    PendingX pend;
+    bool x_pending = gcr_take_pending(L.pre, &pend);
     MgLevel &C = m->lev[(size_t)l + 1];
     // The residual to restrict is the one the pre-smoother's recurrence ended with (r_k = r_{k-1} - alpha A p_{k-1}: b - A x
     // up to rounding) — no further pass over A, x and b.  Solvers with the literal preconditioner hooks, or of more
@@ -263,11 +277,15 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     if (recurrence_residual_enabled() && gcr_last_residual(L.pre, &sel)) {
         MGCR_TRY(mg_restrict(m, l, nullptr, C.b, &sel));
     } else {
+        if (x_pending) {   // b - A x needs x after all
+            MGCR_TRY(gcr_flush_pending(pend, x, L.n));
+            x_pending = false;
+        }
         MGCR_TRY(op_residual_raw(L.A, x, b, L.r, L.n));
         MGCR_TRY(mg_restrict(m, l, L.r, C.b, nullptr));
     }
     MGCR_TRY(mg_cycle(m, l + 1, C.b, C.x));
-    MGCR_TRY(mg_expand(m, l, C.x, x, true, m->damping));
+    MGCR_TRY(mg_expand(m, l, C.x, x, true, m->damping, x_pending ? &pend : nullptr));
     return gcr_run(L.post, b, x, true, nullptr, 0, nullptr, nullptr);
 }
 
@@ -278,7 +296,7 @@ int mg_apply(MgState *m, const cplx *f, cplx *y) { return mg_cycle(m, 0, f, y); 
 using namespace mgcr;
 namespace mgcr {
 int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc, const ResidualSel *sel);
-int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping);
+int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping, const PendingX *pend);
 }  // namespace mgcr
 
 #define LOCK() std::lock_guard<std::recursive_mutex> lk__(ctx().mtx)
@@ -326,7 +344,7 @@ int mgcr_mg_expand(mgcr_op_t mg, int32_t level, mgcr_vec_t coarse, mgcr_vec_t fi
     const MgLevel &L = mg->mg->lev[(size_t)level];
     MGCR_CHECK(fine->n == L.n && coarse->n == L.nagg * L.ne, MGCR_ERR_INVALID, "Lengths of two fields do not match!");
     LOCK();
-    return mg_expand(mg->mg, level, coarse->d, fine->d, false, 1.0);
+    return mg_expand(mg->mg, level, coarse->d, fine->d, false, 1.0, nullptr);
 }
 
 int mgcr_mg_level_op(mgcr_op_t mg, int32_t level, mgcr_op_t *out) {
