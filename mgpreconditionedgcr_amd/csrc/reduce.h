@@ -59,25 +59,72 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;  // valid in lane 0
 }
 
+// NV wave sums at once.  Each scalar is summed over the 64 lanes by the very tree wave_sum builds (pairs (l, l + 32),
+// then (l, l + 16) of those sums, ...: same operands, same order, same bits), but the NV trees share their shuffles:
+// at offset 32 the lower half-wave keeps the first half of the scalars and hands the second half to the upper
+// half-wave (which keeps those and hands over the first half), at offset 16 the halves split again, ... until every
+// lane carries one scalar; the remaining offsets are a plain butterfly.  NV = 16: 17 shuffles of a double instead
+// of 96 (they go through the LDS permute unit, which all 16 waves of a workgroup share: the folds and block
+// reductions of 10-20 scalars were a visible part of every solver kernel in the latency regime).
+// On return lane `l` holds in v[0] the total of scalar wave_multi_owner<NV>(l) (several lanes hold each scalar).
+template <int NV>
+struct WaveMulti {
+    static constexpr int NVP = NV <= 1 ? 1 : NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+    static_assert(NV <= 64, "at most 64 scalars per multi-sum");
+};
+template <int NV>
+__device__ __forceinline__ int wave_multi_sum(double (&v)[NV], double &out) {
+    constexpr int NVP = WaveMulti<NV>::NVP;
+    const int lane = threadIdx.x & 63;
+    double w[NVP];
+#pragma unroll
+    for (int j = 0; j < NVP; j++) w[j] = j < NV ? v[j] : 0.;
+    int base = 0;
+    int c = NVP;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const bool upper = (lane & off) != 0;
+        if (c > 1) {
+            const int h = c / 2;
+#pragma unroll
+            for (int j = 0; j < NVP / 2; j++) {
+                if (j < h) {
+                    const double lo = w[j], hi = w[j + h];
+                    const double keep = upper ? hi : lo;
+                    const double recv = __shfl_xor(upper ? lo : hi, off, 64);
+                    w[j] = upper ? (recv + keep) : (keep + recv);   // always (lower lane's value) + (upper lane's value)
+                }
+            }
+            if (upper) base += h;
+            c = h;
+        } else {
+            const double recv = __shfl_xor(w[0], off, 64);
+            w[0] = upper ? (recv + w[0]) : (w[0] + recv);
+        }
+    }
+    out = w[0];
+    return base;
+}
+
 // Sum NV per-thread doubles over the workgroup in a fixed order (lanes by shuffle tree, waves in
 // index order) and broadcast the totals to every thread.  `lds` needs NV * 17 doubles.
 template <int NV>
 __device__ __forceinline__ void block_sum_bcast(double (&v)[NV], double *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-        double s = wave_sum(v[k]);
-        if (lane == 0) lds[k * 17 + wave] = s;
-    }
+    constexpr int NVP = WaveMulti<NV>::NVP;
+    double s;
+    const int k = wave_multi_sum<NV>(v, s);
+    // scalar k sits in the 64 / NVP lanes whose upper bits spell k: the one with the low bits clear stores it
+    if ((lane & (64 / NVP - 1)) == 0 && k < NV) lds[k * 17 + wave] = s;
     __syncthreads();
     if (threadIdx.x < NV) {
-        double s = 0.;
-        for (int w = 0; w < nwave; w++) s += lds[threadIdx.x * 17 + w];
-        lds[threadIdx.x * 17 + 16] = s;
+        double t = 0.;
+        for (int w = 0; w < nwave; w++) t += lds[threadIdx.x * 17 + w];
+        lds[threadIdx.x * 17 + 16] = t;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = lds[k * 17 + 16];
+    for (int j = 0; j < NV; j++) v[j] = lds[j * 17 + 16];
     __syncthreads();
 }
 
