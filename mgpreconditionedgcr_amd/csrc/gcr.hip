@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(RED_THREADS) norm_partials_kernel(const cplx *
         cplx t = a[i];
         v[0] += t.x * t.x + t.y * t.y;  // Re(conj(a) a), src/Fields.h:228-235
     }
-    block_sum_bcast<1>(v, lds);
-    if (threadIdx.x == 0) parts[blockIdx.x] = v[0];
+    const double tot = block_sum_owner<1>(v, lds);
+    if (threadIdx.x == 0) parts[blockIdx.x] = tot;
 }
 
 // partials of <r,Ap> (conj on r) and <Ap,Ap>  ->  partsA[0..3][blk]
@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(RED_THREADS) dot2_partials_kernel(const cplx *
         cplx u = cconj_mul(a, a);
         v[2] += u.x; v[3] += u.y;
     }
-    block_sum_bcast<4>(v, lds);
-    if (threadIdx.x < 4) parts[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+    const double tot = block_sum_owner<4>(v, lds);
+    if (threadIdx.x < 4) parts[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = tot;
 }
 
 // |r|^2 (written twice: it is |b|^2 as well when r0 = b), <r,Ap> and <Ap,Ap> in one pass; same sums, in the
@@ -186,11 +186,11 @@ __global__ void __launch_bounds__(RED_THREADS) init3_partials_kernel(const cplx 
         cplx u = cconj_mul(a, a);
         v[2] += u.x; v[3] += u.y;
     }
-    block_sum_bcast<5>(v, lds);
-    if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = v[threadIdx.x];
+    const double tot = block_sum_owner<5>(v, lds);
+    if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = tot;
     if (threadIdx.x == 4) {
-        partsR[blockIdx.x] = v[4];
-        if (partsN) partsN[blockIdx.x] = v[4];
+        partsR[blockIdx.x] = tot;
+        if (partsN) partsN[blockIdx.x] = tot;
     }
 }
 
@@ -243,8 +243,8 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
         r_out[i] = rn;  // LEAN: the residual ring (r_out != r_in inside a cycle); else in place
         v[0] += rn.x * rn.x + rn.y * rn.y;
     }
-    block_sum_bcast<1>(v, lds);
-    if (threadIdx.x == 0) partsR[blockIdx.x] = v[0];
+    const double tot = block_sum_owner<1>(v, lds);
+    if (threadIdx.x == 0) partsR[blockIdx.x] = tot;
 }
 
 // applies the x updates still pending when the solve ends (never skipped)
@@ -303,14 +303,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 6 ? 8 : 4)) multidot_kern
             }
         }
     }
-    block_sum_bcast<2 * NDT>(v, lds);
-    if (threadIdx.x < 2 * NDT) {
-        double mine = 0.;
-#pragma unroll
-        for (int j = 0; j < 2 * NDT; j++)
-            if (j == (int)threadIdx.x) mine = v[j];
-        partsB[(size_t)(2 * base + threadIdx.x) * RED_MAX_BLOCKS + blockIdx.x] = mine;
-    }
+    const double mine = block_sum_owner<2 * NDT>(v, lds);
+    if (threadIdx.x < 2 * NDT) partsB[(size_t)(2 * base + threadIdx.x) * RED_MAX_BLOCKS + blockIdx.x] = mine;
 }
 
 // beta_j = <Ar,Aps_j>/<Aps_j,Aps_j>;  p_corr -= ps_j*beta_j;  Ap_corr -= Aps_j*beta_j  (src/GCR.h:257-262)
@@ -410,11 +404,8 @@ __global__ void __launch_bounds__(RED_THREADS) build_kernel(DevState *__restrict
         }
     }
     if (LAST) {
-        block_sum_bcast<4>(v, lds);
-        if (threadIdx.x < 4) {
-            double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
-            partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
-        }
+        const double mine = block_sum_owner<4>(v, lds);
+        if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
     }
 }
 
@@ -530,11 +521,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
         cplx u = cconj_mul(an, an);
         v[2] += u.x; v[3] += u.y;
     }
-    block_sum_bcast<4>(v, lds);
-    if (threadIdx.x < 4) {
-        double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
-        partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
-    }
+    const double mine = block_sum_owner<4>(v, lds);
+    if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
 }
 
 // LEAN, restart > 8: the x / P0 half of the cycle-closing step (the Ap half is build_lean_kernel with
@@ -666,11 +654,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 2 ? 8 : 4)) build_close_k
         cplx u = cconj_mul(an, an);
         v[2] += u.x; v[3] += u.y;
     }
-    block_sum_bcast<4>(v, lds);
-    if (threadIdx.x < 4) {
-        double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
-        partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
-    }
+    const double mine = block_sum_owner<4>(v, lds);
+    if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
 }
 
 // ------------------------------------------------------------------------------------------------

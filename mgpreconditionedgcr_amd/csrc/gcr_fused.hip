@@ -75,14 +75,8 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
         }
         t0 = t0_next;
     }
-    block_sum_bcast<2 * NDT>(v, lds);
-    if (threadIdx.x < 2 * NDT) {
-        double mine = 0.;
-#pragma unroll
-        for (int j = 0; j < 2 * NDT; j++)
-            if (j == (int)threadIdx.x) mine = v[j];
-        parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
-    }
+    const double mine = block_sum_owner<2 * NDT>(v, lds);
+    if (threadIdx.x < 2 * NDT) parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
 }
 
 
@@ -128,15 +122,14 @@ __global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, co
         }
         t0 = t0_next;
     }
-    block_sum_bcast<6>(v, lds);
-    if (threadIdx.x < 4) {
-        double mine = threadIdx.x == 0 ? v[0] : threadIdx.x == 1 ? v[1] : threadIdx.x == 2 ? v[2] : v[3];
-        partsA[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
-    }
+    const double mine = block_sum_owner<6>(v, lds);
+    if (threadIdx.x < 4) partsA[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    // thread 4 owns |r_0|^2, thread 5 |b|^2 (when b is given)
     if (threadIdx.x == 4) {
-        partsR[lb] = v[4];
-        partsN[lb] = b ? v[5] : v[4];
+        partsR[lb] = mine;
+        if (!b) partsN[lb] = mine;
     }
+    if (threadIdx.x == 5 && b) partsN[lb] = mine;
 }
 
 static int g_fuse = -1;

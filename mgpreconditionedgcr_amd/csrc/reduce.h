@@ -128,6 +128,23 @@ __device__ __forceinline__ void block_sum_bcast(double (&v)[NV], double *lds) {
     __syncthreads();
 }
 
+// Same sums (same order, same bits) for a kernel tail that only WRITES them out: thread t < NV returns the total
+// of scalar t, the other threads return 0 — no broadcast back to the workgroup (NV LDS reads per thread and two
+// barriers less).  `lds` must not be reused before another barrier.
+template <int NV>
+__device__ __forceinline__ double block_sum_owner(double (&v)[NV], double *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+    constexpr int NVP = WaveMulti<NV>::NVP;
+    double s;
+    const int k = wave_multi_sum<NV>(v, s);
+    if ((lane & (64 / NVP - 1)) == 0 && k < NV) lds[k * 17 + wave] = s;
+    __syncthreads();
+    double t = 0.;
+    if (threadIdx.x < NV)
+        for (int w = 0; w < nwave; w++) t += lds[threadIdx.x * 17 + w];
+    return t;
+}
+
 // Fold a partial slab parts[k * stride + blk] (nblk valid entries per scalar) to NV totals,
 // identically in every workgroup that calls it (blockDim.x must be >= RED_MAX_BLOCKS).
 // stride = RED_MAX_BLOCKS for a slab written by a producer kernel; stride = 1, nblk = 1 for scalars
