@@ -1094,6 +1094,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
         fuse_ok = b0->kind == OP_CSR && csr_fusable(b0->csr, b0->dist) && b0->csr.nrow == n;
     }
+    bool xr_fuse = false;   // set below once lean / flex / multi are known
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
         MGCR_TRY(op_residual_raw(s->A, x, rhs, s->r, n));
@@ -1119,6 +1120,10 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     // compute stream, and consumers read the global scalars (stride 1, one "partial").
     Comm *comm = s->A->kind == OP_DIRAC ? s->A->base->comm : s->A->comm;
     const bool multi = comm_collectives(comm);
+    if (fuse_ok && lean && !flex && !multi && s->restart > 1) {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        xr_fuse = csr_xr_fusable(b0->csr, b0->dist);
+    }
     MGCR_CHECK(!multi || (!p.left_precond && (!p.right_precond || flex)), MGCR_ERR_UNSUPPORTED,
                "on a distributed operator only flexible right preconditioning is available (set flexible = 1)");
     const DevState *cst = s->st;
@@ -1179,6 +1184,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         MGCR_TRY(ensure_slot(s, nxt));
         // alpha, x, r
         const cplx *dir;
+        bool xr_now = false;
+        const cplx *xr_in = nullptr;
         if (lean) {
             // D_nxt, what direction nxt is started from, lands in the p slot of that direction (nxt >= 1);
             // the step that closes the cycle only needs it for its own build
@@ -1192,6 +1199,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 cur = nxt;
                 return MGCR_OK;
             }
+            xr_now = xr_fuse && !(last && skip_tail);   // latency regime: the update runs inside the apply kernel below
+            xr_in = rcur;
+            if (!xr_now)
             KLAUNCH((xr_update_kernel<true, true>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)nullptr,
                     (const cplx *)s->aps[cur], x, rcur, r_out, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
             rcur = r_out;
@@ -1245,6 +1255,10 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             const cplx *vecs[ND];
             for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < nf ? j : 0];
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+            if (xr_now)
+                MGCR_TRY(csr_step_apply_xr(b0->csr, xr_in, s->aps[cur], const_cast<cplx *>(dir), s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs,
+                                           nf, s->partsB, s->partsR, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc, rmap));
+            else
             MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist, rmap));
             ch0 = 1;
         } else {

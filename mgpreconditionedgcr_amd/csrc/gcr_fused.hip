@@ -80,6 +80,72 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
 }
 
 
+// Latency regime (systems of up to 2^19 rows: every kernel is one wave of workgroups and costs its launch, a fold,
+// one memory round trip and a reduction, ~5 us, whatever it moves): the residual update of the step runs INSIDE the
+// apply kernel.  alpha is folded from the <r,Ap>, <Ap,Ap> partials, r' = r - alpha Ap is formed for the row itself
+// (stored to the residual ring, |r'|^2 summed) and again, with the same expression hence the same bits, for every
+// gathered neighbour; then Ar' and the beta dots as in step_apply_kernel.  One launch less per iteration: worth
+// 1.3 us of ~32 per iteration at 64^3 (the kernel itself gets ~3.7 us longer), 1.7 % of a 256^3 V-cycle.  At 128^3 the
+// doubled gathers lose (65 us against 21.9 + 39.8), hence the size limit.  Lean cycles only (r' never lands on r),
+// single GPU, rows of at most 8 entries.
+template <int MODE, int WT, int NDT>
+__global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m, const cplx *__restrict__ r_in, const cplx *__restrict__ ap,
+                                                                       cplx *__restrict__ r_out, cplx *__restrict__ y, DotVecs d, int64_t n,
+                                                                       int nlogical, RowMap rm, double *__restrict__ parts,
+                                                                       double *__restrict__ partsR, DevState *__restrict__ st, int it,
+                                                                       const double *__restrict__ partsA, int nblkA, int strideA,
+                                                                       cplx *__restrict__ den_slot, int slot, LeanCoef *__restrict__ lc) {
+    __shared__ double lds[(2 * NDT + 1) * 17 > 4 * 17 ? (2 * NDT + 1) * 17 : 4 * 17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
+    if (st->stop_at < st->base + it) return;
+    const int per = (int)(gridDim.x >> 3);
+    const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    // alpha and its bookkeeping: xr_update_kernel<true, true>'s prologue
+    double sa[4];
+    fold_partials<4>(partsA, nblkA, strideA, sa, lds);
+    const cplx num = make_double2(sa[0], sa[1]), den = make_double2(sa[2], sa[3]);
+    const cplx alpha = to_sgpr(cdiv(num, den));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *den_slot = den;
+        st->npend = slot + 1;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < LND) lean_pending_update(lc, slot, alpha, (int)threadIdx.x);
+    if (lb >= nlogical) return;
+    const int32_t W = WT ? WT : m.W;
+    int64_t i, end, stride;
+    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    int32_t t0 = 0;
+    if (MODE != 0 && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    PatLds pl{nullptr, nullptr, nullptr};
+    if (MODE == 1) pl = stage_patterns(m, step_smem);
+    double v[2 * NDT + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * NDT + 1; j++) v[j] = 0.;
+    for (; i < end; i += stride) {
+        int32_t t0_next = 0;
+        if (MODE != 0 && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
+        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return csub(r_in[j], cmul(alpha, ap[j])); });
+        const cplx rn = csub(r_in[i], cmul(alpha, ap[i]));
+        r_out[i] = rn;
+        v[2 * NDT] += rn.x * rn.x + rn.y * rn.y;
+        const cplx yi = m.shift ? csub(rn, cmul(m.k, sum)) : sum;
+        y[i] = yi;
+        cplx b[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) b[j] = ld_stream<true>(d.v[j] + i);
+#pragma unroll
+        for (int j = 0; j < NDT; j++) {
+            cplx t = cconj_mul(yi, b[j]);
+            v[2 * j] += t.x;
+            v[2 * j + 1] += t.y;
+        }
+        t0 = t0_next;
+    }
+    const double mine = block_sum_owner<2 * NDT + 1>(v, lds);
+    if (threadIdx.x < 2 * NDT) parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    if (threadIdx.x == 2 * NDT) partsR[lb] = mine;
+}
+
 // Step 0 of a solve whose first direction is its start residual (lean smoothers, gcr.hip alias_p0): Ap_0 = A r_0
 // AND the partial sums of <r_0,Ap_0>, <Ap_0,Ap_0>, |r_0|^2 — and |b|^2 when b is not r_0 — in ONE pass, instead
 // of the operator apply followed by init3_partials_kernel (+ norm_partials_kernel): r_0 is the row's own x entry
@@ -203,6 +269,61 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
     return MGCR_OK;
 }
 
+
+template <int MODE, int WT>
+static void launch_xr_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *r_in, const cplx *ap, cplx *r_out, cplx *y,
+                         const DotVecs &d, int64_t n, int g, const RowMap &rm, double *parts, double *partsR, DevState *st, int it,
+                         const double *partsA, int nblkA, int strideA, cplx *den_slot, int slot, LeanCoef *lc) {
+#define SX(NDT)                                                                                                                       \
+    hipLaunchKernelGGL((step_apply_xr_kernel<MODE, WT, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r_in, ap, r_out, y, \
+                       d, n, g, rm, parts, partsR, st, it, partsA, nblkA, strideA, den_slot, slot, lc)
+    switch (nd) {
+        case 1: SX(1); break;
+        case 2: SX(2); break;
+        case 3: SX(3); break;
+        case 4: SX(4); break;
+        case 5: SX(5); break;
+        case 6: SX(6); break;
+        case 7: SX(7); break;
+        default: SX(8); break;
+    }
+#undef SX
+}
+
+bool csr_xr_fusable(const CsrDev &A, const DistCsr *dist) {
+    static const int64_t limit = getenv("MGCR_XR_FUSE_ROWS") ? atoll(getenv("MGCR_XR_FUSE_ROWS")) : ((int64_t)1 << 19);
+    // the gathers double, so short rows only: 64^3 7-point, 19 iterations of GCR(10): 0.633 -> 0.608 ms; the 4x4 sample matrix
+    // (39 entries per row) loses 1.6 % and stays with the separate update kernel
+    return !dist && A.nrow <= limit && A.W <= 8 && csr_fusable(A, dist);
+}
+
+// r_out = r_in - alpha ap (alpha from the partsA partials), y = A r_out (or r_out - k A r_out), partials of <y, vecs_j> and of
+// |r_out|^2: xr_update_kernel<true, true> + csr_step_apply in one launch
+int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r_out, cplx *y, bool shift, cplx k, const cplx *const *vecs,
+                      int nd, double *parts, double *partsR, DevState *st, int it, const double *partsA, int nblkA, int strideA,
+                      cplx *den_slot, int slot, LeanCoef *lc, const RowMap &rm) {
+    MGCR_CHECK(r_in != r_out && r_out != y && r_in != y, MGCR_ERR_INVALID, "csr_step_apply_xr: operands must be distinct");
+    MGCR_CHECK(nd >= 1 && nd <= ND, MGCR_ERR_INVALID, "csr_step_apply_xr: 1..8 vectors");
+    RowMat m = row_mat(A, shift, k);
+    DotVecs d;
+    for (int j = 0; j < ND; j++) d.v[j] = vecs[j < nd ? j : 0];
+    const int g = red_grid(A.nrow);
+    const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
+    const size_t lds_bytes = row_mat_lds_bytes(A);
+#define SXW(MODE)                                                                                                                          \
+    do {                                                                                                                                   \
+        if (A.W == 7) launch_xr_nd<MODE, 7>(nd, grid, lds_bytes, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, \
+                                            strideA, den_slot, slot, lc);                                                                  \
+        else launch_xr_nd<MODE, 0>(nd, grid, lds_bytes, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,  \
+                                   den_slot, slot, lc);                                                                                    \
+    } while (0)
+    if (A.pat_mode == 1) SXW(1);
+    else if (A.pat_mode == 2) SXW(2);
+    else SXW(0);
+#undef SXW
+    MGCR_HIP(hipGetLastError());
+    return MGCR_OK;
+}
 
 // aps0 = A r0 (or r0 - k A r0) + the partials of <r0,aps0>, <aps0,aps0> (partsA), |r0|^2 (partsR) and |b|^2 (partsN;
 // b == nullptr: b IS r0); layouts of gcr.hip's init3_partials_kernel; dist as in csr_step_apply

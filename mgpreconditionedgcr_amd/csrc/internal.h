@@ -155,6 +155,12 @@ bool csr_fusable(const CsrDev &A, const DistCsr *dist);
 struct RowMap;  // gcr_dev.h
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
                    DistCsr *dist, const RowMap &rm);
+struct DevState;
+struct LeanCoef;
+bool csr_xr_fusable(const CsrDev &A, const DistCsr *dist);
+int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r_out, cplx *y, bool shift, cplx k, const cplx *const *vecs,
+                      int nd, double *parts, double *partsR, DevState *st, int it, const double *partsA, int nblkA, int strideA,
+                      cplx *den_slot, int slot, LeanCoef *lc, const RowMap &rm);
 int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx k, const cplx *b, double *partsA, double *partsR,
                    double *partsN, DistCsr *dist, const RowMap &rm);
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
