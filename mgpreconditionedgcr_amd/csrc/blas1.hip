@@ -90,12 +90,7 @@ __global__ void __launch_bounds__(64) fold_kernel(const double *__restrict__ pa,
                                                   const double *__restrict__ pb, int nb, double *__restrict__ outb, int nblk) {
     const int k = blockIdx.x, lane = threadIdx.x;
     const double *src = k < na ? pa + (size_t)k * RED_MAX_BLOCKS : pb + (size_t)(k - na) * RED_MAX_BLOCKS;
-    double acc = 0.;
-    for (int w = 0; w < RED_THREADS / 64; w++) {
-        const int t = w * 64 + lane;
-        double s = wave_sum(t < nblk ? src[t] : 0.);
-        if (lane == 0) acc += s;
-    }
+    const double acc = wave_fold_slab(src, nblk);
     if (lane == 0) {
         if (k < na) outa[k] = acc;
         else outb[k - na] = acc;

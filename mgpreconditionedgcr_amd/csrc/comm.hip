@@ -163,12 +163,7 @@ __global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ 
     double acc;
     if (nblk > 0) {  // fold scalar k exactly as fold_kernel does
         const double *src = k < na ? pa + (size_t)k * RED_MAX_BLOCKS : pb + (size_t)(k - na) * RED_MAX_BLOCKS;
-        acc = 0.;
-        for (int w = 0; w < RED_THREADS / 64; w++) {
-            const int t = w * 64 + lane;
-            double s = wave_sum(t < nblk ? src[t] : 0.);
-            if (lane == 0) acc += s;
-        }
+        acc = wave_fold_slab(src, nblk);
     } else {
         acc = out[k];  // already folded: all-reduce in place
     }

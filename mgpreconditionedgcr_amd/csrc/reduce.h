@@ -145,6 +145,27 @@ __device__ __forceinline__ double block_sum_owner(double (&v)[NV], double *lds) 
     return t;
 }
 
+// One wave folds one scalar's slab of per-workgroup partials (multi-GPU fold kernels): the 16 wave-sized pieces are
+// summed by the shuffle tree and added in index order — the tree fold_partials / block_sum_bcast build over a
+// 1024-thread workgroup, so the result has the bits of the in-kernel folds.  The 16 piece sums share their
+// shuffles (wave_multi_sum); piece k ends up in lanes 4k..4k+3.  Returns the total in every lane.
+__device__ __forceinline__ double wave_fold_slab(const double *__restrict__ src, int nblk) {
+    static_assert(RED_THREADS == 1024, "16 wave-sized pieces");
+    const int lane = threadIdx.x & 63;
+    double v[16];
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int t = w * 64 + lane;
+        v[w] = t < nblk ? src[t] : 0.;
+    }
+    double s;
+    wave_multi_sum<16>(v, s);
+    double acc = 0.;
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += __shfl(s, 4 * k, 64);
+    return acc;
+}
+
 // Fold a partial slab parts[k * stride + blk] (nblk valid entries per scalar) to NV totals,
 // identically in every workgroup that calls it (blockDim.x must be >= RED_MAX_BLOCKS).
 // stride = RED_MAX_BLOCKS for a slab written by a producer kernel; stride = 1, nblk = 1 for scalars
