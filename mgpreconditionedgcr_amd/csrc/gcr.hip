@@ -1383,9 +1383,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             s->pending.st = s->st;
             s->has_pending = true;
         } else {
+        // (npend is not cleared afterwards: nothing reads it again before the next solve's reset_kernel zeroes it)
         KLAUNCH(flush_x_kernel, g, s->st, lean ? (const cplx *)s->lc->cx : (const cplx *)s->alphas, d0, x, n, assign_x ? 1 : 0);
-        hipLaunchKernelGGL(clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, s->st);
-        MGCR_HIP(hipGetLastError());
         }
     }
     if (nested) return MGCR_OK;
