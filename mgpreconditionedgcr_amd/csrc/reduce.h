@@ -172,6 +172,13 @@ __device__ __forceinline__ double wave_fold_slab(const double *__restrict__ src,
 // that were already folded and all-reduced over the ranks (multi-GPU).
 template <int NV>
 __device__ __forceinline__ void fold_partials(const double *__restrict__ parts, int nblk, int stride, double (&v)[NV], double *lds) {
+    if (nblk == 1) {
+        // already folded (multi-GPU): the tree would add zeros to the one value — x + 0.0 is x, and turns -0.0 into the
+        // +0.0 the tree yields — so every thread can simply load it: no shuffles, no barriers
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = parts[(size_t)k * stride] + 0.;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = ((int)threadIdx.x < nblk) ? parts[(size_t)k * stride + threadIdx.x] : 0.;
     block_sum_bcast<NV>(v, lds);
