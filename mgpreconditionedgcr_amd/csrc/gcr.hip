@@ -77,6 +77,9 @@ struct GcrState {
     bool keep_pending = false;      // solves that only ever assign x (assign_x below) leave that to the caller: gcr_take_pending
     bool has_pending = false;
     PendingX pending{};
+    bool defer_residual = false;    // nested: the caller forms the last step's residual itself (ResidualSel: r_prev - alpha ap)
+    const cplx *defer_r_prev = nullptr, *defer_ap = nullptr, *defer_alpha = nullptr;
+    int defer_it = 0;
     bool discard_residual = false;  // nested solves whose caller only wants x (post-smoother, coarsest solve): see alpha_only_kernel
     bool x_from_zero = false;  // next gcr_run: x0 = 0 and x's content is garbage (gcr_run_from_zero)
     int64_t n = 0;
@@ -424,7 +427,7 @@ __device__ __forceinline__ void close_step(DevState *st, int it, double rr, doub
 // pending-x bookkeeping of xr_update_kernel<true, true>, without its pass over r and Ap — nobody reads that residual.
 __global__ void __launch_bounds__(RED_THREADS) alpha_only_kernel(DevState *st, int it, const double *__restrict__ partsA, int nblkA,
                                                                  int strideA, cplx *__restrict__ den_slot, int slot,
-                                                                 LeanCoef *__restrict__ lc) {
+                                                                 LeanCoef *__restrict__ lc, cplx *__restrict__ alpha_out) {
     __shared__ double lds[4 * 17];
     if (st->stop_at < st->base + it) return;
     double s[4];
@@ -435,6 +438,7 @@ __global__ void __launch_bounds__(RED_THREADS) alpha_only_kernel(DevState *st, i
         *den_slot = den;
         st->npend = slot + 1;
         st->iter = st->base + it;
+        if (alpha_out) *alpha_out = alpha;
     }
     if ((int)threadIdx.x < LND) lean_pending_update(lc, slot, alpha, (int)threadIdx.x);
 }
@@ -1047,6 +1051,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     const bool flex = p.flexible && p.right_precond;
     const SkipRef outer = get_apply_skip();  // outer solver's predicate: if that solve is over, this one is a no-op too
     s->has_pending = false;
+    s->defer_it = 0;
     const bool from_zero = s->x_from_zero;   // gcr_run_from_zero: x has to be zeroed here, unless the solve only ever ASSIGNS x
     s->x_from_zero = false;
 
@@ -1191,8 +1196,18 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             // the step that closes the cycle only needs it for its own build
             cplx *dslot = nxt >= 1 ? s->ps[nxt] : (flex ? s->z : s->r);
             cplx *r_out = flex ? s->r : dslot;
+            if (last && skip_tail && nested && s->defer_residual && !multi && !flex && !s->r_after.empty()) {
+                // the caller forms this step's residual itself, from the previous one, Ap and alpha (ResidualSel)
+                KLAUNCH(alpha_only_kernel, 1, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc, s->alphas + cur);
+                s->defer_r_prev = rcur; s->defer_ap = s->aps[cur]; s->defer_alpha = s->alphas + cur; s->defer_it = global;
+                s->r_after[(size_t)global] = rcur;   // placeholder: never read (st->iter == defer_it takes the on-the-fly path)
+                for (int k = 0; k < 3; k++) MGCR_TRY(mark());
+                iter_count = ic_next;
+                cur = nxt;
+                return MGCR_OK;
+            }
             if (last && skip_tail && nested && s->discard_residual && !multi) {
-                KLAUNCH(alpha_only_kernel, 1, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc);
+                KLAUNCH(alpha_only_kernel, 1, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc, (cplx *)nullptr);
                 s->r_after.clear();
                 for (int k = 0; k < 3; k++) MGCR_TRY(mark());
                 iter_count = ic_next;
@@ -1432,8 +1447,13 @@ bool gcr_last_residual(GcrState *s, ResidualSel *out) {
     for (int k = 0; k <= LND; k++) out->r[k] = s->r_after[(size_t)k < s->r_after.size() ? (size_t)k : s->r_after.size() - 1];
     out->r[0] = s->r_after[1];
     out->st = s->st;
+    out->r_prev = s->defer_it ? s->defer_r_prev : nullptr;
+    out->ap = s->defer_ap;
+    out->alpha = s->defer_alpha;
+    out->last_it = s->defer_it;
     return true;
 }
+void gcr_set_defer_residual(GcrState *s, bool on) { s->defer_residual = on; }
 
 // nested solve from x0 = 0 into an x whose content does not matter (smoothers, coarsest solve, GCR as a preconditioner)
 int gcr_run_from_zero(GcrState *s, const cplx *rhs, cplx *x) {

@@ -33,9 +33,13 @@ struct DevState {
 // Where a finished solve left its recurrence residual, by the number of steps it actually ran (a solve that
 // converged early skipped the later steps' kernels): r[k] = residual after step k, k = 1..LND.  Consumers read
 // r[st->iter] (mg.hip: the residual a V-cycle restricts after its pre-smoother, without recomputing b - A x).
+// A solve asked to (gcr_set_defer_residual) does not even form the residual of its LAST possible step: if st->iter ==
+// last_it the consumer computes it on the fly as r_prev - alpha * ap (alpha left on the device by alpha_only_kernel).
 struct ResidualSel {
     const cplx *r[LND + 1];
     const DevState *st;
+    const cplx *r_prev, *ap, *alpha;
+    int last_it;   // 0: no deferred step
 };
 
 // x updates a finished solve left pending on request (gcr_set_keep_pending): x = sum_{j < st->npend} coef[j] * v[j],

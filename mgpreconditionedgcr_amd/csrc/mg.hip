@@ -40,9 +40,16 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
+    const cplx *ap = nullptr;
+    cplx alpha = make_double2(0., 0.);
     if (sel.st) {   // x = the residual the smoother that just ran ended with: its slot depends on how many steps it took
         int k = sel.st->iter;
         x = sel.r[k < 0 ? 0 : k > LND ? LND : k];
+        if (sel.last_it && k == sel.last_it) {   // ... and its last step's residual is formed here: r_prev - alpha Ap
+            x = sel.r_prev;
+            ap = sel.ap;
+            alpha = *sel.alpha;
+        }
     }
     int64_t a = c / ne;
     int k = (int)(c - a * ne);
@@ -60,6 +67,7 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
             const int64_t i = idx[u] >= 0 ? idx[u] : 0;
             pvv[u] = pv[i * ne + k];
             xv[u] = x[i];
+            if (ap) xv[u] = csub(xv[u], cmul(alpha, ap[i]));   // same expression as xr_update_kernel: the same bits
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
@@ -95,6 +103,11 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
 // ------------------------------------------------------------------------------------------------
 // hierarchy
 // ------------------------------------------------------------------------------------------------
+static bool recurrence_residual_enabled() {
+    static const bool on = !(getenv("MGCR_MG_RECURRENCE_RESIDUAL") && atoi(getenv("MGCR_MG_RECURRENCE_RESIDUAL")) == 0);
+    return on;
+}
+
 struct MgLevel {
     int64_t n = 0, nagg = 0;
     int ne = 0;
@@ -188,6 +201,7 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         sp.use_x0 = 0;
         rc = gcr_state_create(L.A, &sp, 1, &L.pre);
         if (rc == MGCR_OK) gcr_set_keep_pending(L.pre, true);   // mg_cycle writes the pre-smoother's x together with + P x_c
+        if (rc == MGCR_OK && recurrence_residual_enabled()) gcr_set_defer_residual(L.pre, true);   // restrict_kernel forms the last sweep's residual
         sp.use_x0 = 1;
         if (rc == MGCR_OK) rc = gcr_state_create(L.A, &sp, 1, &L.post);
         if (rc == MGCR_OK) gcr_set_discard_residual(L.post, true);   // the cycle only takes x from its post-smoother
@@ -253,11 +267,6 @@ int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double dampi
 // Corrected cycle (report Algorithm 2; the structure of src/MG.h:405-430 with its defects fixed,
 // see DESIGN.md):  x = S(b) from x0 = 0;  r = b - A x;  b_c = R r;  x_c = cycle(l+1) | coarsest GCR
 // from x0 = 0;  x += damping * P x_c;  x = S(b, x0 = x).
-static bool recurrence_residual_enabled() {
-    static const bool on = !(getenv("MGCR_MG_RECURRENCE_RESIDUAL") && atoi(getenv("MGCR_MG_RECURRENCE_RESIDUAL")) == 0);
-    return on;
-}
-
 static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     MgLevel &L = m->lev[(size_t)l];
     const int nlev = (int)m->lev.size();
