@@ -1264,18 +1264,19 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         const int nchunk = (lim + ND - 1) / ND;
         int ch0 = 0;
         if (fuse_ok) {
-            // Ar = A dir and the <Ar, Aps_j> partials of the first ND stored directions in one pass (gcr_fused.hip);
-            // directions beyond that (restart > 8) go through multidot_kernel below
-            const int nf = lim < ND ? lim : ND;
-            const cplx *vecs[ND];
-            for (int j = 0; j < ND; j++) vecs[j] = s->aps[j < nf ? j : 0];
+            // Ar = A dir and the <Ar, Aps_j> partials of the first FND = 10 stored directions in one pass (gcr_fused.hip);
+            // with more than that (restart > 10) multidot_kernel takes directions 8.. in its chunks of ND = 8 (8 and 9 twice:
+            // the same sums, the same bits)
+            const int nf = lim < FND ? lim : FND;
+            const cplx *vecs[FND];
+            for (int j = 0; j < FND; j++) vecs[j] = s->aps[j < nf ? j : 0];
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
             if (xr_now)
                 MGCR_TRY(csr_step_apply_xr(b0->csr, xr_in, s->aps[cur], const_cast<cplx *>(dir), s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs,
                                            nf, s->partsB, s->partsR, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc, rmap));
             else
             MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist, rmap));
-            ch0 = 1;
+            ch0 = lim <= FND ? nchunk : 1;
         } else {
             MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
             if (p.left_precond) {                         // src/GCR.h:245-247

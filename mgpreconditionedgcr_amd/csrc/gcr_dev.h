@@ -7,6 +7,7 @@
 namespace mgcr {
 
 constexpr int ND = 8;    // directions per multidot / classic build launch
+constexpr int FND = 10;   // directions whose dot products the fused apply kernels take (restart 10 — the reference's usual setting — needs no second pass)
 constexpr int LND = 16;  // slots a lean restart cycle can have (restart <= 16)
 #ifndef MGCR_NT_SLOTS
 #define MGCR_NT_SLOTS 1

@@ -29,7 +29,7 @@
 namespace mgcr {
 
 struct DotVecs {
-    const cplx *v[ND];
+    const cplx *v[FND];
 };
 
 template <int MODE, int WT, int NDT>
@@ -230,17 +230,19 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
         case 5: SK(5); break;
         case 6: SK(6); break;
         case 7: SK(7); break;
-        default: SK(8); break;
+        case 8: SK(8); break;
+        case 9: SK(9); break;
+        default: SK(10); break;
     }
 #undef SK
 }
 
-// y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= ND, laid out like gcr.hip's partsB;
+// y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= FND, laid out like gcr.hip's partsB;
 // dist: A is this rank's row block, the halo exchange of x is enqueued first
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
                    DistCsr *dist, const RowMap &rm) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
-    MGCR_CHECK(nd >= 1 && nd <= ND, MGCR_ERR_INVALID, "csr_step_apply: 1..8 vectors");
+    MGCR_CHECK(nd >= 1 && nd <= FND, MGCR_ERR_INVALID, "csr_step_apply: 1..10 vectors");
     RowMat m = row_mat(A, shift, k);
     if (dist) {
         int64_t ib = 0, ie = 0;
@@ -251,7 +253,7 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         m.xh = dist_halo_ptr(dist);
     }
     DotVecs d;
-    for (int j = 0; j < ND; j++) d.v[j] = vecs[j < nd ? j : 0];
+    for (int j = 0; j < FND; j++) d.v[j] = vecs[j < nd ? j : 0];
     const int g = red_grid(A.nrow);
     const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);  // multiple of 8 => XCD bands
     const size_t lds_bytes = row_mat_lds_bytes(A);
@@ -285,7 +287,9 @@ static void launch_xr_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &
         case 5: SX(5); break;
         case 6: SX(6); break;
         case 7: SX(7); break;
-        default: SX(8); break;
+        case 8: SX(8); break;
+        case 9: SX(9); break;
+        default: SX(10); break;
     }
 #undef SX
 }
@@ -303,10 +307,10 @@ int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r
                       int nd, double *parts, double *partsR, DevState *st, int it, const double *partsA, int nblkA, int strideA,
                       cplx *den_slot, int slot, LeanCoef *lc, const RowMap &rm) {
     MGCR_CHECK(r_in != r_out && r_out != y && r_in != y, MGCR_ERR_INVALID, "csr_step_apply_xr: operands must be distinct");
-    MGCR_CHECK(nd >= 1 && nd <= ND, MGCR_ERR_INVALID, "csr_step_apply_xr: 1..8 vectors");
+    MGCR_CHECK(nd >= 1 && nd <= FND, MGCR_ERR_INVALID, "csr_step_apply_xr: 1..10 vectors");
     RowMat m = row_mat(A, shift, k);
     DotVecs d;
-    for (int j = 0; j < ND; j++) d.v[j] = vecs[j < nd ? j : 0];
+    for (int j = 0; j < FND; j++) d.v[j] = vecs[j < nd ? j : 0];
     const int g = red_grid(A.nrow);
     const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
     const size_t lds_bytes = row_mat_lds_bytes(A);
