@@ -4,23 +4,36 @@ on the 3-D 7-point Poisson system of BASELINE.json configs[1] (128^3, unprecondi
 restart 5, complex fp64, x0 = 0, deterministic RHS), one process per GPU.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...                      (WORLD_SIZE unset: starts its N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one GCR iteration (1 SpMV + the fused orthogonalisation kernels).  The timed region
-is one mgcr_gcr_solve call limited to exactly K iterations (tol = 0 so it cannot stop early),
-inputs resident in HBM, bracketed by barrier + device synchronisation; the max over ranks is
-reported.  N > 1: the grid grows along i to (128 N) x 128 x 128 and is slab-partitioned, 128
-planes (= the N=1 problem) per GPU — weak scaling; value = N * iterations/s (shard-iterations/s).
+A "step" is one GCR iteration (1 SpMV + the fused orthogonalisation kernels).  The timed region is
+one mgcr_gcr_solve call limited to exactly K iterations (tol = 0 so it cannot stop early), inputs
+resident in HBM, bracketed by barrier + device synchronisation, max over ranks; it is repeated until
+>= 0.25 s have been timed and the MEDIAN is reported (`timing` holds repetitions, min and max).
+N > 1: the grid grows along i to (128 N) x 128 x 128 and is slab-partitioned, 128 planes (= the N=1
+problem) per GPU — weak scaling; value = N * iterations/s (shard-iterations/s).
 
-One JSON line on stdout (rank 0), with `roofline` (the phase of the iteration that takes longest,
-hipEvent-timed on the library's own stream inside a solve) and `cpu_baseline` (the real reference, oracle/_ref/ref_harness, on this box's host
-cores; falls back to the oracle port when that binary is absent) plus `cpu_baseline_optimised` (an OpenMP,
-fused-pass CPU port on all host cores).
+One JSON line on stdout (rank 0) with `roofline` (the phase of the iteration that takes longest,
+hipEvent-timed on the library's own stream inside a solve), `cpu_baseline` (the real reference,
+oracle/_ref/ref_harness, on this box's host cores; the oracle port when that binary is absent — `kind` and
+`binary` say which), `cpu_baseline_optimised` (OpenMP fused-pass CPU port) and, at N = 1,
+`workloads`: the other BASELINE.json configs, each measured by a child process of this script
+(`python bench.py --workload NAME` runs one alone).
+
+Process structure.  N = 1: the headline runs in this process, every other workload in a child process
+(bounded time; a failure is recorded, never fatal).  N > 1: each rank is a SUPERVISOR that never touches
+the GPU; it starts the measuring WORKER as a child process and, should the worker fail or hang on any
+rank, all supervisors agree (gloo) to try again with a more conservative transport: peer-write kernels
+-> plain RCCL -> host-staged.  `launch` in the JSON says what ran.  With WORLD_SIZE unset the N
+supervisors are started by this script (the launcher), which exits non-zero if any of them does.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -29,47 +42,191 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "bcsr", "sample"]
+MG_PARITY_NOTE = ("unpinned: the reference's MG::operator() returns uninitialised memory (src/MG.h:124-129,405-430), so no reference "
+                  "output exists; the cycle is checked against the oracle's corrected cycle (tests/test_gpu_mg.py)")
+# transports a multi-GPU run falls back through (environment of the worker processes)
+LADDER = [("default: peer-write kernels where their self-test passes, RCCL otherwise", {}),
+          ("RCCL only", {"MGCR_PEER_ALLREDUCE": "0", "MGCR_PEER_HALO": "0"}),
+          ("host-staged transport (slow; a flagged line instead of none)", {"MGCR_BENCH_TRANSPORT": "host"})]
+ATTEMPT_TIMEOUT_S = [420, 240, 240]
 
 
+# ------------------------------------------------------------------------------------------------
+# launching
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_plan(n_gpus, argv, port, base_env=None):
+    """Commands and environments of the N rank processes `python bench.py --gpus N` starts when it was not
+    launched by torch.distributed.run (pure function: tests/test_bench_launcher.py checks it on CPU)."""
+    base = dict(os.environ if base_env is None else base_env)
+    plan = []
+    for r in range(n_gpus):
+        env = dict(base)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (hipIpc mailboxes, RCCL)
+        env.pop("MGCR_BENCH_ROLE", None)
+        plan.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return plan
+
+
+def run_launcher(args, argv):
+    """WORLD_SIZE unset and --gpus N > 1: start the N ranks (before anything here has touched the GPU), pass rank
+    0's line through, exit non-zero if any rank failed."""
+    procs = []
+    for r, (cmd, env) in enumerate(launcher_plan(args.gpus, argv, free_port())):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + sum(ATTEMPT_TIMEOUT_S) + 300
+    pending = list(procs)
+    while pending and time.time() < deadline:
+        for p in list(pending):
+            if p.poll() is not None:
+                pending.remove(p)
+                rc = rc or p.returncode
+        time.sleep(0.2)
+    for p in pending:   # the exact processes started above
+        p.kill()
+        rc = rc or 1
+    return 1 if rc else 0
+
+
+def worker_command(argv, port, mode_env, base_env=None):
+    env = dict(os.environ if base_env is None else base_env)
+    env.update(mode_env)
+    env.update(MGCR_BENCH_ROLE="worker", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    return [sys.executable, os.path.abspath(__file__)] + list(argv), env
+
+
+def last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def run_supervisor(args, argv):
+    """One per rank, N > 1.  Never touches the GPU: starts the worker as a child and walks the transport ladder with
+    the other supervisors until a run succeeds on every rank."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout to the one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    attempts, result, ok = [], None, False
+    for (label, mode_env), limit in zip(LADDER, ATTEMPT_TIMEOUT_S):
+        port = torch.tensor([free_port() if rank == 0 else 0], dtype=torch.int64)
+        dist.broadcast(port, src=0)
+        cmd, env = worker_command(argv, int(port[0]), mode_env)
+        t0 = time.time()
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = p.communicate(timeout=limit)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            rc = -9
+        parsed = last_json_line(out) if rank == 0 else None
+        good = rc == 0 and (rank != 0 or parsed is not None)
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        bad = torch.tensor([0 if good else 1], dtype=torch.int32)
+        dist.all_reduce(bad)
+        attempts.append({"transport": label, "ok": bool(int(flag[0])), "ranks_failed": int(bad[0]), "seconds": round(time.time() - t0, 1),
+                         "rank0_rc": rc, "rank0_stderr_tail": "" if good else err[-600:]})
+        if not good:
+            sys.stderr.write("[bench rank %d] attempt '%s' failed (rc %s)\n%s\n" % (rank, label, rc, err[-2000:]))
+        if int(flag[0]):
+            ok, result = True, parsed
+            break
+    if rank == 0:
+        if ok:
+            result["launch"] = {"ranks": world, "started_by": os.environ.get("MGCR_BENCH_STARTED_BY", "torch.distributed.run or bench.py launcher"),
+                                "attempts": attempts}
+            print(json.dumps(result), flush=True)
+        else:
+            sys.stderr.write("bench.py: no transport produced a result: %s\n" % json.dumps(attempts))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers shared by the workloads
+# ------------------------------------------------------------------------------------------------
 def spmv_algorithmic_bytes(nnz, nrow, ncol):
     """complex-fp64 values + int32 columns + int32 row pointers + x read once
     + y written once."""
     return nnz * 20 + (nrow + 1) * 4 + ncol * 16 + nrow * 16
 
 
-def cpu_baseline(n, iters=10):
-    """Time the reference CPU path on this box's host cores (bounded sample: `iters` GCR
-    iterations of the same system, 1 thread — the reference's Sparse/Field path is single
-    threaded, src/Operator.h:330-346, src/Fields.h:192-308)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    ncores = os.cpu_count() or 1
-    if os.path.exists(exe):
-        out = subprocess.run([exe, "/tmp", "bench", str(n), str(iters)], capture_output=True, text=True, timeout=900)
-        for line in out.stdout.splitlines():
-            if line.startswith("{"):
-                d = json.loads(line)
-                return {"value": d["it_per_s"], "unit": "it/s", "cores": 1, "kind": "reference",
-                        "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by the real reference "
-                                  "(oracle/_ref/ref_harness, g++ -O3), 1 thread of %d host cores" % (iters, n, ncores),
-                        "spmv_seconds": d["spmv_seconds"], "host_cores": ncores}
-    # fallback: the oracle port (same operation order, fewer temporaries => faster than the reference)
-    import numpy as np  # noqa: F401
-    from oracle import oracle as orc
-    N, rowptr, col, val = orc.poisson3d(n)
-    A = orc.csr(N, N, rowptr, col, val)
-    b = orc.fill_rhs(N, 0)
-    t0 = time.perf_counter()
-    orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=iters, tol=0.0), b)
-    dt = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "it/s", "cores": 1, "kind": "port",
-            "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by oracle/mgcr_oracle.c, 1 thread"
-                      % (iters, n), "host_cores": ncores}
+def source_sha16():
+    """Fingerprint of the kernel sources: a committed PMC traffic figure is only printed next to live timings when it
+    was measured on exactly these sources (tools/pmc_traffic.py stamps it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mgpreconditionedgcr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline_optimised(n, restart, seconds=8.0):
-    """SURVEY.md §8(d) "optimised CPU" row: the OpenMP port with fused passes (oracle/mgcr_cpu_opt.c) on all
-    of this box's host cores, bounded to about `seconds` of work."""
-    from oracle import oracle as orc
+def pmc_traffic(key, n):
+    """(HBM bytes per launch of phase `key` measured by PMC, note) — null unless measured on the current sources."""
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(prof))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if d.get("n") != n:
+        return None, "profiles/pmc_traffic.json was measured at n = %s" % d.get("n")
+    if d.get("src_sha16") != source_sha16():
+        return None, ("profiles/pmc_traffic.json was measured on other kernel sources (%s, now %s): not printed next to live timings"
+                      % (d.get("src_sha16"), source_sha16()))
+    return d["phase_hbm_bytes_per_launch"].get(key), "PMC FETCH_SIZE / WRITE_SIZE passes of these sources (tools/pmc_traffic.py)"
+
+
+def stats(samples):
+    s = sorted(samples)
+    m = len(s)
+    med = s[m // 2] if m % 2 else 0.5 * (s[m // 2 - 1] + s[m // 2])
+    return {"median": med, "min": s[0], "max": s[-1], "repetitions": m}
+
+
+def repeat_timed(fn, min_total=0.25, min_reps=5, max_reps=400):
+    """fn() -> seconds of one timed region; repeated until min_total seconds have been timed."""
+    out, tot = [], 0.0
+    while len(out) < min_reps or (tot < min_total and len(out) < max_reps):
+        dt = fn()
+        out.append(dt)
+        tot += dt
+    return out
+
+
+def usable_cores():
     ncores = os.cpu_count() or 1
     try:
         usable = len(os.sched_getaffinity(0))
@@ -89,73 +246,145 @@ def cpu_baseline_optimised(n, restart, seconds=8.0):
                 usable = max(1, min(usable, int(q / per + 0.5)))
         except Exception:
             pass
+    return usable, ncores
+
+
+def cpu_baseline(n, iters=10):
+    """Time the reference CPU path on this box's host cores (bounded sample: `iters` GCR
+    iterations of the same system, 1 thread — the reference's Sparse/Field path is single
+    threaded, src/Operator.h:330-346, src/Fields.h:192-308)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    ncores = os.cpu_count() or 1
+    if os.path.exists(exe):
+        out = subprocess.run([exe, "/tmp", "bench", str(n), str(iters)], capture_output=True, text=True, timeout=900)
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                d = json.loads(line)
+                return {"value": d["it_per_s"], "unit": "it/s", "cores": 1, "kind": "reference", "binary": "oracle/_ref/ref_harness",
+                        "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by the real reference "
+                                  "(oracle/_ref/ref_harness: the reference's own headers compiled by oracle/Makefile, g++ -O3), 1 thread of %d "
+                                  "host cores" % (iters, n, ncores),
+                        "spmv_seconds": d["spmv_seconds"], "host_cores": ncores}
+    # oracle/_ref is git-ignored (built by __graft_entry__.build() where /root/reference exists): without it the oracle
+    # port is timed instead (same operation order, fewer temporaries => faster than the reference) and says so
+    from oracle import oracle as orc
+    N, rowptr, col, val = orc.poisson3d(n)
+    A = orc.csr(N, N, rowptr, col, val)
+    b = orc.fill_rhs(N, 0)
+    t0 = time.perf_counter()
+    orc.gcr_solve(A, orc.gcr_param(restart=5, max_iter=iters, tol=0.0), b)
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "it/s", "cores": 1, "kind": "port", "binary": "oracle/libmgcr_oracle.so (oracle/_ref/ref_harness absent)",
+            "sample": "%d GCR iterations (restart 5) of the same Poisson %d^3 system by oracle/mgcr_oracle.c, 1 thread"
+                      % (iters, n), "host_cores": ncores}
+
+
+def cpu_baseline_optimised(n, restart, seconds=8.0):
+    """SURVEY.md §8(d) "optimised CPU" row: the OpenMP port with fused passes (oracle/mgcr_cpu_opt.c) on all
+    of this box's host cores, bounded to about `seconds` of work."""
+    from oracle import oracle as orc
+    usable, ncores = usable_cores()
     dt, _ = orc.opt_gcr_poisson(n, restart, 5, usable)          # page-in + a first rate estimate
     iters = int(max(10, min(500, seconds / max(dt / 5, 1e-6))))
     dt, hist = orc.opt_gcr_poisson(n, restart, iters, usable)
-    return {"value": iters / dt, "unit": "it/s", "cores": usable, "kind": "port",
+    return {"value": iters / dt, "unit": "it/s", "cores": usable, "kind": "port", "binary": "oracle/libmgcr_oracle.so",
             "sample": "%d GCR iterations (restart %d) of the same Poisson %d^3 system by oracle/mgcr_cpu_opt.c: OpenMP over "
                       "%d threads (= the CPU share this process is granted), CSR with int32 columns and real values, update / "
                       "SpMV+dots / build fused as on the GPU" % (iters, restart, n, usable),
             "final_rel_residual": float(hist[-1]), "host_cores": ncores}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--grid", dest="n", type=int, default=128, help="Poisson grid edge per GPU shard (128 = BASELINE configs[1])")
-    ap.add_argument("--restart", type=int, default=5)
-    ap.add_argument("--spmv-reps", type=int, default=50)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def storage_name(fmt, npat):
+    return {0: "ELL slab",
+            1: "row-pattern dictionary, %s patterns (2 B per row + table)" % npat,
+            2: "row-pattern dictionary for the columns (%s patterns) + value slab" % npat,
+            3: "stencil view: %s slots, one value per slot, one 64-bit presence word per wave of 64 rows and slot" % npat}[fmt]
 
+
+def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
+    """Bytes each phase of the timed iterations has to move per launch with the layout actually stored ("if
+    the implementation stores something else ... it must report with its stored sizes"):
+      xr      r, Ap read + r written                                              3 V
+      apply   matrix + r read + Ar written + lim Aps_j read (+ Ar re-read by the separate multidot kernel when the
+              fused kernel is not used)
+      build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
+    exact for the iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored directions."""
+    lims = [((k - 1) % R) + 1 for k in range(1, max(n_it, 1) + 1)]
+    b_apply = [matrix_bytes + 16 * ncol + 16 * N + l * V + (0 if fused else V) + (V if l > 8 else 0) for l in lims]
+    b_build = [(2 * R + 6) * V if l == R else (3 + l) * V for l in lims]
+    return [3.0 * V, sum(b_apply) / len(lims), sum(b_build) / len(lims)], sum(lims) / float(len(lims))
+
+
+def cold_apply_ms(mg, A, xin, yout, reps, Field):
+    """The stand-alone operator apply with COLD caches: between two applies a 512 MiB copy sweeps L2 and the 256 MiB
+    Infinity Cache; the apply alone sits between the library's stream events."""
+    import ctypes
+    nf = 16 * 1024 * 1024                      # 2 x 256 MiB of complex fp64
+    fa, fb = Field((nf,)).set_zero(), Field((nf,))
+    t_c = ctypes.c_double()
+    ts = []
+    for _ in range(reps):
+        fb.assign(fa)
+        mg.lib().mgcr_timer_start()
+        A(xin, out=yout)
+        mg.lib().mgcr_timer_stop(ctypes.byref(t_c))
+        ts.append(t_c.value)
+    # the same sweep + events around a plain copy of one vector: what "cold" costs a kernel that does nothing else
+    cp = []
+    for _ in range(reps):
+        fb.assign(fa)
+        mg.lib().mgcr_timer_start()
+        yout.assign(xin)
+        mg.lib().mgcr_timer_stop(ctypes.byref(t_c))
+        cp.append(t_c.value)
+    del fa, fb
+    return stats(ts), stats(cp)
+
+
+# ------------------------------------------------------------------------------------------------
+# the headline workload (also the N > 1 worker)
+# ------------------------------------------------------------------------------------------------
+def run_headline(args, with_cpu=True):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, world, args.gpus))
-
-    import numpy as np
+    import ctypes
     import torch
     import mgpreconditionedgcr_amd as mg
     from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, Sparse, problems
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    # bring-up switch: MGCR_BENCH_TRANSPORT=host runs the N > 1 code path with every rank on GPU 0 and
-    # the host-staged (gloo) transport, so that it can be rehearsed on a one-GPU box; numbers
-    # obtained that way are not benchmark results
-    host_transport = os.environ.get("MGCR_BENCH_TRANSPORT", "rccl") == "host"
-    if host_transport:
+    # bring-up switches: MGCR_BENCH_ONE_GPU=1 puts every rank on GPU 0 so that the N > 1 code path can be rehearsed on a
+    # one-GPU box (RCCL refuses two ranks on one device: the run then uses the host-staged transport); numbers obtained
+    # that way are not benchmark results.  MGCR_BENCH_TRANSPORT=host: host-staged (gloo) transport on purpose.
+    one_gpu = os.environ.get("MGCR_BENCH_ONE_GPU", "0") == "1"
+    host_transport = os.environ.get("MGCR_BENCH_TRANSPORT", "rccl") == "host" or (one_gpu and world > 1)
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     mg.init(local_rank)
     dist = None
     n = args.n
+    comm = None
+    rccl_note = None
     if world > 1:
         # control plane (barriers, id broadcast, max-reduce of the timing) over gloo; the data path
-        # (halo exchange + dot-product all-reduces) is RCCL inside libmgcr_hip.so
+        # (halo exchange + dot-product all-reduces) is inside libmgcr_hip.so
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from mgpreconditionedgcr_amd import Comm, DistSparse
-        rccl_note = None
         if host_transport:
             comm = Comm.host(dist)
         else:
-            # RCCL communicator; should its creation fail on any rank, every rank falls back to the host-staged
-            # transport so that the run still yields a (flagged) line instead of nothing
             try:
                 comm, err = Comm.rccl(dist), None
             except Exception as e:  # noqa: BLE001
                 comm, err = None, repr(e)
             bad = torch.tensor([0 if err is None else 1], dtype=torch.int32)
             dist.all_reduce(bad)
-            if int(bad[0]):
-                rccl_note = "RCCL communicator creation failed on %d rank(s) (%s): host-staged transport" % (int(bad[0]), err)
-                comm = Comm.host(dist)
+            if int(bad[0]):   # every rank leaves: the supervisors move on to the next transport
+                raise SystemExit("RCCL communicator creation failed on %d rank(s): %s" % (int(bad[0]), err))
         # weak scaling: the grid grows along i, every GPU owns n planes (= the N=1 problem)
         N, ncol, rowptr, col, val = problems.poisson3d_csr(n, rank * n, (rank + 1) * n, ni=world * n)
         nnz = int(rowptr[-1])
@@ -189,25 +418,33 @@ def main():
         gcr.solve(rhs, x)
         mg.lib().mgcr_synchronize()
         torch.cuda.synchronize()
-        barrier()
         dt = time.perf_counter() - t0
+        barrier()
         if dist is not None:  # max over ranks
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
         assert gcr.last_iterations == iters, (gcr.last_iterations, iters)
-        return dt, gcr
+        return dt
 
     run(max(args.warmup, 1))  # at least one untimed solve: it allocates the solver's work vectors
-    dt, gcr = run(args.steps)
+    # the number of repetitions must be the same on every rank: rank 0 decides after the first timed solve
+    first = run(args.steps)
+    reps = int(min(400, max(5, 0.25 / max(first, 1e-6))))
+    if dist is not None:
+        t = torch.tensor([reps], dtype=torch.int64)
+        dist.broadcast(t, src=0)
+        reps = int(t[0])
+    samples = [first] + [run(args.steps) for _ in range(reps - 1)]
+    st = stats(samples)
+    dt = st["median"]
     hist = gcr.last_history
     ms_per_step = dt * 1e3 / args.steps
     it_per_s = args.steps / dt
 
-    # Per-phase timing IN SITU: a third solve of the same length with hipEvents (library stream) between
+    # Per-phase timing IN SITU: one more solve of the same length with hipEvents (library stream) between
     # the phases of every iteration — back-to-back replays of one kernel would be served from the
     # 256 MiB Infinity Cache once its operands fit, which at this size they do.
-    import ctypes
     run(args.steps, profile=True)
     ph_ms = (ctypes.c_double * 3)()
     n_it, fused = ctypes.c_int32(), ctypes.c_int32()
@@ -215,58 +452,26 @@ def main():
     ph_us = [1e3 * v / max(n_it.value, 1) for v in ph_ms]           # average microseconds per iteration
     y = Field(dims)
     spmv_ms_replay = A.bench_apply(rhs, y, reps=args.spmv_reps)
-    # The stand-alone SpMV with COLD caches (the metric's "SpMV GB/s vs HBM roofline"): between two applies a
-    # 256 MiB copy sweeps L2 and the Infinity Cache, the apply alone sits between the library's stream events.
-    spmv_ms_cold = None
+    cold, cold_copy = (None, None)
     if world == 1:
-        nf = 16 * 1024 * 1024                      # 2 x 256 MiB of complex fp64
-        fa, fb = Field((nf,)).set_zero(), Field((nf,))
-        t_c = ctypes.c_double()
-        tot = 0.0
-        for _ in range(args.spmv_reps):
-            fb.assign(fa)
-            mg.lib().mgcr_timer_start()
-            A(rhs, out=y)
-            mg.lib().mgcr_timer_stop(ctypes.byref(t_c))
-            tot += t_c.value
-        spmv_ms_cold = tot / args.spmv_reps
-        del fa, fb
+        cold, cold_copy = cold_apply_ms(mg, A, rhs, y, args.spmv_reps, Field)
     stored = A.stored_bytes()
     fmt, npat = A.storage_format()
     V = 16 * N
     R = args.restart
-    # Bytes each phase has to move per launch with the layout actually stored ("if the
-    # implementation stores something else ... it must report with its stored sizes"), averaged over a
-    # restart cycle (lim = number of stored directions the step orthogonalises against):
-    #   xr      r, Ap read + r written                                              3 V
-    #   apply   matrix (pattern ids + tables, or slab) + r read + Ar written + lim Aps_j read (+ Ar re-read
-    #           by the separate multidot kernel when the fused kernel is not used)
-    #   build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
-    # exact for the K iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored
-    # directions, k = 1..R, and k = R closes the cycle
-    lims = [((k - 1) % R) + 1 for k in range(1, max(n_it.value, 1) + 1)]
-    b_apply = [stored["matrix_bytes"] + 16 * ncol + 16 * N + l * V + (0 if fused.value else V) + (V if l > 8 else 0) for l in lims]
-    b_build = [(2 * R + 6) * V if l == R else (3 + l) * V for l in lims]
-    b_phase = [3.0 * V, sum(b_apply) / len(lims), sum(b_build) / len(lims)]
+    b_phase, mean_lim = gcr_phase_model(n_it.value, R, V, stored["matrix_bytes"], ncol, N, fused.value)
     names = ["xr_update_kernel (alpha, residual ring, |r|^2)",
              "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value else "SpMV + multidot_kernel",
              "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
     keys = ["xr", "apply_dots", "build"]
     dom = max(range(3), key=lambda k: ph_us[k])
     achieved = b_phase[dom] / (ph_us[dom] * 1e-6) / 1e9
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            d = json.load(open(prof))
-            if d.get("n") == n and world == 1:
-                traffic = d["phase_hbm_bytes_per_launch"].get(keys[dom])
-        except Exception:
-            traffic = None
+    traffic, traffic_note = pmc_traffic(keys[dom], n) if world == 1 else (None, "N > 1")
     b_spmv_survey = spmv_algorithmic_bytes(nnz, N, ncol)
-    mean_lim = sum(lims) / float(len(lims))
     iter_bytes_survey = b_spmv_survey + (13 + 3 * mean_lim) * V   # SURVEY.md §8(d) accounting
     iter_bytes_ours = sum(b_phase)                                # what this implementation moves
+    spmv_bytes = stored["matrix_bytes"] + 16 * ncol + 16 * N
+    cold_ms = cold["median"] if cold else None
 
     out = {
         "metric": "gcr_iterations_per_sec", "value": it_per_s * world, "unit": "it/s", "n_gpus": world,
@@ -275,38 +480,48 @@ def main():
         "value_definition": "iterations/s of ONE solve on one GPU" if world == 1 else
                             "iterations/s of the ONE distributed solve (%.1f) x n_gpus: every iteration sweeps n_gpus shards of "
                             "%d^3 rows, the weak-scaling aggregate (shard-iterations per second)" % (it_per_s, n),
+        "timing": {"what": "wall seconds of one solve of exactly %d iterations (barrier + synchronise on both sides, max over ranks), "
+                           "repeated; value and ms_per_step come from the median" % args.steps,
+                   "seconds": st, "it_per_s_min": args.steps / st["max"] * world, "it_per_s_max": args.steps / st["min"] * world},
+        "per_shard_it_per_s": it_per_s,
         "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, complex fp64, x0=0, "
                                "RHS splitmix64 seed 0" % (n, args.restart),
                    "rows": N, "nnz": nnz, "complex": True,
-                   "matrix_storage": {0: "ELL slab",
-                                      1: "row-pattern dictionary, %s patterns (2 B per row + table)" % npat,
-                                      2: "row-pattern dictionary for the columns (%s patterns) + value slab" % npat}[fmt],
+                   "matrix_storage": storage_name(fmt, npat),
                    "stored_matrix_bytes": stored["matrix_bytes"], "ell_width": stored["ell_width"], "tail_nnz": stored["tail_nnz"],
                    "partition": "1 GPU" if world == 1 else "slab x%d (grid %dx%dx%d), %s" % (
-                       world, world * n, n, n, "host-staged transport (bring-up, not a result)" if host_transport
-                       else (rccl_note or "RCCL communicator; halo: %s, all-reduce: %s" % (A.halo_kind, comm.allreduce_kind)))},
+                       world, world * n, n, n, ("host-staged transport%s (not a result)" % (", all ranks on GPU 0" if one_gpu else ""))
+                       if host_transport else "RCCL communicator; halo: %s, all-reduce: %s" % (A.halo_kind, comm.allreduce_kind))},
         "phases": {keys[k]: {"kernel": names[k], "us_per_iteration": ph_us[k], "bytes_per_launch": b_phase[k],
                              "GBps": b_phase[k] / (ph_us[k] * 1e-6) / 1e9 if ph_us[k] > 0 else None} for k in range(3)},
         "phases_timed": "in situ: hipEvents between the phases of each of the %d iterations of a GCR solve" % n_it.value,
         "spmv": {"kernel": "stand-alone operator apply (inside the solver loop it runs fused with the beta dot products: phases.apply_dots)",
-                 "ms_cold_caches": spmv_ms_cold, "ms_back_to_back_replay": spmv_ms_replay, "includes_halo_exchange": world > 1,
-                 "bytes_moved_stored_layout": stored["matrix_bytes"] + 16 * ncol + 16 * N,
-                 "GBps": None if not spmv_ms_cold else (stored["matrix_bytes"] + 16 * ncol + 16 * N) / spmv_ms_cold / 1e6,
-                 "frac_hbm_peak": None if not spmv_ms_cold else (stored["matrix_bytes"] + 16 * ncol + 16 * N) / spmv_ms_cold / 1e6 / HBM_PEAK_GBS,
+                 "ms_cold_caches": cold_ms, "ms_cold_caches_stats": cold, "ms_back_to_back_replay": spmv_ms_replay,
+                 "includes_halo_exchange": world > 1,
+                 "bytes_moved_stored_layout": spmv_bytes,
+                 "GBps": None if not cold_ms else spmv_bytes / cold_ms / 1e6,
+                 "frac_hbm_peak": None if not cold_ms else spmv_bytes / cold_ms / 1e6 / HBM_PEAK_GBS,
+                 "GBps_back_to_back": spmv_bytes / spmv_ms_replay / 1e6,
+                 "copy_of_one_vector_same_conditions": None if not cold_copy else {
+                     "ms_cold_caches": cold_copy["median"], "bytes": 2 * V, "GBps": 2 * V / cold_copy["median"] / 1e6,
+                     "frac_hbm_peak": 2 * V / cold_copy["median"] / 1e6 / HBM_PEAK_GBS,
+                     "note": "a plain y = x between the same cache sweep and the same stream events: the ceiling a cold "
+                             "%d-row kernel has under this measurement" % N},
                  "algorithmic_bytes_survey_formula": b_spmv_survey,
-                 "GBps_survey_formula": None if not spmv_ms_cold else b_spmv_survey / spmv_ms_cold / 1e6},
+                 "GBps_survey_formula": None if not cold_ms else b_spmv_survey / cold_ms / 1e6},
         "iteration": {"bytes_moved_model": iter_bytes_ours, "GBps": iter_bytes_ours / (ms_per_step * 1e-3) / 1e9,
                       "frac_hbm_peak": iter_bytes_ours / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "algorithmic_bytes_survey": iter_bytes_survey,
                       "GBps_survey": iter_bytes_survey / (ms_per_step * 1e-3) / 1e9},
         "roofline": {"kernel": names[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": b_phase[dom],
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": b_phase[dom],
                      "us_per_launch": ph_us[dom],
                      "note": "dominant phase of the iteration by time; achieved = bytes of the stored layout the phase's "
                              "kernel has to move per launch (average over a restart cycle) / its hipEvent-timed duration"
                              + ("" if world == 1 else "; N > 1: the phase times include the halo exchange (apply_dots) and both "
                                                       "all-reduces of the iteration (build)")},
         "final_rel_residual": float(hist[-1]),
+        "kernel_sources_sha16": source_sha16(),
     }
     if world > 1:
         # what the iteration's two all-reduces (4 doubles; 1 + 2 lim doubles) and its halo exchange cost on their own
@@ -318,8 +533,10 @@ def main():
         out["comm"] = comm_us
         out["comm"]["allreduce_kind"] = comm.allreduce_kind
         out["comm"]["halo_kind"] = A.halo_kind
+        out["comm"]["ranks"] = comm.size
+        out["comm"]["transport"] = "host-staged" if host_transport else "RCCL"
         out["comm"]["spmv_with_halo_exchange_ms_replay"] = spmv_ms_replay
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and with_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(n)
         except Exception as e:  # the baseline leg must never take the GPU numbers down with it
@@ -328,8 +545,6 @@ def main():
             out["cpu_baseline_optimised"] = cpu_baseline_optimised(n, args.restart)
         except Exception as e:
             out["cpu_baseline_optimised"] = {"value": None, "unit": "it/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     # orderly teardown: solver state and operator first, then the communicator, then the process group
     del gcr, x, rhs, y
     del A
@@ -341,7 +556,300 @@ def main():
         comm.h = None
         dist.destroy_process_group()
     mg.finalize()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the other BASELINE.json configs (single GPU; each runs in its own process: python bench.py --workload NAME)
+# ------------------------------------------------------------------------------------------------
+def timed_solve(mg, gcr, rhs, x, x0=None):
+    if x0 is None:
+        x.set_zero()
+    else:
+        x.assign(x0)
+    mg.lib().mgcr_synchronize()
+    t0 = time.perf_counter()
+    gcr.solve(rhs, x)
+    mg.lib().mgcr_synchronize()
+    return time.perf_counter() - t0
+
+
+def wl_poisson256_gcr(args):
+    """configs[1]'s solver at 256^3 — the working set (12 vectors of 268 MB) is far beyond the 256 MiB Infinity Cache, so
+    this is the honest HBM point of the GCR iteration."""
+    import ctypes
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, Sparse, problems
+    mg.init(0)
+    n, R, iters = 256, 5, 50
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    nnz = int(rowptr[-1])
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    dims = (n, n, n)
+    rhs, x, y = Field(dims).fill_rhs(0), Field(dims), Field(dims)
+    prm = GCR_Param(0, R, iters, 0.0, False, check_every=iters)
+    gcr = GCR(A, prm)
+    timed_solve(mg, gcr, rhs, x)
+    st = stats(repeat_timed(lambda: timed_solve(mg, gcr, rhs, x), min_total=0.25, min_reps=5))
+    prm.profile_spmv = True
+    timed_solve(mg, gcr, rhs, x)
+    ph, na, fu = (ctypes.c_double * 3)(), ctypes.c_int32(), ctypes.c_int32()
+    mg.lib().mgcr_gcr_last_profile(ph, ctypes.byref(na), ctypes.byref(fu))
+    ph_us = [1e3 * v / max(na.value, 1) for v in ph]
+    stored = A.stored_bytes()
+    fmt, npat = A.storage_format()
+    V = 16 * N
+    b_phase, mean_lim = gcr_phase_model(na.value, R, V, stored["matrix_bytes"], ncol, N, fu.value)
+    keys = ["xr", "apply_dots", "build"]
+    dom = max(range(3), key=lambda k: ph_us[k])
+    ms = st["median"] * 1e3 / iters
+    cold, cold_copy = cold_apply_ms(mg, A, rhs, y, 10, Field)
+    spmv_bytes = stored["matrix_bytes"] + 2 * V
+    b_survey = spmv_algorithmic_bytes(nnz, N, ncol) + (13 + 3 * mean_lim) * V
+    return {"workload": "3D 7-point Poisson 256^3, unpreconditioned GCR restart 5, complex fp64 (configs[1]'s solver at configs[2]'s size)",
+            "rows": N, "nnz": nnz, "matrix_storage": storage_name(fmt, npat), "iterations_per_solve": iters,
+            "it_per_s": iters / st["median"], "ms_per_iteration": ms, "timing_seconds": st,
+            "phases": {keys[k]: {"us_per_iteration": ph_us[k], "bytes_per_launch": b_phase[k], "GBps": b_phase[k] / ph_us[k] / 1e3} for k in range(3)},
+            "iteration": {"bytes_moved_model": sum(b_phase), "GBps": sum(b_phase) / ms / 1e6, "frac_hbm_peak": sum(b_phase) / ms / 1e6 / HBM_PEAK_GBS,
+                          "algorithmic_bytes_survey": b_survey, "GBps_survey": b_survey / ms / 1e6},
+            "roofline": {"kernel": keys[dom], "bound": "hbm", "achieved": b_phase[dom] / ph_us[dom] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b_phase[dom] / ph_us[dom] / 1e3 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": b_phase[dom]},
+            "spmv": {"ms_cold_caches": cold["median"], "stats": cold, "bytes_moved_stored_layout": spmv_bytes,
+                     "GBps": spmv_bytes / cold["median"] / 1e6, "frac_hbm_peak": spmv_bytes / cold["median"] / 1e6 / HBM_PEAK_GBS,
+                     "copy_of_one_vector_ms": cold_copy["median"], "copy_frac_hbm_peak": 2 * V / cold_copy["median"] / 1e6 / HBM_PEAK_GBS}}
+
+
+def wl_mg256(args):
+    """configs[2]: Poisson 256^3, 3-level aggregation MG (2^3 aggregates, piecewise-constant P, Galerkin) as flexible right
+    preconditioner of GCR restart 5; smoother 2 GCR sweeps, coarsest solve GCR tol 1e-2 / 50 iterations (src/main.cpp:841)."""
+    import numpy as np
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, MG, MG_Param, Mesh, Sparse, problems
+    mg.init(0)
+    n, levels, tol = 256, 2, 1e-8
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    nnz = int(rowptr[-1])
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    dims = (n, n, n)
+    rhs, x, y = Field(dims).fill_rhs(0), Field(dims).set_zero(), Field(dims)
+    t0 = time.perf_counter()
+    prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   levels, None, None, null_vectors=np.ones((1, N), np.complex128))
+    M = MG(A, prm)
+    mg.lib().mgcr_synchronize()
+    setup_s = time.perf_counter() - t0
+    M(rhs, out=y)
+
+    def cycle():
+        mg.lib().mgcr_synchronize()
+        t = time.perf_counter()
+        M(rhs, out=y)
+        mg.lib().mgcr_synchronize()
+        return time.perf_counter() - t
+    vc = stats(repeat_timed(cycle, min_total=0.2, min_reps=10))
+    # SURVEY.md §8(d) "algorithmic bytes — V-cycle": per level nu_pre + nu_post smoother iterations B_iter(lim) =
+    # B_spmv + (13 + 3 lim) V with lim = 1, 2, the residual B_spmv + 2 V, restrict V_l + V_(l+1), prolong+add V_(l+1) + 2 V_l
+    tot, moved, nl = 0, 0, n
+    for _ in range(levels):
+        Nl, nnzl = nl ** 3, 7 * nl ** 3 - 6 * nl ** 2
+        Vl, Vc = 16 * Nl, 16 * (nl // 2) ** 3
+        bsp = nnzl * 20 + (Nl + 1) * 4 + 2 * Vl
+        tot += 2 * sum(bsp + (13 + 3 * lim) * Vl for lim in (1, 2)) + bsp + 2 * Vl + Vl + Vc + Vc + 2 * Vl
+        moved += 5 * (Nl // 8) + 44 * Vl + 2 * Vc    # what this implementation moves above the coarsest level (DESIGN.md §6)
+        nl //= 2
+    outer = GCR(A, GCR_Param(0, 5, 200, tol, False, None, M, flexible=True, check_every=2))
+    timed_solve(mg, outer, rhs, x)
+    sv = stats(repeat_timed(lambda: timed_solve(mg, outer, rhs, x), min_total=0.3, min_reps=3, max_reps=10))
+    r = rhs - A(x)
+    return {"workload": "3D 7-point Poisson 256^3, 3-level MG V-cycle preconditioner (2^3 aggregates), flexible GCR restart 5 to 1e-8, fp64 (configs[2])",
+            "parity": MG_PARITY_NOTE, "rows": N, "nnz": nnz, "levels": [M.level_info(l) for l in range(levels + 1)],
+            "mg_setup_seconds": setup_s, "vcycle_ms": vc["median"] * 1e3, "vcycle_timing_seconds": vc,
+            "vcycle_bytes_survey_model_excl_coarsest": tot, "vcycle_GBps_survey": tot / vc["median"] / 1e9,
+            "vcycle_bytes_moved_model_excl_coarsest": moved, "vcycle_GBps_moved_lower_bound": moved / vc["median"] / 1e9,
+            "vcycle_frac_hbm_peak_moved_lower_bound": moved / vc["median"] / 1e9 / HBM_PEAK_GBS,
+            "outer_iterations": outer.last_iterations, "converged": outer.last_converged, "seconds_to_tol": sv["median"],
+            "solve_timing_seconds": sv, "tol": tol, "final_rel_residual": float(outer.last_history[-1]),
+            "true_rel_residual": r.norm() / rhs.norm()}
+
+
+def wl_ell_slab_spmv128(args):
+    """The general-matrix SpMV path (north_star's "CSR/ELL-hybrid layout with coalesced HBM row reads"): the same 128^3
+    Poisson matrix with the row-pattern dictionary switched off, i.e. as any unstructured matrix is stored — ELL slab
+    (real values here: every imaginary part is zero) + int32 columns."""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, Sparse, problems
+    mg.init(0)
+    n = 128
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    nnz = int(rowptr[-1])
+    prev = mg.set_option("pattern_storage", 0)
+    try:
+        A = Sparse(N, ncol, rowptr, col, val)
+        Ac = Sparse(N, ncol, rowptr, col, val * (1.0 + 0.25j))   # complex values: 20 B per stored entry
+    finally:
+        mg.set_option("pattern_storage", prev)
+    del rowptr, col, val
+    out = {"workload": "SpMV alone, 3D 7-point Poisson 128^3 stored as a general matrix (pattern_storage=0): ELL slab, int32 columns",
+           "rows": N, "nnz": nnz}
+    xf, yf = Field((n, n, n)).fill_rhs(0), Field((n, n, n))
+    for tag, op in (("real_values", A), ("complex_values", Ac)):
+        stored = op.stored_bytes()
+        fmt, npat = op.storage_format()
+        b = stored["matrix_bytes"] + 32 * N
+        cold, cold_copy = cold_apply_ms(mg, op, xf, yf, 30, Field)
+        warm = op.bench_apply(xf, yf, reps=50)
+        out[tag] = {"matrix_storage": storage_name(fmt, npat), "ell_width": stored["ell_width"], "bytes_moved_stored_layout": b,
+                    "ms_cold_caches": cold["median"], "stats": cold, "GBps": b / cold["median"] / 1e6,
+                    "frac_hbm_peak": b / cold["median"] / 1e6 / HBM_PEAK_GBS, "ms_back_to_back": warm, "GBps_back_to_back": b / warm / 1e6,
+                    "algorithmic_bytes_survey_formula": spmv_algorithmic_bytes(nnz, N, ncol)}
+    out["roofline"] = {"kernel": "ell_spmv_rowthread (complex slab)", "bound": "hbm", "achieved": out["complex_values"]["GBps"],
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["complex_values"]["frac_hbm_peak"], "traffic": None}
+    return out
+
+
+def wl_bcsr(args):
+    """configs[4] on one GPU: unstructured HierarchicalSparse, bs = 20, skewed blocks/row (80 % of the rows 5-9 blocks, 20 %
+    10-64), ~3 GB of blocks, diagonally dominant: apply GB/s and GCR on it."""
+    import numpy as np
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, HierarchicalSparse
+    mg.init(0)
+    rng = np.random.default_rng(5)
+    bs, nb = 20, 36000
+    per_row = np.where(rng.random(nb) < 0.8, rng.integers(5, 10, nb), rng.integers(10, 65, nb))
+    rows = np.repeat(np.arange(nb, dtype=np.int32), per_row)
+    cols = rng.integers(0, nb, rows.size).astype(np.int32)
+    first = np.concatenate([[0], np.cumsum(per_row)[:-1]])
+    cols[first] = np.arange(nb, dtype=np.int32)
+    nblk = rows.size
+    blocks = np.empty((nblk, bs, bs), np.complex128)
+    for s in range(0, nblk, 20000):
+        e = min(nblk, s + 20000)
+        blocks[s:e] = (rng.uniform(-1, 1, (e - s, bs, bs)) + 1j * rng.uniform(-1, 1, (e - s, bs, bs))) * (0.5 / bs)
+    offsum = np.bincount(rows, weights=np.abs(blocks).sum(axis=(1, 2)) / bs, minlength=nb)
+    blocks[first] = np.eye(bs)[None] * (1.0 + offsum)[:, None, None]
+    H = HierarchicalSparse(nb, nb, rows, cols, blocks)
+    del blocks
+    n = nb * bs
+    xf, yf = Field((n,)).fill_rhs(1), Field((n,))
+    H(xf, out=yf)
+    ms = stats([H.bench_apply(xf, yf, reps=10) for _ in range(7)])   # 3 GB per apply: nothing survives in a cache
+    b_alg = nblk * (bs * bs * 16 + 4) + (nb + 1) * 4 + 2 * n * 16
+    rhs, x = Field((n,)).fill_rhs(2), Field((n,))
+    gcr = GCR(H, GCR_Param(0, 5, 200, 1e-10, False, check_every=5))
+    timed_solve(mg, gcr, rhs, x)
+    sv = stats(repeat_timed(lambda: timed_solve(mg, gcr, rhs, x), min_total=0.2, min_reps=3, max_reps=10))
+    r = rhs - H(x)
+    return {"workload": "unstructured HierarchicalSparse (block-CSR, bs 20, 5-64 blocks/row), apply + GCR restart 5 to 1e-10, 1 GPU (configs[4]'s operator)",
+            "block_rows": nb, "bs": bs, "blocks": int(nblk), "matrix_GB": nblk * bs * bs * 16 / 1e9, "apply_ms": ms["median"], "apply_ms_stats": ms,
+            "algorithmic_bytes": b_alg, "GBps": b_alg / ms["median"] / 1e6,
+            "roofline": {"kernel": "bcsr_wave_kernel_t", "bound": "hbm", "achieved": b_alg / ms["median"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b_alg / ms["median"] / 1e6 / HBM_PEAK_GBS, "traffic": None},
+            "gcr_iterations": gcr.last_iterations, "gcr_converged": gcr.last_converged, "gcr_seconds": sv["median"], "gcr_timing_seconds": sv,
+            "gcr_it_per_s": gcr.last_iterations / sv["median"], "true_rel_residual": r.norm() / rhs.norm()}
+
+
+def wl_sample(args):
+    """configs[0] on the GPU: data/sample_matrix (3072 rows, 39 entries per row) through read_data, DiracOp k = 0.15, GCR restart 5
+    to 1e-13 — the reference's own golden history G3 is the check (118 iterations)."""
+    import gzip
+    import shutil
+    import tempfile
+    import numpy as np
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import DiracOp, Field, GCR, GCR_Param, read_data
+    mg.init(0)
+    d = tempfile.mkdtemp()
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "4x4parsed.txt.gz"), "rb") as fi, open(os.path.join(d, "4x4parsed.txt"), "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):   # read_data prints the reference's "File read is successful."
+        D = read_data("4x4parsed.txt", directory=d)
+    dirac = DiracOp(D, 0.15)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sample_4x4.npz"))
+    dims = (4, 4, 4, 4, 4, 3)
+    rhs, x = Field(dims, g["gcr_rhs"]), Field(dims)
+    gcr = GCR(dirac, GCR_Param(0, 5, 4000, 1e-13, False, check_every=20))
+    timed_solve(mg, gcr, rhs, x)
+    sv = stats(repeat_timed(lambda: timed_solve(mg, gcr, rhs, x), min_total=0.2, min_reps=10))
+    ref = g["g3_restart5_hist"]
+    h = gcr.last_history
+    m = min(h.size, ref.size)
+    return {"workload": "data/sample_matrix 4x4 (3072 rows), 1 - 0.15 D, GCR restart 5 to 1e-13 (configs[0] on the GPU)",
+            "iterations": gcr.last_iterations, "reference_iterations": int(ref.size - 1), "seconds": sv["median"], "timing_seconds": sv,
+            "it_per_s": gcr.last_iterations / sv["median"], "final_rel_residual": float(h[-1]), "reference_final": float(ref[-1]),
+            "max_rel_deviation_from_reference_history": float(np.max(np.abs(h[1:m] - ref[1:m]) / ref[1:m])),
+            "note": "latency regime: 3 dependent kernels per iteration on 3072 rows"}
+
+
+WORKLOADS = {"poisson256_gcr": wl_poisson256_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
+             "sample": wl_sample}
+
+
+def run_extras(argv_base, budget_s=240.0):
+    """Every other workload in its own child process (python bench.py --workload NAME), bounded in time."""
+    out = {}
+    t_end = time.time() + budget_s
+    for name in EXTRA_WORKLOADS:
+        left = t_end - time.time()
+        if left < 20:
+            out[name] = {"skipped": "time budget of the default run used up"}
+            continue
+        env = dict(os.environ, MGCR_BENCH_ROLE="worker")
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name], env=env, capture_output=True, text=True,
+                               timeout=min(left, 120))
+            d = last_json_line(p.stdout)
+            out[name] = d if (p.returncode == 0 and d is not None) else {"failed": "rc %d" % p.returncode, "stderr_tail": p.stderr[-500:]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"failed": "timeout"}
+    return out
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", dest="n", type=int, default=128, help="Poisson grid edge per GPU shard (128 = BASELINE configs[1])")
+    ap.add_argument("--restart", type=int, default=5)
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs' workloads (N = 1)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), help="run ONE of the other workloads in this process and print its JSON")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.workload:
+        print(json.dumps(WORKLOADS[args.workload](args)), flush=True)
+        return 0
+    role = os.environ.get("MGCR_BENCH_ROLE")
+    world_env = os.environ.get("WORLD_SIZE")
+    if role == "worker":
+        out = run_headline(args, with_cpu=False)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(out), flush=True)
+        return 0
+    if args.gpus > 1 and world_env is None:
+        os.environ["MGCR_BENCH_STARTED_BY"] = "bench.py launcher"
+        return run_launcher(args, argv)
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        return run_supervisor(args, argv)
+    out = run_headline(args, with_cpu=not args.no_cpu_baseline)
+    if not args.no_extras:
+        out["workloads"] = run_extras(argv)
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -128,8 +128,8 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns) {
     MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
     const Op *o = op->kind == OP_DIRAC ? op->base : op;
     MGCR_CHECK(o->kind == OP_CSR, MGCR_ERR_UNSUPPORTED, "mgcr_op_storage_format: not a Sparse");
-    if (format) *format = o->csr.pat_mode;
-    if (n_patterns) *n_patterns = o->csr.npat;
+    if (format) *format = csr_stencil_active(o->csr) ? 3 : o->csr.pat_mode;
+    if (n_patterns) *n_patterns = csr_stencil_active(o->csr) ? o->csr.sten_ns : o->csr.npat;
     return MGCR_OK;
 }
 
@@ -145,6 +145,7 @@ int mgcr_set_option(const char *name, int value, int *previous) {
     MGCR_CHECK(name, MGCR_ERR_INVALID, "null option name");
     bool prev;
     if (!strcmp(name, "pattern_storage")) prev = set_patterns_enabled(value != 0);
+    else if (!strcmp(name, "stencil_storage")) prev = set_stencil_enabled(value != 0);
     else if (!strcmp(name, "lean_cycles")) prev = set_lean_enabled(value != 0);
     else if (!strcmp(name, "fused_apply")) prev = set_fuse_enabled(value != 0);
     else if (!strcmp(name, "graph_replay")) prev = set_graph_enabled(value != 0);
@@ -160,7 +161,8 @@ int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width
         const CsrDev &A = o->csr;
         int64_t slab = (int64_t)A.nchunk * A.npad * A.L;
         int64_t ell_bytes = slab * (A.ell_val_re ? 12 : 20);
-        if (A.pat_mode == 1) ell_bytes = A.npad * 2 + (int64_t)A.npat * A.W * (A.pat_real ? 12 : 20);
+        if (csr_stencil_active(A)) ell_bytes = (A.npad / 64) * A.sten_stride * 8 + A.sten_ns * 20;   // presence words + slot table
+        else if (A.pat_mode == 1) ell_bytes = A.npad * 2 + (int64_t)A.npat * A.W * (A.pat_real ? 12 : 20);
         else if (A.pat_mode == 2) ell_bytes = A.npad * 2 + (int64_t)A.npat * A.W * 4 + slab * (A.ell_val_re ? 8 : 16);
         if (matrix_bytes) *matrix_bytes = ell_bytes + A.tail_nnz * 20 + A.n_tail_rows * 8 + (A.n_tail_rows ? 4 : 0);
         if (ell_width) *ell_width = A.nchunk * A.L;

@@ -33,7 +33,7 @@ struct DotVecs {
 };
 
 template <int MODE, int WT, int NDT>
-__global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+__global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <= 7)) && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                  DotVecs d, int64_t n, int nlogical, RowMap rm,
                                                                  double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
     __shared__ double lds[2 * NDT * 17];
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
     int64_t i, end, stride;
     row_range(rm, lb, nlogical, n, &i, &end, &stride);
     int32_t t0 = 0;
-    if (MODE != 0 && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    if ((MODE == 1 || MODE == 2) && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
     PatLds pl{nullptr, nullptr, nullptr};
     if (MODE == 1) pl = stage_patterns(m, step_smem);
     double v[2 * NDT];
@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(RED_THREADS, (MODE == 1 && NDT <= 5 ? 8 : 4)) 
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
     for (; i < end; i += stride) {
         int32_t t0_next = 0;
-        if (MODE != 0 && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
-        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
+        if ((MODE == 1 || MODE == 2) && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
+        const cplx sum = fused_row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
         const cplx yi = m.shift ? csub(x[i], cmul(m.k, sum)) : sum;
         y[i] = yi;
         // the direction streams are loaded only now (the scheduler must not hoist them): the gathers and
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m,
     int64_t i, end, stride;
     row_range(rm, lb, nlogical, n, &i, &end, &stride);
     int32_t t0 = 0;
-    if (MODE != 0 && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    if ((MODE == 1 || MODE == 2) && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
     PatLds pl{nullptr, nullptr, nullptr};
     if (MODE == 1) pl = stage_patterns(m, step_smem);
     double v[2 * NDT + 1];
@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m,
     for (int j = 0; j < 2 * NDT + 1; j++) v[j] = 0.;
     for (; i < end; i += stride) {
         int32_t t0_next = 0;
-        if (MODE != 0 && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
-        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return csub(r_in[j], cmul(alpha, ap[j])); });
+        if ((MODE == 1 || MODE == 2) && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
+        const cplx sum = fused_row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return csub(r_in[j], cmul(alpha, ap[j])); });
         const cplx rn = csub(r_in[i], cmul(alpha, ap[i]));
         r_out[i] = rn;
         v[2 * NDT] += rn.x * rn.x + rn.y * rn.y;
@@ -166,14 +166,14 @@ __global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, co
     int64_t i, end, stride;
     row_range(rm, lb, nlogical, n, &i, &end, &stride);
     int32_t t0 = 0;
-    if (MODE != 0 && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
+    if ((MODE == 1 || MODE == 2) && i < end) t0 = (int32_t)__builtin_nontemporal_load(m.pid + i) * W;
     PatLds pl{nullptr, nullptr, nullptr};
     if (MODE == 1) pl = stage_patterns(m, step_smem);
     double v[6] = {0., 0., 0., 0., 0., 0.};
     for (; i < end; i += stride) {
         int32_t t0_next = 0;
-        if (MODE != 0 && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
-        const cplx sum = row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
+        if ((MODE == 1 || MODE == 2) && i + stride < end) t0_next = (int32_t)__builtin_nontemporal_load(m.pid + i + stride) * W;
+        const cplx sum = fused_row_product<MODE, WT>(m, i, t0, pl, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
         const cplx rv = x[i];
         const cplx yi = m.shift ? csub(rv, cmul(m.k, sum)) : sum;
         y[i] = yi;
@@ -263,9 +263,16 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm); \
         else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm);          \
     } while (0)
-    if (A.pat_mode == 1) ST_W(1);
+#define ST_S(MODE)                                                                                   \
+    do {                                                                                             \
+        if (sten_slots(A) == 7) launch_nd<MODE, 7>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm); \
+        else launch_nd<MODE, 9>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm);                    \
+    } while (0)
+    if (csr_stencil_active(A)) { if (A.sten_rare) ST_S(4); else ST_S(3); }
+    else if (A.pat_mode == 1) ST_W(1);
     else if (A.pat_mode == 2) ST_W(2);
     else ST_W(0);
+#undef ST_S
 #undef ST_W
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
@@ -321,9 +328,18 @@ int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r
         else launch_xr_nd<MODE, 0>(nd, grid, lds_bytes, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,  \
                                    den_slot, slot, lc);                                                                                    \
     } while (0)
-    if (A.pat_mode == 1) SXW(1);
+#define SXS(MODE)                                                                                                                          \
+    do {                                                                                                                                   \
+        if (sten_slots(A) == 7) launch_xr_nd<MODE, 7>(nd, grid, 0, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, \
+                                                      strideA, den_slot, slot, lc);                                                        \
+        else launch_xr_nd<MODE, 9>(nd, grid, 0, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,     \
+                                   den_slot, slot, lc);                                                                                    \
+    } while (0)
+    if (csr_stencil_active(A)) { if (A.sten_rare) SXS(4); else SXS(3); }
+    else if (A.pat_mode == 1) SXW(1);
     else if (A.pat_mode == 2) SXW(2);
     else SXW(0);
+#undef SXS
 #undef SXW
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
@@ -348,7 +364,14 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
 #define IA(MODE, WT)                                                                                                            \
     hipLaunchKernelGGL((init_apply_kernel<MODE, WT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r0, aps0, b, A.nrow, g, \
                        rm, partsA, partsR, partsN, sk.p, sk.it)
-    if (A.pat_mode == 1) { if (A.W == 7) IA(1, 7); else IA(1, 0); }
+    if (csr_stencil_active(A)) {
+#define IAS(MODE, NS) hipLaunchKernelGGL((init_apply_kernel<MODE, NS>), dim3(grid), dim3(RED_THREADS), 0, ctx().stream, m, r0, aps0, b, A.nrow, g, \
+                                         rm, partsA, partsR, partsN, sk.p, sk.it)
+        if (A.sten_rare) { if (sten_slots(A) == 7) IAS(4, 7); else IAS(4, 9); }
+        else { if (sten_slots(A) == 7) IAS(3, 7); else IAS(3, 9); }
+#undef IAS
+    }
+    else if (A.pat_mode == 1) { if (A.W == 7) IA(1, 7); else IA(1, 0); }
     else if (A.pat_mode == 2) { if (A.W == 7) IA(2, 7); else IA(2, 0); }
     else { if (A.W == 7) IA(0, 7); else IA(0, 0); }
 #undef IA

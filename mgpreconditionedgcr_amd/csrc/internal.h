@@ -45,6 +45,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // extra "finalise" launch is needed and results are reproducible run to run.
 constexpr int RED_THREADS = 1024;
 constexpr int RED_MAX_BLOCKS = 512;
+constexpr int STEN_MAX = 9;   // slots of a stencil view (CsrDev::sten_*): kernels are instantiated for 7 and 9
 
 struct Context {
     bool ready = false;
@@ -91,6 +92,15 @@ struct CsrDev {
     double *pat_re = nullptr, *pat_im = nullptr;  // [npat][W], mode 1
     bool pat_real = false;        // mode 1: every imaginary part is zero
     int64_t reach = 0;            // max |column - row| over the pattern table (0: unknown) — how far a row's gathers go
+    // Stencil view of a mode-1 dictionary (spmv.hip sten_try), what the apply kernels read when it exists: the
+    // ascending superset of all patterns' column offsets (sten_ns <= STEN_MAX slots), ONE value per slot, and per
+    // wave of 64 rows one 64-bit presence word per slot (sten_planes[wave * sten_stride + slot], bit l = row
+    // 64 * wave + l has the slot).  A row's x loads then depend on nothing but the row number.
+    int32_t sten_ns = 0, sten_stride = 0;
+    uint32_t sten_rare = 0;       // slots fewer than 1/16 of the rows have: loaded only by waves whose presence word is not 0
+    int32_t sten_off[16] = {};
+    double sten_re[16] = {}, sten_im[16] = {};
+    uint64_t *sten_planes = nullptr;
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]
@@ -144,6 +154,8 @@ int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const 
                      const double *h_val_ri, CsrDev *out);
 void csr_free(CsrDev *c);
 bool set_patterns_enabled(bool on);
+bool set_stencil_enabled(bool on);
+bool csr_stencil_active(const CsrDev &A);  // the apply kernels read A through its stencil view (CsrDev::sten_*)
 bool set_lean_enabled(bool on);
 bool set_fuse_enabled(bool on);
 bool set_graph_enabled(bool on);

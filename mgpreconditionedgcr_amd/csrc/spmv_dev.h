@@ -65,6 +65,12 @@ struct RowMat {
     cplx k;
     const cplx *xh;        // halo segment of x (row block of a distributed matrix), columns >= n_own
     int32_t n_own;
+    // MODE 3: stencil view (CsrDev::sten_*)
+    int32_t sten_ns, sten_stride, sten_last;   // slots, presence words per wave, last column (clamp)
+    uint32_t sten_rare;
+    int32_t sten_off[STEN_MAX];
+    double sten_re[STEN_MAX], sten_im[STEN_MAX];
+    const uint64_t *sten_planes;
 };
 
 inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
@@ -75,8 +81,13 @@ inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
     m.pid = A.pat_id; m.poff = A.pat_off; m.pre = A.pat_re; m.pim = A.pat_im;
     m.shift = shift ? 1 : 0; m.k = k;
     m.xh = nullptr; m.n_own = INT32_MAX;
+    m.sten_ns = A.sten_ns; m.sten_stride = A.sten_stride; m.sten_last = (int32_t)A.ncol - 1; m.sten_rare = A.sten_rare;
+    for (int c = 0; c < STEN_MAX; c++) { m.sten_off[c] = A.sten_off[c]; m.sten_re[c] = A.sten_re[c]; m.sten_im[c] = A.sten_im[c]; }
+    m.sten_planes = A.sten_planes;
     return m;
 }
+// slots the stencil kernels are instantiated for (0: no stencil view)
+inline int sten_slots(const CsrDev &A) { return A.sten_ns == 0 ? 0 : A.sten_ns <= 7 ? 7 : 9; }
 inline size_t row_mat_lds_bytes(const CsrDev &A) { return A.pat_mode == 1 ? (size_t)A.npat * A.W * (A.pat_real ? 12 : 20) : 0; }
 
 // pattern table -> LDS (MODE 1); call from every thread of the workgroup, ends with a barrier
@@ -133,6 +144,64 @@ __device__ __forceinline__ cplx row_product(const RowMat &m, int64_t row, int32_
         for (int32_t c = 0; c < W; c++) sum = cadd(sum, term(c, xf(column(c))));
     }
     return sum;
+}
+
+// MODE 3.  Row `row` of A times x through the stencil view: slot c is column row + sten_off[c] (clamped into the matrix;
+// a clamped load is never used), present in this row iff bit (row & 63) of the wave's presence word c is set.  Slots
+// are in ascending column order = CSR order and absent ones are skipped, so the sum is the one row_product forms minus
+// its "+ 0 * x" padding terms: same bits for finite x.  The x loads depend on the row number alone — the presence
+// words arrive through the scalar cache meanwhile — where the dictionary kernels chain id -> table -> gather.
+// All 64 lanes of a wave must hold consecutive rows starting at a multiple of 64.  RARE: some slots (halo columns of
+// a distributed row block) are loaded only when the wave's presence word is not 0.
+template <int NS, bool RARE, class XF>
+__device__ __forceinline__ cplx sten_row_product(const RowMat &m, int64_t row, XF xf) {
+    const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(row >> 6));
+    const uint64_t *pp = m.sten_planes + (int64_t)wave * m.sten_stride;
+    uint64_t pl[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) pl[c] = pp[c];
+    cplx xv[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        xv[c] = make_double2(0., 0.);
+        if (!RARE || !(m.sten_rare >> c & 1u)) {
+            int32_t j = (int32_t)row + m.sten_off[c];
+            j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
+            xv[c] = xf(j);
+        }
+    }
+    if (RARE) {
+#pragma unroll
+        for (int c = 0; c < NS; c++)
+            if ((m.sten_rare >> c & 1u) && pl[c] != 0ull) {
+                int32_t j = (int32_t)row + m.sten_off[c];
+                j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
+                xv[c] = xf(j);
+            }
+    }
+    // the presence bits must not be looked at before every load is in flight (the scheduler would otherwise
+    // wait for them first and serialise the two round trips)
+    __builtin_amdgcn_sched_barrier(0);
+    const int lane = (int)(threadIdx.x & 63);
+    cplx sum = make_double2(0., 0.);
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        const bool on = (pl[c] >> lane & 1ull) != 0ull;
+        const cplx t = m.realv ? make_double2(m.sten_re[c] * xv[c].x, m.sten_re[c] * xv[c].y)
+                               : cmul(make_double2(m.sten_re[c], m.sten_im[c]), xv[c]);
+        const cplx nsum = cadd(sum, t);
+        sum.x = on ? nsum.x : sum.x;
+        sum.y = on ? nsum.y : sum.y;
+    }
+    return sum;
+}
+
+// the row product of the GCR step kernels (gcr_fused.hip): MODE 0..2 as above, 3 / 4 = stencil view without / with
+// rarely present slots, WT = its slot count
+template <int MODE, int WT, class XF>
+__device__ __forceinline__ cplx fused_row_product(const RowMat &m, int64_t row, int32_t t0, const PatLds &pl, XF xf) {
+    if constexpr (MODE >= 3) return sten_row_product<WT, MODE == 4>(m, row, xf);
+    else return row_product<MODE, WT>(m, row, t0, pl, xf);
 }
 
 }  // namespace mgcr

@@ -1,0 +1,101 @@
+"""bench.py's process structure (no GPU): `python bench.py --gpus N` with WORLD_SIZE unset must start its N ranks
+itself, each rank supervising a worker child it can restart with a more conservative transport; a failed rank must
+surface as a non-zero exit.  The launcher's command / environment construction is a pure function and is checked here;
+the supervisor ladder is run end to end over gloo with a stand-in worker."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_launcher_plan_builds_one_rank_per_gpu():
+    plan = bench.launcher_plan(4, ["--gpus", "4", "--steps", "7"], 29511, base_env={"PATH": "/usr/bin", "MGCR_BENCH_ROLE": "worker"})
+    assert len(plan) == 4
+    for r, (cmd, env) in enumerate(plan):
+        assert cmd[0] == sys.executable and cmd[1] == os.path.join(ROOT, "bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "7"]
+        assert env["RANK"] == env["LOCAL_RANK"] == str(r)
+        assert env["WORLD_SIZE"] == "4" and env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29511"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"     # dmabuf IPC: hipIpc mailboxes and RCCL need it on this pool
+        assert "MGCR_BENCH_ROLE" not in env                 # the ranks are supervisors, not workers
+        assert env["PATH"] == "/usr/bin"
+
+
+def test_worker_command_carries_the_transport_mode():
+    cmd, env = bench.worker_command(["--gpus", "2"], 1234, {"MGCR_PEER_ALLREDUCE": "0"}, base_env={"RANK": "1", "WORLD_SIZE": "2"})
+    assert env["MGCR_BENCH_ROLE"] == "worker" and env["MASTER_PORT"] == "1234" and env["MGCR_PEER_ALLREDUCE"] == "0"
+    assert env["RANK"] == "1" and cmd[-2:] == ["--gpus", "2"]
+    # the ladder ends with the host-staged transport and starts with the library's own choice
+    assert bench.LADDER[0][1] == {} and bench.LADDER[-1][1] == {"MGCR_BENCH_TRANSPORT": "host"}
+    assert len(bench.ATTEMPT_TIMEOUT_S) == len(bench.LADDER)
+
+
+def test_last_json_line_and_stats():
+    assert bench.last_json_line("noise\n{\"a\": 1}\nwarning: x\n") == {"a": 1}
+    assert bench.last_json_line("nothing here") is None
+    s = bench.stats([3.0, 1.0, 2.0, 10.0])
+    assert s == {"median": 2.5, "min": 1.0, "max": 10.0, "repetitions": 4}
+
+
+def test_traffic_is_only_reported_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    sha = bench.source_sha16()
+    assert len(sha) == 16 and sha == bench.source_sha16()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "mgpreconditionedgcr_amd" / "csrc")
+    (tmp_path / "mgpreconditionedgcr_amd" / "csrc" / "a.hip").write_text("kernel v1")
+    now = bench.source_sha16()
+    json.dump({"n": 128, "src_sha16": now, "phase_hbm_bytes_per_launch": {"build": 5.0}}, open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
+    assert bench.pmc_traffic("build", 128)[0] == 5.0
+    assert bench.pmc_traffic("build", 256)[0] is None
+    (tmp_path / "mgpreconditionedgcr_amd" / "csrc" / "a.hip").write_text("kernel v2")   # a kernel changed: stale
+    val, note = bench.pmc_traffic("build", 128)
+    assert val is None and "other kernel sources" in note
+
+
+def _run_ladder(tmp_path, fail_modes):
+    """Two supervisors over gloo with a stand-in worker that fails in the given transport modes."""
+    fake = tmp_path / "fake_bench.py"
+    fake.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import bench
+        if os.environ.get("MGCR_BENCH_ROLE") == "worker":
+            mode = "host" if os.environ.get("MGCR_BENCH_TRANSPORT") == "host" else "rccl" if os.environ.get("MGCR_PEER_ALLREDUCE") == "0" else "default"
+            if mode in %r and os.environ["RANK"] == "1":     # only ONE rank fails: every rank must move on together
+                sys.exit(3)
+            if os.environ["RANK"] == "0":
+                print(json.dumps({"metric": "gcr_iterations_per_sec", "value": 1.0, "mode": mode}))
+            sys.exit(0)
+        bench.__file__ = os.path.abspath(__file__)
+        sys.exit(bench.run_supervisor(None, sys.argv[1:]))
+    """ % (ROOT, list(fail_modes))))
+    port = bench.free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("MGCR_BENCH_ROLE", None)
+        procs.append(subprocess.Popen([sys.executable, str(fake), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_supervisors_fall_back_together(tmp_path):
+    rcs, outs = _run_ladder(tmp_path, ["default"])
+    assert rcs == [0, 0], outs
+    d = bench.last_json_line(outs[0][0])
+    assert d["mode"] == "rccl"
+    att = d["launch"]["attempts"]
+    assert [a["ok"] for a in att] == [False, True] and att[0]["ranks_failed"] == 1 and d["launch"]["ranks"] == 2
+    assert bench.last_json_line(outs[1][0]) is None        # exactly one line, from rank 0
+
+
+def test_supervisors_exit_non_zero_when_nothing_works(tmp_path):
+    rcs, outs = _run_ladder(tmp_path, ["default", "rccl", "host"])
+    assert rcs == [1, 1], outs
+    assert bench.last_json_line(outs[0][0]) is None

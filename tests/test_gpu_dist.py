@@ -35,7 +35,7 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
     for kind in ("poisson", "random", "poisson48"):
         N, rowptr, col, val, gran = problem(kind)
         A = Sparse(N, N, rowptr, col, val)
-        assert res[0][kind]["format"] == (1 if kind == "poisson48" else 0)
+        assert res[0][kind]["format"] == (3 if kind == "poisson48" else 0)   # stencil view, halo columns as rarely present slots
         # the per-iteration scalars went through the peer-write mailboxes (self-test passed on every rank), unless
         # the run asked for the transport's own all-reduce
         want = "host" if os.environ.get("MGCR_PEER_ALLREDUCE") == "0" else "peer-write"

@@ -202,7 +202,7 @@ def test_device_setup_bit_identical_to_oracle(kind, sample_matrix_path, mg_gold)
         dims, nlevel = (n, n, n), 2
         vecs = np.ones((1, N), np.complex128)
         A = Sparse(N, ncol, rowptr, col, val)
-        assert A.storage_format()[0] == (1 if n == 32 else 0)
+        assert A.storage_format()[0] == (3 if n == 32 else 0)   # 32^3: dictionary + stencil view
         M = MG(A, MG_Param(Mesh(dims), 2, 1, None, co, sm, nlevel, None, None, null_vectors=vecs))
         Mo = orc.MG(orc.csr(N, ncol, rowptr, col, val), rowptr, col, val, dims, (1, 1, 1), 2, vecs, nlevel + 1, smo, coo)
     else:

@@ -338,16 +338,26 @@ def test_row_pattern_storage_is_bit_exact(case):
     x = problems.rhs_grid(N, 9)
     O = orc.csr(N, ncol, rowptr, col, val)
     ref = O(x)
-    A = Sparse(N, ncol, rowptr, col, val)
-    fmt, npat = A.storage_format()
-    assert fmt == want, (fmt, npat)
-    if case in ("real-constant", "complex-constant"):
-        assert npat == 27  # 3 boundary classes per axis
     xf = Field((N,), x)
-    y = A(xf).to_numpy()
-    assert np.array_equal(y, ref)
     k = 0.3 - 0.2j
-    assert np.array_equal(DiracOp(A, k)(xf).to_numpy(), orc.dirac(O, k)(x))
+    # constant-coefficient stencils additionally get the stencil view (format 3: 7 slots, presence words per wave,
+    # csrc/spmv.hip sten_try), which the apply kernels then read instead of the dictionary: both must give the bits
+    for stencil in (1, 0):
+        prev = mg.set_option("stencil_storage", stencil)
+        try:
+            A = Sparse(N, ncol, rowptr, col, val)
+            fmt, npat = A.storage_format()
+            if stencil and want == 1:
+                assert (fmt, npat) == (3, 7), (fmt, npat)
+            else:
+                assert fmt == want, (fmt, npat)
+                if want == 1:
+                    assert npat == 27  # 3 boundary classes per axis
+            y = A(xf).to_numpy()
+            assert np.array_equal(y, ref)
+            assert np.array_equal(DiracOp(A, k)(xf).to_numpy(), orc.dirac(O, k)(x))
+        finally:
+            mg.set_option("stencil_storage", prev)
     prev = mg.set_option("pattern_storage", 0)
     try:
         B = Sparse(N, ncol, rowptr, col, val)
@@ -365,18 +375,21 @@ def test_row_pattern_storage_same_solve():
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
     b = Field((n, n, n)).fill_rhs(3)
     out = []
-    for on in (1, 0):
+    for on, stencil in ((1, 1), (1, 0), (0, 0)):   # stencil view | dictionary | plain slab
         prev = mg.set_option("pattern_storage", on)
+        prev_s = mg.set_option("stencil_storage", stencil)
         try:
             A = Sparse(N, ncol, rowptr, col, val)
+            g = GCR(A, GCR_Param(0, 5, 60, 1e-12, False))
+            x = Field((n, n, n)).set_zero()
+            g.solve(b, x)
+            out.append((A.storage_format()[0], g.last_history.copy(), x.to_numpy()))
         finally:
             mg.set_option("pattern_storage", prev)
-        g = GCR(A, GCR_Param(0, 5, 60, 1e-12, False))
-        x = Field((n, n, n)).set_zero()
-        g.solve(b, x)
-        out.append((A.storage_format()[0], g.last_history.copy(), x.to_numpy()))
-    assert out[0][0] == 1 and out[1][0] == 0
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+            mg.set_option("stencil_storage", prev_s)
+    assert [o[0] for o in out] == [3, 1, 0]
+    for o in out[1:]:
+        assert np.array_equal(out[0][1], o[1]) and np.array_equal(out[0][2], o[2])
 
 
 @pytest.mark.parametrize("kind,restart,tol", [("poisson", 5, 1e-10), ("poisson", 1, 1e-6), ("poisson", 8, 1e-10),
