@@ -186,6 +186,9 @@ int mgcr_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y) {
     MGCR_CHECK(x->n == op->dim, MGCR_ERR_INVALID, "Sparse matrix dimension does not match Field dimension!");
     int64_t nrow = op->nrow ? op->nrow : op->dim;
     MGCR_CHECK(y->n == nrow, MGCR_ERR_INVALID, "output Field has %lld entries, operator has %lld rows", (long long)y->n, (long long)nrow);
+    // no operator applies in place: the matrix kernels gather from x while they write y, and an MG / GCR operator reads its
+    // input again after it has started to write the output (post-smoother, x0 handling)
+    MGCR_CHECK(x->d != y->d, MGCR_ERR_INVALID, "mgcr_op_apply: input and output must be different Fields");
     LOCK();
     return op_apply_raw(op, x->d, y->d, x->n);
 }

@@ -95,6 +95,40 @@ struct Comm {
     int *pw_err = nullptr;                   // pinned host word the kernel sets when a wait timed out
 };
 
+// live communicators: every host synchronisation point that hands distributed results back asks each of them whether a
+// peer-write wait timed out since the last look (comm_check_all) — an operator apply, a V-cycle or a nested solve on a
+// distributed operator must not return plausible numbers computed from a halo that never arrived
+static std::vector<Comm *> &live_comms() {
+    static std::vector<Comm *> v;
+    return v;
+}
+static std::mutex &live_comms_mtx() {
+    static std::mutex m;
+    return m;
+}
+static void comm_register(Comm *c) {
+    std::lock_guard<std::mutex> lk(live_comms_mtx());
+    live_comms().push_back(c);
+}
+static void comm_unregister(Comm *c) {
+    std::lock_guard<std::mutex> lk(live_comms_mtx());
+    auto &v = live_comms();
+    v.erase(std::remove(v.begin(), v.end(), c), v.end());
+}
+
+// first sequence number of the peer-write exchanges (tests start just below the 32-bit wrap: MGCR_TEST_PW_SEQ0)
+static uint32_t pw_seq0() {
+    const char *e = getenv("MGCR_TEST_PW_SEQ0");
+    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+}
+// Next sequence number.  Never 0 (mailboxes start zeroed), and the slot parity (seq & 1) must keep alternating: after
+// 0xFFFFFFFF (odd) comes 2, not 1 — two consecutive exchanges in one slot would let a fast rank overwrite words a slower
+// peer has not read yet.
+static uint32_t pw_advance(uint32_t seq) {
+    seq++;
+    return seq == 0 ? 2u : seq;
+}
+
 static int comm_device_ready(Comm *c) {
     if (c->comm_stream) return MGCR_OK;
     MGCR_TRY(require_ctx());
@@ -201,8 +235,7 @@ __global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ 
 }
 
 static uint32_t pw_next_seq(Comm *c) {
-    c->pw_seq++;
-    if (c->pw_seq == 0) c->pw_seq = 1;
+    c->pw_seq = pw_advance(c->pw_seq);
     return c->pw_seq;
 }
 
@@ -542,6 +575,8 @@ struct HaloPwPeer {
     uint64_t *flag_remote[2];     // the peer's flag word for this rank
     const uint64_t *flag_local[2];  // this rank's flag word for the peer
     int64_t send_off, send_cnt;   // this rank's send list for the peer (send_idx)
+    cplx *rx_local[2];            // where the peer's rows land in this rank's receive slots ...
+    int64_t recv_cnt;             // ... and how many: poisoned with NaN when the peer never arrives
 };
 
 __global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restrict__ tab, int npeer, const int32_t *__restrict__ idx,
@@ -570,7 +605,14 @@ __global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restri
                 __builtin_amdgcn_s_sleep(2);
             }
         }
-        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok) {
+            // the neighbour never published: flag it (every host synchronisation point turns the flag into MGCR_ERR_COMM,
+            // comm_check_all) and poison the rows it owed with NaN, as the all-reduce does with its sums — a missed
+            // check must not be able to yield plausible numbers from a stale or half-written slot
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int64_t i = 0; i < q.recv_cnt; i++) q.rx_local[slot][i] = make_double2(nan, nan);
+        }
     }
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -588,8 +630,7 @@ static const cplx *halo_pw_slot(const DistCsr *d, uint32_t seq) {
 
 static int halo_pw_launch(DistCsr *d, const cplx *x) {
     Comm *c = d->comm;
-    d->pw_seq++;
-    if (d->pw_seq == 0) d->pw_seq = 1;
+    d->pw_seq = pw_advance(d->pw_seq);
     const int np = (int)d->plan->peers.size();
     hipLaunchKernelGGL(halo_pw_kernel, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
                        (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, d->pw_on ? pw_timeout_run() : PW_TIMEOUT_TEST);
@@ -682,6 +723,8 @@ static int halo_pw_setup(DistCsr *d) {
             }
             e.send_off = d->send_off[(size_t)p];
             e.send_cnt = d->send_cnt[(size_t)p];
+            for (int sl = 0; sl < 2; sl++) e.rx_local[sl] = reinterpret_cast<cplx *>(d->pw_rx + (size_t)sl * slot_bytes) + P->recv_off[(size_t)p];
+            e.recv_cnt = P->recv_count[(size_t)p];
             max_cnt = std::max(max_cnt, e.send_cnt);
         }
         d->pw_grid_x = (unsigned)std::min<int64_t>(std::max<int64_t>((max_cnt + 255) / 256, 1), 1024);
@@ -884,10 +927,20 @@ int comm_fold_allreduce(Comm *c, const double *pa, int na, const double *pb, int
 int comm_check(Comm *c) {
     if (c && c->pw_err && *(volatile int *)c->pw_err != 0) {
         *(volatile int *)c->pw_err = 0;
-        set_error("peer-write all-reduce: a rank did not arrive within the time limit; the communicator is no longer usable");
+        set_error("peer-write exchange (all-reduce or halo): a rank did not arrive within the time limit; the communicator is no longer usable");
         return MGCR_ERR_COMM;
     }
     return MGCR_OK;
+}
+
+int comm_check_all() {
+    std::lock_guard<std::mutex> lk(live_comms_mtx());
+    int rc = MGCR_OK;
+    for (Comm *c : live_comms()) {
+        int r = comm_check(c);
+        if (r != MGCR_OK) rc = r;
+    }
+    return rc;
 }
 
 int dist_halo_kind(DistCsr *d) { return d->pw_on ? 2 : d->comm->is_rccl ? 1 : 0; }
@@ -900,6 +953,7 @@ int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const
     DistCsr *d = new DistCsr();
     d->comm = c;
     d->plan = P;
+    d->pw_seq = pw_seq0();
     const int64_t nh = (int64_t)P->halo_gid.size();
     int rc = csr_build_device(nloc, nloc + nh, rowptr, P->col_local.data(), val_ri, &op->csr);
     if (rc != MGCR_OK) { dist_free(d); return rc; }
@@ -974,6 +1028,8 @@ int mgcr_comm_create_rccl(int rank, int nranks, const void *id128, mgcr_comm_t *
     }
     int rc = comm_device_ready(c);
     if (rc != MGCR_OK) { delete c; return rc; }
+    c->pw_seq = pw_seq0();
+    comm_register(c);
     *out = c;
     return MGCR_OK;
 }
@@ -984,6 +1040,8 @@ int mgcr_comm_create_host(int rank, int nranks, mgcr_allreduce_cb allreduce, mgc
     mgcr_comm_s *c = new mgcr_comm_s();
     c->rank = rank; c->nranks = nranks; c->is_rccl = false;
     c->allreduce = allreduce; c->exchange = exchange; c->user = user;
+    c->pw_seq = pw_seq0();
+    comm_register(c);
     *out = c;
     return MGCR_OK;
 }
@@ -1022,6 +1080,7 @@ int mgcr_comm_bench_allreduce(mgcr_comm_t c, int32_t count, int32_t reps, double
 
 int mgcr_comm_destroy(mgcr_comm_t c) {
     if (!c) return MGCR_OK;
+    comm_unregister(c);
     if (ctx().ready) {
         hipStreamSynchronize(ctx().stream);
         if (c->comm_stream) hipStreamSynchronize(c->comm_stream);

@@ -209,6 +209,7 @@ bool comm_collectives(Comm *c);
 int comm_allreduce_dev(Comm *c, double *dbuf, int count);
 int comm_fold_allreduce(Comm *c, const double *pa, int na, const double *pb, int nb, double *out, int nblk);
 int comm_check(Comm *c);
+int comm_check_all();   // every live communicator; called where results are handed back to the host
 constexpr int PW_MAX_RANKS = 16;  // peer-write all-reduce (comm.hip): one lane per rank
 
 // ---- mg.hip ----------------------------------------------------------------------------------

@@ -134,6 +134,34 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         os._exit(0)   # the communicator is unusable after the timeout: skip its destructors
+    if mode == "pw-timeout-apply":
+        # the same for an operator apply alone (no solve around it): rank 1 never starts the halo exchange rank 0 waits
+        # for.  The download that hands y back must fail with MGCR_ERR_COMM, and the rows that depend on the halo that
+        # never arrived must be NaN, not stale values
+        import ctypes
+        import time
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistSparse, Field
+        mg.init(0)
+        N, rowptr, col, val, gran = problem("poisson")
+        offs = split_rows(N // gran, world)
+        r0, r1 = offs[rank] * gran, offs[rank + 1] * gran
+        lp, lc, lv = local_block(rowptr, col, val, r0, r1)
+        A = DistSparse(comm, N, r0, lp, lc, lv)
+        results["kind"] = A.halo_kind
+        results["rc"] = 0
+        if rank == 0 and results["kind"] == "peer-write":
+            xf = Field((r1 - r0,), problems.rhs_grid(N, 5)[r0:r1])
+            yf = Field((r1 - r0,))
+            t0 = time.time()
+            rc_apply = mg.lib().mgcr_op_apply(A.h, xf.h, yf.h)
+            out = np.empty(r1 - r0, np.complex128)
+            rc = mg.lib().mgcr_vec_download(yf.h, out.ctypes.data)
+            results.update(rc_apply=rc_apply, rc=rc, seconds=time.time() - t0, error=mg.lib().mgcr_last_error().decode(), y=out)
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        os._exit(0)
     if mode == "nullvec":
         # MG::Arnoldi (src/MG.h:90-122) on a distributed operator: the inverse iteration's norms and the Gram-Schmidt
         # dot products must be GLOBAL (Comm.dot), and the start vector the same global vector on every world size

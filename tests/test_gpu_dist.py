@@ -121,6 +121,32 @@ def test_peer_write_wait_times_out_cleanly(tmp_path, monkeypatch):
     assert res[1]["rc"] == 0
 
 
+def test_peer_write_halo_timeout_is_reported_by_an_apply(tmp_path, monkeypatch):
+    """A neighbour that never starts its halo exchange, seen from an operator apply with no solver around it: the apply
+    is enqueued, the download that hands y back returns MGCR_ERR_COMM, and the rows next to the missing halo are NaN —
+    a stale or half-written receive slot can not yield plausible numbers."""
+    monkeypatch.setenv("MGCR_PEER_TIMEOUT_MS", "300")
+    res = run_workers("pw-timeout-apply", 2, tmp_path, timeout=300)
+    if res[0]["kind"] != "peer-write":
+        pytest.skip("peer-write halo path not available here (%s)" % res[0]["kind"])
+    assert res[0]["rc_apply"] == 0                      # enqueueing succeeds ...
+    assert res[0]["rc"] != 0 and "did not arrive" in res[0]["error"], res[0]     # ... the hand-back does not
+    assert res[0]["seconds"] < 30.0
+    y = res[0]["y"]
+    n = 6
+    assert np.isnan(y[-n * n:]).all()                   # the last plane reads the halo that never came
+    assert np.isfinite(y[:-n * n]).all()
+    assert res[1]["rc"] == 0
+
+
+def test_peer_write_sequence_number_wrap(tmp_path, monkeypatch):
+    """The peer-write exchanges alternate between two slots by sequence parity; across the 32-bit wrap the sequence goes
+    0xFFFFFFFF -> 2 (never 0, parity keeps alternating).  Starting three steps below the wrap, a distributed solve must
+    give what it gives anywhere else."""
+    monkeypatch.setenv("MGCR_TEST_PW_SEQ0", "0xFFFFFFFD")
+    test_distributed_gcr_matches_single_process(tmp_path, 2)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_near_null_vectors(tmp_path, world):
     """MG_Param without given null vectors on a distributed operator: the inverse iteration (src/MG.h:90-122) runs with

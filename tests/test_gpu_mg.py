@@ -329,3 +329,24 @@ def test_mg_on_a_hierarchical_sparse_operator():
     xs = Field(dims).set_zero()
     outer.solve(Field(dims, x), xs)
     assert outer.last_converged and ((Field(dims, x) - H(xs)).norm() / np.linalg.norm(x)) <= 2e-10
+
+
+def test_no_operator_applies_in_place():
+    """mgcr_op_apply rejects input == output for EVERY operator kind: the matrix kernels gather from x while they write y,
+    and an MG (or GCR) operator reads its input again after it has begun to write the output (src/MG.h:405-430 passes
+    fields by value, so the reference cannot alias them either)."""
+    n = 8
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    prm = MG_Param(Mesh((n, n, n)), 2, 1, None, GCR(GCR_Param(0, 10, 20, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   1, None, None, null_vectors=np.ones((1, N), np.complex128))
+    M = MG(A, prm)
+    S = GCR(A, GCR_Param(0, 5, 3, 1e-30, False))
+    rng = np.random.default_rng(0)
+    H = HierarchicalSparse(4, 4, [0, 1, 2, 3], [0, 1, 2, 3], rng.standard_normal((4, 2, 2)) + 0j)
+    x = Field((n, n, n)).fill_rhs(1)
+    for op, f in ((A, x), (DiracOp(A, 0.1), x), (M, x), (S, x), (H, Field((8,)).fill_rhs(2))):
+        before = f.to_numpy()
+        with pytest.raises(mg.MgcrError, match="different Fields|in place"):
+            op(f, out=f)
+        assert np.array_equal(f.to_numpy(), before)     # rejected before anything ran
