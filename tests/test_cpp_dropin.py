@@ -35,9 +35,19 @@ def test_config1_history_through_the_cpp_interface(sample_matrix_path, sample_go
     ref = sample_gold["g3_restart5_hist"]
     assert "GCR converged after 118 steps." in out or "GCR converged after 117 steps." in out or "GCR converged after 119 steps." in out
     n = min(hist.size, ref.size)
-    # printed with 11 significant digits (src/GCR.h:271); steps > 60 are at the mercy of the summation order (see test_gpu_parity)
-    assert np.allclose(hist[1:60], ref[1:60], rtol=1e-9, atol=0)
-    assert np.allclose(hist[60:n], ref[60:n], rtol=1e-4, atol=0)
+    # Printed with 11 significant digits (src/GCR.h:271): 5e-11 relative is the print's own resolution.  The bound is the
+    # one tests/test_gpu_parity.py uses: max(1e-9 h_ref, 8 s(k)), s(k) = how far the REFERENCE's own history moves when
+    # its dot products are summed in another order (oracle, pinned to the reference bit for bit) — and, this being the
+    # headline golden, SURVEY.md 8(c)'s fixed bound on top: 1e-9 relative while h_ref >= 1e-9, 1e-6 below.
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc  # checker only
+    nrow, ncol, rowptr, col, val = orc.read_text_csr(sample_matrix_path)
+    _, sens, _ = orc.gcr_reorder_sensitivity(orc.dirac(orc.csr(nrow, ncol, rowptr, col, val), 0.15),
+                                             orc.gcr_param(restart=5, max_iter=4000, tol=1e-13), sample_gold["gcr_rhs"])
+    for k in range(1, n):
+        tol = max(1e-9 * ref[k], 8 * sens[k] if k < sens.size else 0.0) + 5e-11 * ref[k]
+        assert abs(hist[k] - ref[k]) <= tol, (k, hist[k], ref[k], tol)
+        assert abs(hist[k] - ref[k]) <= ((1e-9 if ref[k] >= 1e-9 else 1e-6) + 5e-11) * ref[k], (k, hist[k], ref[k])
     m = re.search(r"true relative residual of \(x - x0\): (\S+)", out)
     assert m and float(m.group(1)) < 1e-12  # x_final = x0 + A^-1 b
 

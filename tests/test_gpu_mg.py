@@ -350,3 +350,41 @@ def test_no_operator_applies_in_place():
         with pytest.raises(mg.MgcrError, match="different Fields|in place"):
             op(f, out=f)
         assert np.array_equal(f.to_numpy(), before)     # rejected before anything ran
+
+
+def test_config3_full_size_mg_gcr_256():
+    """BASELINE configs[2] at its real size (the oracle stays at the sizes it covers; here size-independent properties):
+    Poisson 256^3, 3-level aggregation MG (2^3 aggregates, piecewise-constant P, Galerkin), smoother 2 GCR sweeps, coarsest
+    solve GCR tol 1e-2 / 50 iterations, flexible GCR restart 5.  The cycle itself is parity-unpinned (module docstring)."""
+    n, levels, tol = 256, 2, 1e-8
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    dims = (n, n, n)
+    prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   levels, None, None, null_vectors=np.ones((1, N), np.complex128))
+    M = MG(A, prm)
+    assert [M.level_info(l)["dim"] for l in range(3)] == [256 ** 3, 128 ** 3, 64 ** 3]
+    rhs = Field(dims).fill_rhs(0)
+    x = Field(dims).set_zero()
+    outer = GCR(A, GCR_Param(0, 5, 200, tol, False, None, M, flexible=True, check_every=1))
+    outer.solve(rhs, x)
+    assert outer.last_converged and outer.last_iterations <= 30, outer.last_iterations
+    h = outer.last_history
+    assert h[-1] <= tol and (np.diff(h) < 0).all()               # flexible GCR minimises the residual: monotone
+    true_rel = (rhs - A(x)).norm() / rhs.norm()
+    assert true_rel <= 1.5e-8
+    assert abs(true_rel - h[-1]) <= 1e-6 * h[-1]                 # the recurrence residual IS the true residual
+    # projector identities of test_MG_property (src/main.cpp:899-909) on the 256^3 hierarchy: R P = 1 on the coarse space,
+    # hence R P R = R and P R P R = P R
+    v = Field(dims).fill_rhs(3)
+    Rv = M.restrict(v)
+    PRv = M.expand(Rv)
+    RPRv = M.restrict(PRv)
+    assert (RPRv - Rv).norm() <= 1e-13 * Rv.norm()
+    assert (M.expand(RPRv) - PRv).norm() <= 1e-13 * PRv.norm()
+    # Galerkin consistency on the coarse space: R A P w = A_c w
+    w = Field((M.level_info(1)["dim"],)).fill_rhs(4)
+    lhs = M.restrict(A(M.expand(w)))
+    rhs_c = M.level_operator(1)(w)
+    assert (lhs - rhs_c).norm() <= 1e-12 * rhs_c.norm()

@@ -63,12 +63,53 @@ def x_close(x, A, rhs, gcr, xo, sens):
         assert np.abs(x.to_numpy() - xo).max() <= 1e-8 * np.abs(xo).max()
 
 
-def hist_close(h, ref, what="", sens=None):
+OBSERVED = {}   # golden tag -> observed deviation of the GPU history from the reference's (written out at module teardown)
+
+
+def record_deviation(tag, path, h, ref):
+    """Observed deviation per golden, committed as tests/golden/observed_r02.json: max relative deviation over the steps
+    with h_ref >= 1e-9 and over those below, and the step at which the maximum occurs."""
     n = min(h.size, ref.size)
+    rel = np.abs(h[1:n] - ref[1:n]) / ref[1:n]
+    hi = ref[1:n] >= 1e-9
+    k = int(np.argmax(rel)) + 1 if n > 1 else 0
+    OBSERVED.setdefault(tag, {})[path] = {
+        "steps_compared": int(n - 1), "iterations_gpu": int(h.size - 1), "iterations_reference": int(ref.size - 1),
+        "max_rel_dev_where_ref_ge_1e-9": float(rel[hi].max()) if hi.any() else 0.0,
+        "max_rel_dev_where_ref_lt_1e-9": float(rel[~hi].max()) if (~hi).any() else 0.0,
+        "step_of_max": k, "ref_at_step_of_max": float(ref[k]) if n > 1 else None}
+
+
+def fixed_bound_ok(h, ref, hi=1e-9, lo=1e-6):
+    """SURVEY.md §8(c), the FIXED bound: |h_gpu(k) - h_ref(k)| / h_ref(k) <= 1e-9 while h_ref(k) >= 1e-9, <= 1e-6 below
+    that.  Returns (ok, first offending step)."""
+    n = min(h.size, ref.size)
+    for k in range(1, n):
+        if abs(h[k] - ref[k]) > (hi if ref[k] >= 1e-9 else lo) * ref[k]:
+            return False, k
+    return True, None
+
+
+def hist_close(h, ref, what="", sens=None, path=None):
+    n = min(h.size, ref.size)
+    if path is not None:
+        record_deviation(what, path, h, ref)
     for k in range(1, n):
         s = sens[k] if sens is not None and k < sens.size else 0.0
         tol = max(1e-9 * ref[k], 8 * s) + 1e-17
         assert abs(h[k] - ref[k]) <= tol, "%s step %d: %.12e vs ref %.12e (sensitivity %.2e)" % (what, k, h[k], ref[k], s)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_observed():
+    yield
+    if OBSERVED:
+        import json
+        import os
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "observed_deviation.json"), "w") as f:
+            json.dump(OBSERVED, f, indent=1, sort_keys=True)
 
 
 @pytest.fixture(scope="module")
@@ -133,7 +174,7 @@ def _okw(kw):
 
 
 @pytest.mark.parametrize("tag,kw,iters", GCR_CASES)
-def test_gcr_history_vs_reference(sample, sample_oracle, sample_gold, tag, kw, iters):
+def test_gcr_history_vs_reference(sample, sample_oracle, sample_gold, tag, kw, iters, solver_path):
     g = sample_gold
     dirac = DiracOp(sample, 0.15)
     rhs = Field(DIMS, g["gcr_rhs"])
@@ -143,7 +184,17 @@ def test_gcr_history_vs_reference(sample, sample_oracle, sample_gold, tag, kw, i
     ref, sens, rng = orc.gcr_reorder_sensitivity(orc.dirac(sample_oracle, 0.15), orc.gcr_param(**_okw(kw)), g["gcr_rhs"])
     assert np.array_equal(ref[1:], g[tag + "_hist"][1:])  # the oracle IS the reference here
     assert its_close(gcr.last_iterations, iters, rng)
-    hist_close(gcr.last_history, g[tag + "_hist"], tag, sens)
+    hist_close(gcr.last_history, g[tag + "_hist"], tag, sens, path=solver_path)
+    if tag in ("g3_restart5", "g4_restart2"):
+        # The headline goldens additionally under a FIXED bound and +-1 iteration.  G3 (restart 5): SURVEY.md §8(c)'s own
+        # bound, 1e-9 relative while h_ref >= 1e-9 and 1e-6 below (observed: 1.1e-11 / 5.5e-9, tests/golden/observed_r02.json).
+        # G4 (restart 2) cannot meet it with ANY parallel sum: the reference's own history moves by up to 2e-4 relative at
+        # step 112 when its dot products are merely summed in reverse or pairwise order (`sens`); observed here 9.5e-9 while
+        # h_ref >= 1e-9 (first above 1e-9 at step 69) and 2.0e-5 below.  Its fixed bound is therefore 1e-7 / 1e-4.
+        hi, lo = (1e-9, 1e-6) if tag == "g3_restart5" else (1e-7, 1e-4)
+        ok, k = fixed_bound_ok(gcr.last_history, g[tag + "_hist"], hi, lo)
+        assert ok, "%s: fixed bound broken at step %s" % (tag, k)
+        assert abs(gcr.last_iterations - iters) <= 1
     x_close(x, dirac, rhs, gcr, g[tag + "_x"] if gcr.last_iterations == iters else None, sens)
 
 
@@ -210,7 +261,7 @@ def test_precond_hooks_literal(sample, sample_gold):
     hist_close(gcr.last_history, g["g11_left_neumann_hist"], "left precond")
 
 
-def test_poisson_goldens(poisson_gold):
+def test_poisson_goldens(poisson_gold, solver_path):
     g = poisson_gold
     for n, kw, tag in [(32, dict(re=5, max_it=10, tau=1e-13), "p32"),
                        (8, dict(trunc=4, max_it=300, tau=1e-10), "p8_trunc4"),
@@ -229,11 +280,15 @@ def test_poisson_goldens(poisson_gold):
                                                       problems.rhs_grid(N, 0))
         assert np.array_equal(oref[1:], ref[1:])
         assert its_close(gcr.last_iterations, ref.size - 1, rng), (tag, gcr.last_iterations, ref.size - 1, rng)
-        hist_close(gcr.last_history, ref, tag, sens)
+        hist_close(gcr.last_history, ref, tag, sens, path=solver_path)
+        if tag == "p32":
+            ok, k = fixed_bound_ok(gcr.last_history, ref)
+            assert ok, "%s: fixed bound broken at step %s" % (tag, k)
+            assert gcr.last_iterations == ref.size - 1
         x_close(x, A, rhs, gcr, g.get(tag + "_x") if gcr.last_iterations == ref.size - 1 else None, sens)
 
 
-def test_poisson128_first_steps_vs_reference(poisson_gold):
+def test_poisson128_first_steps_vs_reference(poisson_gold, solver_path):
     """BASELINE config 2 matrix: first 10 steps against the real reference run on the same RHS."""
     n = 128
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
@@ -243,7 +298,9 @@ def test_poisson128_first_steps_vs_reference(poisson_gold):
     x = Field((n, n, n)).set_zero()
     gcr = GCR(A, GCR_Param(0, 5, 10, 1e-13, False))
     gcr.solve(rhs, x)
-    hist_close(gcr.last_history, poisson_gold["p128_hist"], "poisson128")
+    hist_close(gcr.last_history, poisson_gold["p128_hist"], "p128", path=solver_path)
+    ok, k = fixed_bound_ok(gcr.last_history, poisson_gold["p128_hist"])
+    assert ok, "p128: fixed bound (SURVEY 8(c)) broken at step %s" % k
     # size-independent property: the recurrence residual equals the true residual b - A x
     r = rhs - A(x)
     assert abs(r.norm() / rhs.norm() - gcr.last_history[-1]) <= 1e-10 * gcr.last_history[-1]
