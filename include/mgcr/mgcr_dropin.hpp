@@ -312,6 +312,34 @@ public:
     void mod_VAL_at(num_type l, std::complex<double> v) const { VAL[l] = v; dirty = true; }
     Field<num_type> operator()(Field<num_type> const &f) override { return this->apply_handle(f, handle(), nrow); }
     Sparse &operator=(const Sparse &m) noexcept { if (this != &m) { drop(); std::free(ROW); std::free(COL); std::free(VAL); copy_from(m); } return *this; }
+    // Set-up-time algebra on the host arrays, like the reference's.  dagger (:296-328): conjugate transpose in place;
+    // a new row's entries keep the order of the old rows.  operator*(complex) (:535-544).  operator+ / operator-
+    // (:404-534) are NOT provided: their merge loops read COL[] one entry past the end of either matrix while the
+    // other still has entries, so what they return depends on memory the matrices do not own.
+    void dagger() {
+        const num_type nnz = get_nnz(), ncol = this->dim;
+        auto *NR = (num_type *)std::calloc((size_t)(ncol + 1), sizeof(num_type));
+        auto *NC = (num_type *)std::malloc(sizeof(num_type) * (size_t)(nnz ? nnz : 1));
+        auto *NV = (std::complex<double> *)std::malloc(sizeof(std::complex<double>) * (size_t)(nnz ? nnz : 1));
+        for (num_type l = 0; l < nnz; l++) NR[COL[l] + 1]++;
+        for (num_type c = 0; c < ncol; c++) NR[c + 1] += NR[c];
+        std::vector<num_type> fill(NR, NR + ncol);
+        for (num_type r = 0; r < nrow; r++)
+            for (num_type l = ROW[r]; l < ROW[r + 1]; l++) {
+                const num_type at = fill[(size_t)COL[l]]++;
+                NC[at] = r;
+                NV[at] = std::conj(VAL[l]);
+            }
+        std::free(ROW); std::free(COL); std::free(VAL);
+        ROW = NR; COL = NC; VAL = NV;
+        this->dim = nrow; nrow = ncol;
+        dirty = true;
+    }
+    Sparse operator*(std::complex<double> a) const {
+        Sparse out(*this);
+        for (num_type i = 0; i < get_nnz(); i++) out.VAL[i] = VAL[i] * a;
+        return out;
+    }
     mgcr_op_t handle() override {
         if (!op || dirty) {
             drop();
@@ -385,6 +413,32 @@ public:
     ~Dense() override { if (op) mgcr_op_destroy(op); }
     std::complex<double> val_at(num_type location) const override { return mat[(size_t)location]; }
     std::complex<double> val_at(num_type row, num_type col) const override { return mat[(size_t)(row * this->dim + col)]; }
+    // Set-up-time algebra (:139-190).  operator+ adds all d*d entries; the reference hands `d` to vec_add (:144), so
+    // only the first row of ITS sum is computed and the rest is uninitialised memory.  operator* sums over k in index
+    // order (mat_mult, src/utils.cpp:70-81); dagger = conjugate transpose (mat_dagger :84-90).
+    Dense operator+(const Dense &B) const {
+        Dense out(*this);
+        for (size_t e = 0; e < mat.size(); e++) out.mat[e] = mat[e] + B.mat[e];
+        return out;
+    }
+    Dense operator*(const Dense &B) const {
+        const size_t d = (size_t)this->dim;
+        Dense out(*this);
+        for (size_t i = 0; i < d; i++)
+            for (size_t j = 0; j < d; j++) {
+                std::complex<double> sum(0., 0.);
+                for (size_t k = 0; k < d; k++) sum += mat[i * d + k] * B.mat[k * d + j];
+                out.mat[i * d + j] = sum;
+            }
+        return out;
+    }
+    Dense dagger() const {
+        const size_t d = (size_t)this->dim;
+        Dense out(*this);
+        for (size_t i = 0; i < d; i++)
+            for (size_t j = 0; j < d; j++) out.mat[j * d + i] = std::conj(mat[i * d + j]);
+        return out;
+    }
     Field<num_type> operator()(const Field<num_type> &f) override {
         if (!op) {
             mgcr_detail::ensure_init();
@@ -646,7 +700,10 @@ private:
         return p;
     }
     // Arnoldi::solve :90-122 — inverse iteration for the smallest modes, Gram-Schmidt between them.
-    // The start vector is init_rand(9) as in the reference; each solve starts from x0 = 0.
+    // The start vector is init_rand(9) as in the reference, and the first vector follows the reference's literal loop
+    // gcr.solve(b, b): rhs and x are one Field, i.e. x0 = b with r0 = b (src/GCR.h:189) — pinned against the real
+    // reference in tests/test_gpu_mg.py::test_arnoldi_vs_reference.  The later vectors are solved from x0 = 0: the
+    // reference solves them into a malloc'ed, never initialised Field (:110), which has no defined value.
     std::vector<Field<num_type>> near_null(Operator<num_type> *M) {
         GCR_Param<num_type> gp = *param->eigenvector_precomp_param;
         gp.verbose = false;
@@ -654,7 +711,7 @@ private:
         Field<num_type> b(param->mesh), x(param->mesh);
         b.init_rand(9);
         std::printf("Computing smallest eigenvector 0\n");
-        for (int i = 0; i < 10; i++) { x.set_zero(); gcr.solve(b, x); b = x; b.normalise(); }
+        for (int i = 0; i < 10; i++) { x = b; gcr.solve(b, x); b = x; b.normalise(); }
         std::vector<Field<num_type>> v;
         v.push_back(b);
         for (int c = 1; c < param->n_eigen; c++) {

@@ -200,7 +200,9 @@ class Operator:
 
 
 class Sparse(Operator):
-    """Sparse<long> (src/Operator.h:56-101): CSR with int64 indices on the host side."""
+    """Sparse<long> (src/Operator.h:56-101): CSR with int64 indices on the host side.  The host arrays are kept (the
+    reference's get_ROW / get_COL / val_at accessors and its set-up-time algebra work on them); the device copy is what
+    operator() uses."""
 
     def __init__(self, rows, cols, rowptr, col, val):
         super().__init__()
@@ -214,9 +216,46 @@ class Sparse(Operator):
         check(_lib.lib().mgcr_csr_create(rows, cols, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, C.byref(h)))
         self.h = h
         self._nnz = int(rowptr[-1])
+        self._shape = (int(rows), int(cols))
+        self.ROW, self.COL, self.VAL = rowptr, col, val
+
+    @classmethod
+    def from_triplets(cls, rows, cols, trip_rows, trip_cols, trip_vals):
+        """Sparse(rows, cols, triplets, n) (src/Operator.h:250-294): unordered triplets, duplicates summed."""
+        from . import hostalg
+        return cls(rows, cols, *hostalg.csr_from_triplets(rows, cols, trip_rows, trip_cols, trip_vals))
 
     def get_nnz(self):  # src/Operator.h:73
         return self._nnz
+
+    def get_ROW(self, l):  # src/Operator.h:78-79
+        return int(self.ROW[l])
+
+    def get_COL(self, l):
+        return int(self.COL[l])
+
+    def val_at(self, row, col=None):  # src/Operator.h:392-402
+        if col is None:
+            return complex(self.VAL[row])
+        for l in range(self.ROW[row], self.ROW[row + 1]):
+            if self.COL[l] == col:
+                return complex(self.VAL[l])
+        return 0j
+
+    def dagger(self):
+        """void Sparse::dagger() (src/Operator.h:296-328): conjugate transpose IN PLACE (rows and columns swap)."""
+        from . import hostalg
+        nr, nc, rp, ci, va = hostalg.csr_dagger(self._shape[0], self._shape[1], self.ROW, self.COL, self.VAL)
+        new = Sparse(nr, nc, rp, ci, va)
+        _lib.lib().mgcr_op_destroy(self.h)
+        self.h, new.h = new.h, None
+        self._shape, self.ROW, self.COL, self.VAL = new._shape, new.ROW, new.COL, new.VAL
+        return self
+
+    def __mul__(self, a):
+        """Sparse operator*(complex) (src/Operator.h:535-544): a new Sparse with every value scaled."""
+        from . import hostalg
+        return Sparse(self._shape[0], self._shape[1], self.ROW, self.COL, hostalg.csr_scale(self.VAL, a))
 
 
 class DiracOp(Operator):
@@ -265,6 +304,23 @@ class Dense(HierarchicalSparse):
         if dim * dim != m.size:
             raise MgcrError(1, "Dense: matrix must hold dim*dim entries")
         super().__init__(1, 1, [0], [0], m.reshape(1, dim, dim))
+        self.mat = m.reshape(dim, dim).copy()
+
+    def val_at(self, row, col=None):  # src/Operator.h:45-46
+        return complex(self.mat.reshape(-1)[row] if col is None else self.mat[row, col])
+
+    # set-up-time algebra (src/Operator.h:139-190), on the host like the reference's
+    def __add__(self, other):
+        from . import hostalg
+        return Dense(hostalg.dense_add(self.mat, other.mat))
+
+    def __mul__(self, other):
+        from . import hostalg
+        return Dense(hostalg.dense_mul(self.mat, other.mat))
+
+    def dagger(self):
+        from . import hostalg
+        return Dense(hostalg.dense_dagger(self.mat))
 
 
 class GCR_Param:
@@ -462,11 +518,16 @@ class MG(Operator):
         if M is not None:
             self.initialise(M)
 
-    def near_null_vectors(self, M):
+    def near_null_vectors(self, M, start=None, alias_rhs_x=True, double=True):
         """Arnoldi::solve (src/MG.h:90-122): inverse iteration with GCR for the smallest modes,
         Gram-Schmidt between them, then chirality doubling when the mesh has a spinor dimension.
-        The start vector is the repo's deterministic RHS (seed 9) instead of libc rand(), and each
-        inverse-iteration solve starts from x0 = 0 (the reference aliases rhs and x there)."""
+        The start vector is the repo's deterministic RHS (seed 9) instead of libc rand() unless `start` is given (the
+        reference's is init_rand(9)).  `alias_rhs_x` (default, the reference's literal first loop): gcr.solve(b, b) —
+        rhs and x are ONE Field, i.e. x0 = b while r0 = b (src/GCR.h:189), so each of the ten steps is
+        b <- normalise(b + GCR(b)); False: each solve starts from x0 = 0, b <- normalise(GCR(b)).
+        The later vectors are solved from x0 = 0 either way: the reference solves
+        them into a malloc'ed, never initialised Field (src/MG.h:110, src/Fields.h:97-101), which has no defined value
+        (tests/test_gpu_mg.py::test_arnoldi_vs_reference)."""
         prm = self.param
         dims = prm.mesh.dims
         gp = prm.eigenvector_precomp_param
@@ -479,10 +540,13 @@ class MG(Operator):
         def gnormalise(f):
             return f * (1.0 / np.sqrt(gdot(f, f).real)) if comm is not None else f.normalise()
 
-        b = Field(dims).fill_rhs(9, global_offset=getattr(M, "row0", 0))
+        b = Field(dims).fill_rhs(9, global_offset=getattr(M, "row0", 0)) if start is None else Field(dims, start)
         x = Field(dims)
         for _ in range(10):
-            x.set_zero()
+            if alias_rhs_x:
+                x.assign(b)
+            else:
+                x.set_zero()
             gcr.solve(b, x)
             b = gnormalise(b.assign(x))
         vecs = [b.copy()]
@@ -493,7 +557,7 @@ class MG(Operator):
             for v in vecs:       # Gram-Schmidt against the vectors found so far (src/MG.h:112-118), Field algebra on the device
                 t = t - v * gdot(v, t)
             vecs.append(gnormalise(t))
-        if any(prm.spinor):
+        if double and any(prm.spinor):
             vecs = _vec_double_fields(vecs, prm.spinor.index(True))
         return np.array([v.to_numpy() for v in vecs])
 

@@ -32,20 +32,11 @@ def parse_data(file_loc, out_path):
         data = np.loadtxt(f, ndmin=2)
     if data.shape[0] != elements:
         raise ValueError("expected %d triplets, found %d" % (elements, data.shape[0]))
-    r = data[:, 0].astype(np.int64) - 1
-    c = data[:, 1].astype(np.int64) - 1
-    v = data[:, 2] + 1j * data[:, 3]
-    key = r * cols + c
-    order = np.argsort(key, kind="stable")
-    key, v = key[order], v[order]
-    uniq, start = np.unique(key, return_index=True)
-    vals = np.add.reduceat(v, start)  # duplicates summed in sorted order
-    rr, cc = uniq // cols, uniq % cols
-    rowptr = np.zeros(rows + 1, np.int64)
-    np.add.at(rowptr, rr + 1, 1)
-    np.cumsum(rowptr, out=rowptr)
+    from .hostalg import csr_from_triplets
+    rowptr, cc, vals = csr_from_triplets(rows, cols, data[:, 0].astype(np.int64) - 1, data[:, 1].astype(np.int64) - 1,
+                                         data[:, 2] + 1j * data[:, 3])
     with open(out_path, "w") as f:
-        f.write("%d %d %d\n" % (rows, cols, uniq.size))
+        f.write("%d %d %d\n" % (rows, cols, cc.size))
         f.write(" ".join(str(int(x)) for x in rowptr[:rows]) + " ")
         for j, z in zip(cc, vals):
             f.write("\n%d (%s,%s)" % (j, _g6(z.real), _g6(z.imag)))

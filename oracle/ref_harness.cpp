@@ -347,9 +347,118 @@ static void case_mg() {
     delete mg; delete solver_coarse; delete solver_smooth; delete Dirac; delete D;
 }
 
+
+// ---- round 2 pins: the input builders, Arnoldi, and the well-defined part of the operator algebra -------------------
+
+// G12: Sparse from shuffled triplets with duplicated (row, col) pairs (src/Operator.h:250-294).  The constructor
+// assumes that the first sorted triplet sits in row 0 and that no row is empty; duplicates come in PAIRS only
+// (std::sort is not stable: with three or more equal keys the order of the additions, hence the rounding, would be
+// unspecified).
+static void case_builders(const std::string &mtx_path) {
+    const long rows = 9, cols = 7;
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> U(-1., 1.);
+    typedef std::pair<cplx, std::pair<long, long>> Trip;
+    std::vector<Trip> t;
+    for (long r = 0; r < rows; r++) {
+        int len = 1 + (int)(rng() % 4);
+        std::vector<long> cs;
+        while ((int)cs.size() < len) { long c = (long)(rng() % cols); if (std::find(cs.begin(), cs.end(), c) == cs.end()) cs.push_back(c); }
+        for (long c : cs) t.push_back(Trip(cplx(U(rng), U(rng)), {r, c}));
+        if (r % 3 == 1) t.push_back(Trip(cplx(U(rng), U(rng)), {r, cs[0]}));   // one duplicated pair in this row
+    }
+    std::shuffle(t.begin(), t.end(), rng);
+    std::vector<long> tr, tc; std::vector<cplx> tv;
+    for (auto &e : t) { tr.push_back(e.second.first); tc.push_back(e.second.second); tv.push_back(e.first); }
+    dump_vec("g12_trip_rows", tr); dump_vec("g12_trip_cols", tc); dump_vec("g12_trip_vals", tv);
+    Sparse<long> S(rows, cols, t.data(), (long)t.size());
+    long nnz = S.get_nnz();
+    std::vector<long> R(rows + 1), C(nnz); std::vector<cplx> V(nnz);
+    for (long r = 0; r <= rows; r++) R[r] = S.get_ROW(r);
+    for (long l = 0; l < nnz; l++) { C[l] = S.get_COL(l); V[l] = S.val_at(l); }
+    long meta[3] = {rows, cols, nnz};
+    dump("g12_meta", meta, sizeof(meta));
+    dump_vec("g12_ROW", R); dump_vec("g12_COL", C); dump_vec("g12_VAL", V);
+
+    // G15 (algebra on the same matrix): dagger (src/Operator.h:296-328) and * scalar (:535-544)
+    {
+        Sparse<long> T(S);
+        T.dagger();
+        long tn = T.get_nnz();
+        std::vector<long> TR(T.get_nrow() + 1), TC(tn); std::vector<cplx> TV(tn);
+        for (long r = 0; r <= T.get_nrow(); r++) TR[r] = T.get_ROW(r);
+        for (long l = 0; l < tn; l++) { TC[l] = T.get_COL(l); TV[l] = T.val_at(l); }
+        long tm[3] = {T.get_nrow(), T.get_dim(), tn};
+        dump("g15_dagger_meta", tm, sizeof(tm));
+        dump_vec("g15_dagger_ROW", TR); dump_vec("g15_dagger_COL", TC); dump_vec("g15_dagger_VAL", TV);
+        cplx a(0.3, -1.1);
+        Sparse<long> M = S * a;
+        std::vector<cplx> MV(nnz);
+        for (long l = 0; l < nnz; l++) MV[l] = M.val_at(l);
+        dump_vec("g15_scaled_VAL", MV);
+        cplx av[1] = {a};
+        dump("g15_scalar", av, sizeof(av));
+    }
+    // Dense algebra (src/Operator.h:139-190).  operator+ passes `d`, not d*d, to vec_add (:144): only the first d
+    // entries (the first row) of A + B are computed, the rest of the result is uninitialised memory — the golden
+    // holds the first row only.
+    {
+        const long d = 5;
+        std::vector<cplx> A(d * d), B(d * d);
+        for (auto &v : A) v = cplx(U(rng), U(rng));
+        for (auto &v : B) v = cplx(U(rng), U(rng));
+        dump_vec("g15_dense_A", A); dump_vec("g15_dense_B", B);
+        Dense<long> DA(A.data(), d), DB(B.data(), d);
+        Dense<long> P = DA * DB, H = DA.dagger(), Sum = DA + DB;
+        std::vector<cplx> vp(d * d), vh(d * d), vs(d);
+        for (long e = 0; e < d * d; e++) { vp[e] = P.val_at(e); vh[e] = H.val_at(e); }
+        for (long e = 0; e < d; e++) vs[e] = Sum.val_at(e);
+        dump_vec("g15_dense_AB", vp); dump_vec("g15_dense_Adag", vh); dump_vec("g15_dense_sum_row0", vs);
+    }
+
+    // G13: parse_data (src/Parse.cpp:9-61): MatrixMarket "row col re im" (1-based, % comments) -> the text CSR format
+    // of read_data.  It writes "../../data/sample_matrix/parsed.txt" relative to the cwd: make_golden.py runs this case
+    // from a scratch directory two levels below a scratch root that holds data/sample_matrix/, never inside the reference.
+    if (!mtx_path.empty()) parse_data(mtx_path);
+}
+
+// G14: Arnoldi (src/MG.h:90-122) on the 4x4 sample, k = 0.1, GCR_Param(0,10,10,1e-8): the start vector init_rand(9),
+// the first vector — gcr.solve(b, b) ALIASES rhs and x, i.e. x0 = b with r0 = b (src/GCR.h:189): b <- normalise(b + GCR_10(b)),
+// ten times — and the second vector in its only well-defined form: the reference solves into `Field tmp(mesh)`, which is
+// malloc'ed and never initialised (src/MG.h:110, src/Fields.h:97-101), so its own second vector depends on heap contents;
+// here tmp is zeroed first, everything else is the reference's code.
+static void case_arnoldi() {
+    long dims[6] = {4, 4, 4, 4, 4, 3};
+    Mesh<long> mesh(dims, 6);
+    auto D = new Sparse<long>(read_data("4x4parsed.txt"));
+    auto Dirac = new DiracOp<long>(D, cplx(0.1, 0.));
+    GCR_Param<long> eigen(0, 10, 10, 1e-8, false, nullptr, nullptr);
+    Field<long> b(mesh);
+    b.init_rand(9);
+    dump_field("g14_start", b);
+    GCR<long> gcr(Dirac, &eigen);
+    for (int i = 0; i < 10; i++) { gcr.solve(b, b); b.normalise(); }
+    dump_field("g14_vec0", b);
+    {   // the reference's own Arnoldi must give the same first vector, bit for bit
+        auto ev = new Field<long>[1];
+        Arnoldi<long> ar(&eigen, 1);
+        ar.solve(Dirac, ev, mesh);
+        for (long i = 0; i < b.field_size(); i++) assert(ev[0].val_at(i) == b.val_at(i));
+        delete[] ev;
+    }
+    Field<long> tmp(mesh);
+    tmp.set_zero();
+    gcr.solve(b, tmp);
+    cplx h = b.dot(tmp);
+    tmp -= b * h;
+    tmp.normalise();
+    dump_field("g14_vec1_x0zero", tmp);
+    delete Dirac; delete D;
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s <outdir> sample|hsparse|mg|poisson <n> <iters> <tag> [trunc restart tol]|bench <n> <iters>\n", argv[0]);
+        fprintf(stderr, "usage: %s <outdir> sample|hsparse|mg|arnoldi|builders [file.mtx]|poisson <n> <iters> <tag> [trunc restart tol]|bench <n> <iters>\n", argv[0]);
         return 1;
     }
     char absout[4096];
@@ -357,7 +466,7 @@ int main(int argc, char **argv) {
     g_out = absout;
     std::string c = argv[2];
     // read_data() opens "../../data/sample_matrix/<name>" relative to the cwd (src/Parse.cpp:66)
-    if (c == "sample" || c == "mg") {
+    if (c == "sample" || c == "mg" || c == "arnoldi") {
         const char *root = getenv("MGCR_REFERENCE_ROOT");
         std::string d = std::string(root ? root : "/root/reference") + "/data/sample_matrix";
         if (chdir(d.c_str()) != 0) { fprintf(stderr, "cannot chdir to %s\n", d.c_str()); return 1; }
@@ -365,6 +474,8 @@ int main(int argc, char **argv) {
     if (c == "sample") case_sample();
     else if (c == "hsparse") case_hsparse();
     else if (c == "mg") case_mg();
+    else if (c == "arnoldi") case_arnoldi();
+    else if (c == "builders") case_builders(argc >= 4 ? argv[3] : "");
     else if (c == "poisson" && argc >= 9) case_poisson(atol(argv[3]), atoi(argv[4]), argv[5], false, atoi(argv[6]), atoi(argv[7]), atof(argv[8]));
     else if (c == "poisson" && argc >= 6) case_poisson(atol(argv[3]), atoi(argv[4]), argv[5], false);
     else if (c == "bench" && argc >= 5) case_poisson(atol(argv[3]), atoi(argv[4]), "bench", true);

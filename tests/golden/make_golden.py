@@ -108,6 +108,48 @@ def main():
             pois["p128_hist"] = d(out, "p128_hist")
         np.savez_compressed(os.path.join(HERE, "poisson.npz"), **pois)
 
+        # round 2: input builders, Arnoldi, operator algebra (oracle/ref_harness.cpp G12-G15)
+        # parse_data writes ../../data/sample_matrix/parsed.txt relative to the cwd: give it a scratch tree
+        scratch = tempfile.mkdtemp(prefix="mgcr_parse_")
+        os.makedirs(os.path.join(scratch, "data", "sample_matrix"))
+        cwd = os.path.join(scratch, "a", "b")
+        os.makedirs(cwd)
+        rng = np.random.default_rng(2024)
+        n = 12
+        lines = ["%%MatrixMarket matrix coordinate complex general", "% 12 x 12 test matrix for parse_data (src/Parse.cpp:9-61)"]
+        ents = []
+        for r in range(n):
+            cs = rng.choice(n, size=int(rng.integers(1, 5)), replace=False)
+            for cc in cs:
+                mag = 10.0 ** rng.integers(-6, 4)
+                ents.append((r + 1, int(cc) + 1, float(rng.uniform(-1, 1) * mag), float(rng.uniform(-1, 1) * mag)))
+            if r % 4 == 2:   # a duplicated pair: summed by the triplet constructor
+                ents.append((r + 1, int(cs[0]) + 1, 0.5, -0.25))
+        ents[0] = (ents[0][0], ents[0][1], 2.0, 0.0)          # an integer-valued entry
+        order = rng.permutation(len(ents))
+        lines.append("%d %d %d" % (n, n, len(ents)))
+        for i in order:
+            lines.append("%d %d %.17g %.17g" % ents[i])
+        mtx_text = "\n".join(lines) + "\n"
+        mtx = os.path.join(scratch, "in.mtx")
+        open(mtx, "w").write(mtx_text)
+        subprocess.run([HARNESS, out, "builders", mtx], check=True, capture_output=True, text=True, cwd=cwd)
+        parsed_text = open(os.path.join(scratch, "data", "sample_matrix", "parsed.txt")).read()
+        shutil.rmtree(scratch, ignore_errors=True)
+        L = lambda name: d(out, name, np.int64)  # noqa: E731
+        np.savez_compressed(
+            os.path.join(HERE, "builders.npz"),
+            trip_rows=L("g12_trip_rows"), trip_cols=L("g12_trip_cols"), trip_vals=c(out, "g12_trip_vals"),
+            meta=L("g12_meta"), ROW=L("g12_ROW"), COL=L("g12_COL"), VAL=c(out, "g12_VAL"),
+            dagger_meta=L("g15_dagger_meta"), dagger_ROW=L("g15_dagger_ROW"), dagger_COL=L("g15_dagger_COL"),
+            dagger_VAL=c(out, "g15_dagger_VAL"), scalar=c(out, "g15_scalar"), scaled_VAL=c(out, "g15_scaled_VAL"),
+            dense_A=c(out, "g15_dense_A"), dense_B=c(out, "g15_dense_B"), dense_AB=c(out, "g15_dense_AB"),
+            dense_Adag=c(out, "g15_dense_Adag"), dense_sum_row0=c(out, "g15_dense_sum_row0"),
+            mtx_text=np.frombuffer(mtx_text.encode(), np.uint8), parsed_text=np.frombuffer(parsed_text.encode(), np.uint8))
+        run(out, "arnoldi")
+        np.savez_compressed(os.path.join(HERE, "arnoldi_4x4.npz"), k=0.1, start=c(out, "g14_start"), vec0=c(out, "g14_vec0"),
+                            vec1_x0zero=c(out, "g14_vec1_x0zero"))
+
         src = os.path.join(REF, "data", "sample_matrix", "4x4parsed.txt")
         with open(src, "rb") as fi, gzip.GzipFile(
                 os.path.join(HERE, "4x4parsed.txt.gz"), "wb", mtime=0) as fo:

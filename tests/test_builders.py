@@ -1,0 +1,132 @@
+"""The input builders and the set-up-time operator algebra either side of the hot path
+against outputs of the REAL reference (tests/golden/builders.npz, oracle/ref_harness.cpp `builders`, G12/G13/G15):
+Sparse from shuffled triplets with duplicated pairs (src/Operator.h:250-294), parse_data (src/Parse.cpp:9-61),
+Sparse::dagger and * scalar (:296-328, :535-544), Dense + * dagger (:139-190).  Host code in both mirrors: the numpy
+one (mgpreconditionedgcr_amd/hostalg.py) and the C++ one (include/mgcr/mgcr_dropin.hpp via examples/builders_check) are
+checked here without a GPU; the classes that upload the results are checked in the gpu-marked test at the end."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mgpreconditionedgcr_amd import hostalg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "builders.npz")))
+
+
+def test_triplet_constructor_matches_reference(gold):
+    g = gold
+    rows, cols, nnz = (int(v) for v in g["meta"])
+    assert g["trip_rows"].size > nnz          # the input really holds duplicated (row, col) pairs
+    rowptr, col, val = hostalg.csr_from_triplets(rows, cols, g["trip_rows"], g["trip_cols"], g["trip_vals"])
+    assert np.array_equal(rowptr, g["ROW"]) and np.array_equal(col, g["COL"])
+    assert np.array_equal(val, g["VAL"])      # bit for bit: duplicates come in pairs, a + b == b + a
+
+
+def test_triplet_constructor_generalisations():
+    """What the reference's constructor cannot take: empty rows, no triplet in row 0, no triplets."""
+    rowptr, col, val = hostalg.csr_from_triplets(4, 3, [2, 2, 3], [1, 1, 0], [1.0, 2.0, 5j])
+    assert rowptr.tolist() == [0, 0, 0, 1, 2] and col.tolist() == [1, 0] and val.tolist() == [3.0, 5j]
+    rowptr, col, val = hostalg.csr_from_triplets(2, 2, [], [], [])
+    assert rowptr.tolist() == [0, 0, 0] and col.size == 0
+    with pytest.raises(ValueError):
+        hostalg.csr_from_triplets(2, 2, [2], [0], [1.0])
+
+
+def test_sparse_dagger_and_scale_match_reference(gold):
+    g = gold
+    rows, cols, nnz = (int(v) for v in g["meta"])
+    nr, nc, rp, ci, va = hostalg.csr_dagger(rows, cols, g["ROW"], g["COL"], g["VAL"])
+    assert [nr, nc, rp[-1]] == g["dagger_meta"].tolist()
+    assert np.array_equal(rp, g["dagger_ROW"]) and np.array_equal(ci, g["dagger_COL"]) and np.array_equal(va, g["dagger_VAL"])
+    # twice = identity when every row is sorted by column (the constructor's output is)
+    r2 = hostalg.csr_dagger(nr, nc, rp, ci, va)
+    assert np.array_equal(r2[2], g["ROW"]) and np.array_equal(r2[3], g["COL"]) and np.array_equal(r2[4], g["VAL"])
+    assert np.array_equal(hostalg.csr_scale(g["VAL"], g["scalar"][0]), g["scaled_VAL"])
+
+
+def test_dense_algebra_matches_reference(gold):
+    g = gold
+    d = int(round(np.sqrt(g["dense_A"].size)))
+    A, B = g["dense_A"].reshape(d, d), g["dense_B"].reshape(d, d)
+    assert np.array_equal(hostalg.dense_mul(A, B).ravel(), g["dense_AB"])
+    assert np.array_equal(hostalg.dense_dagger(A).ravel(), g["dense_Adag"])
+    # Dense::operator+ computes only its first row (vec_add gets d, not d*d: src/Operator.h:144); the rest of the
+    # reference's result is uninitialised memory and is not in the golden
+    assert np.array_equal(hostalg.dense_add(A, B)[0], g["dense_sum_row0"])
+
+
+def test_parse_data_matches_reference_text(gold, tmp_path):
+    from mgpreconditionedgcr_amd.experiments import parse_data
+    mtx = tmp_path / "in.mtx"
+    mtx.write_bytes(bytes(gold["mtx_text"]))
+    out = tmp_path / "parsed.txt"
+    parse_data(str(mtx), str(out))
+    assert out.read_text() == bytes(gold["parsed_text"]).decode()    # byte for byte, 6 significant digits included
+
+
+def test_cpp_mirror_matches_reference(gold, tmp_path):
+    """The same through include/mgcr/mgcr_dropin.hpp (host side only, plain g++)."""
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    g = gold
+    d = str(tmp_path)
+    for name, key, dt in (("trip_rows", "trip_rows", np.int64), ("trip_cols", "trip_cols", np.int64), ("trip_vals", "trip_vals", np.complex128),
+                          ("meta", "meta", np.int64), ("scalar", "scalar", np.complex128), ("dense_A", "dense_A", np.complex128),
+                          ("dense_B", "dense_B", np.complex128)):
+        np.asarray(g[key], dt).tofile(os.path.join(d, name + ".bin"))
+    open(os.path.join(d, "in.mtx"), "wb").write(bytes(g["mtx_text"]))
+    p = subprocess.run([os.path.join(ROOT, "examples", "build", "builders_check"), d], capture_output=True, text=True,
+                       env=dict(os.environ, MGCR_SAMPLE_DIR=d), timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rd = lambda n, dt: np.fromfile(os.path.join(d, "out_" + n + ".bin"), dtype=dt)  # noqa: E731
+    assert np.array_equal(rd("csr_ROW", np.int64), g["ROW"]) and np.array_equal(rd("csr_COL", np.int64), g["COL"])
+    assert np.array_equal(rd("csr_VAL", np.complex128), g["VAL"])
+    assert rd("dagger_meta", np.int64).tolist() == g["dagger_meta"].tolist()
+    assert np.array_equal(rd("dagger_ROW", np.int64), g["dagger_ROW"]) and np.array_equal(rd("dagger_COL", np.int64), g["dagger_COL"])
+    assert np.array_equal(rd("dagger_VAL", np.complex128), g["dagger_VAL"])
+    assert np.array_equal(rd("scaled_VAL", np.complex128), g["scaled_VAL"])
+    assert np.array_equal(rd("dense_AB", np.complex128), g["dense_AB"]) and np.array_equal(rd("dense_Adag", np.complex128), g["dense_Adag"])
+    dd = g["dense_sum_row0"].size
+    assert np.array_equal(rd("dense_sum", np.complex128)[:dd], g["dense_sum_row0"])
+    assert open(os.path.join(d, "parsed.txt")).read() == bytes(g["parsed_text"]).decode()
+
+
+@pytest.mark.gpu
+def test_operator_classes_apply_what_the_algebra_built(gold):
+    """Sparse.from_triplets / dagger / * scalar and Dense + * dagger as operators on the device: the applies agree with
+    numpy on the reference's matrices."""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Dense, Field, Sparse, problems
+    mg.init()
+    g = gold
+    rows, cols, nnz = (int(v) for v in g["meta"])
+    S = Sparse.from_triplets(rows, cols, g["trip_rows"], g["trip_cols"], g["trip_vals"])
+    assert S.get_nnz() == nnz and S.get_ROW(rows) == nnz and S.val_at(3) == g["VAL"][3]
+    dense = np.zeros((rows, cols), np.complex128)
+    for r in range(rows):
+        for l in range(g["ROW"][r], g["ROW"][r + 1]):
+            dense[r, g["COL"][l]] += g["VAL"][l]
+    assert S.val_at(2, int(g["COL"][g["ROW"][2]])) == g["VAL"][g["ROW"][2]]
+    x = problems.rhs_grid(cols, 1)
+    assert np.abs(S(Field((cols,), x)).to_numpy() - dense @ x).max() <= 1e-13
+    a = complex(g["scalar"][0])
+    assert np.abs((S * a)(Field((cols,), x)).to_numpy() - (dense * a) @ x).max() <= 1e-13
+    y = problems.rhs_grid(rows, 2)
+    S.dagger()
+    assert S.get_nrow() == cols and S.get_dim() == rows
+    assert np.abs(S(Field((rows,), y)).to_numpy() - dense.conj().T @ y).max() <= 1e-13
+    d = int(round(np.sqrt(g["dense_A"].size)))
+    A, B = Dense(g["dense_A"], d), Dense(g["dense_B"], d)
+    z = problems.rhs_grid(d, 3)
+    An, Bn = g["dense_A"].reshape(d, d), g["dense_B"].reshape(d, d)
+    for op, ref in ((A * B, An @ Bn), (A + B, An + Bn), (A.dagger(), An.conj().T)):
+        assert np.abs(op(Field((d,), z)).to_numpy() - ref @ z).max() <= 1e-13 * np.abs(ref).sum()
+    assert np.array_equal((A * B).mat.ravel(), g["dense_AB"])

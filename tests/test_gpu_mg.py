@@ -388,3 +388,30 @@ def test_config3_full_size_mg_gcr_256():
     lhs = M.restrict(A(M.expand(w)))
     rhs_c = M.level_operator(1)(w)
     assert (lhs - rhs_c).norm() <= 1e-12 * rhs_c.norm()
+
+
+def test_arnoldi_vs_reference(sample_matrix_path):
+    """Arnoldi::solve (src/MG.h:90-122) against the real reference (tests/golden/arnoldi_4x4.npz, oracle/ref_harness.cpp
+    `arnoldi`): 4x4 sample, k = 0.1, GCR_Param(0,10,10,1e-8), start = the reference's init_rand(9).  Vector 0 with the
+    reference's literal aliasing gcr.solve(b, b) (x0 = b, r0 = b), ten times; vector 1 in its only well-defined form,
+    solved from x0 = 0 — the reference solves it into an uninitialised Field (src/MG.h:110), which is why ITS OWN second
+    vector (golden G9 eigvec1) differs from this one by 2e-4 and cannot be a golden."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arnoldi_4x4.npz"))
+    D = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path))
+    dirac = DiracOp(D, float(g["k"]))
+    prm = MG_Param(Mesh(DIMS), 2, 2, GCR_Param(0, 10, 10, 1e-8, False), GCR(GCR_Param(0, 10, 1, 1e-8, False)),
+                   GCR(GCR_Param(0, 10, 1, 1e-8, False)), 1, None, None)
+    vecs = MG(None, prm).near_null_vectors(dirac, start=g["start"], alias_rhs_x=True, double=False)
+    assert vecs.shape == (2, 3072)
+    d0 = np.abs(vecs[0] - g["vec0"]).max() / np.abs(g["vec0"]).max()
+    d1 = np.abs(vecs[1] - g["vec1_x0zero"]).max() / np.abs(g["vec1_x0zero"]).max()
+    print("near-null vectors vs reference: max rel. deviation %.2e (vector 0, 100 aliased GCR steps), %.2e (vector 1)" % (d0, d1))
+    assert d0 <= 1e-10 and d1 <= 1e-10
+    # and what they are for: the hierarchy built from them has the span of the reference's vectors in every aggregate
+    both = vec_double([g["vec0"], g["vec1_x0zero"]], DIMS, 4)
+    ours = vec_double(list(vecs), DIMS, 4)
+    assert np.abs(ours - both).max() <= 1e-10
+    # without the aliasing (x0 = 0) the iteration is b <- normalise(GCR(b)): a different, equally valid
+    # near-null vector — it must NOT be mistaken for the reference's
+    plain = MG(None, prm).near_null_vectors(dirac, start=g["start"], alias_rhs_x=False, double=False)
+    assert np.abs(plain[0] - g["vec0"]).max() > 1e-3
