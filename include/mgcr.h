@@ -253,6 +253,13 @@ int mgcr_plan_destroy(mgcr_plan_t plan);
  * its dot products (2 small all-reduces per iteration).  Collective over `comm`. */
 int mgcr_dcsr_create(mgcr_comm_t comm, int64_t n_global, int64_t row0, int64_t nrow_local, const int64_t *rowptr,
                      const int64_t *col_global, const double *val_ri, mgcr_op_t *out);
+/* Row block of a distributed HierarchicalSparse (reference apply: src/HierarchicalSparse.h:101-161; the reference has no
+ * distribution, SURVEY.md 8(e) "Unstructured (config 5)"): block rows [brow0, brow0 + nbrow_local) of nb_global, block
+ * columns GLOBAL, blocks [nblocks][bs][bs] row-major interleaved (re, im), duplicates of a (row, col) pair kept and
+ * summed at apply time like the single-GPU operator.  The halo travels at block granularity (bs values per needed block
+ * row of x) and the block kernel reads it in place.  Fields hold this rank's nbrow_local * bs entries.  Collective. */
+int mgcr_dbcsr_create(mgcr_comm_t comm, int64_t nb_global, int64_t brow0, int32_t nbrow_local, int32_t bs, const int32_t *browptr,
+                      const int64_t *bcol_global, const double *blocks_ri, mgcr_op_t *out);
 
 /* ---- measurement helpers (bench.py) ------------------------------------------------------- */
 /* runs `reps` applies back to back on the library stream, bracketed by hipEvents there;

@@ -109,6 +109,7 @@ _SIGS = {
     "mgcr_plan_halo_globals": (C.c_int, [_vp, _vp]),
     "mgcr_plan_destroy": (C.c_int, [_vp]),
     "mgcr_dcsr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "mgcr_dbcsr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp, C.POINTER(_vp)]),
     "mgcr_set_small_solve_rows": (C.c_int, [C.c_int64]),
     "mgcr_gcr_last_profile": (C.c_int, [_dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mgcr_bench_op_apply": (C.c_int, [_vp, _vp, _vp, C.c_int32, _dp]),

@@ -103,7 +103,7 @@ int mgcr_op_destroy(mgcr_op_t op) {
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     switch (op->kind) {
         case OP_CSR: csr_free(&op->csr); dist_free(op->dist); break;
-        case OP_BCSR: bcsr_free(&op->bcsr); break;
+        case OP_BCSR: bcsr_free(&op->bcsr); dist_free(op->dist); break;
         case OP_GCR: gcr_state_destroy(op->gcr); break;
         case OP_MG: mg_destroy(op->mg); break;
         default: break;  // OP_DIRAC borrows its Sparse (src/Operator.h:117,555-560)

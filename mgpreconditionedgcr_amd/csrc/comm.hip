@@ -946,18 +946,14 @@ int comm_check_all() {
 int dist_halo_kind(DistCsr *d) { return d->pw_on ? 2 : d->comm->is_rccl ? 1 : 0; }
 int comm_allreduce_kind(Comm *c) { return c->pw_on ? 2 : c->is_rccl ? 1 : 0; }
 
-int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col,
-                    const double *val_ri, Op *op) {
-    Plan *P = nullptr;
-    MGCR_TRY(plan_build(c, n_global, row0, nloc, rowptr, col, &P));
+// the device side of a partition plan: halo segment, send lists, peer-write receive slots (collective: the peer-write
+// self-tests run here).  Takes ownership of P.
+static int dist_attach(Comm *c, Plan *P, DistCsr **out) {
     DistCsr *d = new DistCsr();
     d->comm = c;
     d->plan = P;
     d->pw_seq = pw_seq0();
     const int64_t nh = (int64_t)P->halo_gid.size();
-    int rc = csr_build_device(nloc, nloc + nh, rowptr, P->col_local.data(), val_ri, &op->csr);
-    if (rc != MGCR_OK) { dist_free(d); return rc; }
-    std::vector<int64_t>().swap(P->col_local);
     const int np = (int)P->peers.size();
     int64_t off = 0;
     std::vector<int32_t> idx;
@@ -977,15 +973,70 @@ int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const
     if (e == hipSuccess && off) e = hipMalloc((void **)&d->send_idx, sizeof(int32_t) * (size_t)off);
     if (e == hipSuccess && off) e = hipMemcpy(d->send_idx, idx.data(), sizeof(int32_t) * (size_t)off, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        csr_free(&op->csr);
         dist_free(d);
-        set_error("dist_csr_create: device allocation failed: %s", hipGetErrorString(e));
+        set_error("distributed operator: device allocation failed: %s", hipGetErrorString(e));
         return MGCR_ERR_ALLOC;
     }
-    rc = comm_device_ready(c);
+    int rc = comm_device_ready(c);
     if (rc == MGCR_OK) rc = comm_pw_setup(c);
     if (rc == MGCR_OK) rc = halo_pw_setup(d);
-    if (rc != MGCR_OK) { csr_free(&op->csr); dist_free(d); return rc; }
+    if (rc != MGCR_OK) { dist_free(d); return rc; }
+    *out = d;
+    return MGCR_OK;
+}
+
+int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col,
+                    const double *val_ri, Op *op) {
+    Plan *P = nullptr;
+    MGCR_TRY(plan_build(c, n_global, row0, nloc, rowptr, col, &P));
+    const int64_t nh = (int64_t)P->halo_gid.size();
+    int rc = csr_build_device(nloc, nloc + nh, rowptr, P->col_local.data(), val_ri, &op->csr);
+    if (rc != MGCR_OK) { delete P; return rc; }
+    std::vector<int64_t>().swap(P->col_local);
+    DistCsr *d = nullptr;
+    rc = dist_attach(c, P, &d);
+    if (rc != MGCR_OK) { csr_free(&op->csr); return rc; }
+    op->dist = d;
+    op->comm = c;
+    return MGCR_OK;
+}
+
+// Row block of a distributed HierarchicalSparse (src/HierarchicalSparse.h:101-161): block rows [brow0, brow0 + nbloc) of
+// nb_global, block columns GLOBAL.  The partition plan is made at BLOCK granularity (a halo entry = one block row of x,
+// bs values) and expanded to the element lists the halo machinery above works on; the apply reads a block column's bs
+// values from x (owned) or in place from the halo segment.
+int dist_bcsr_create(Comm *c, int64_t nb_global, int64_t brow0, int32_t nbloc, int32_t bs, const int32_t *browptr,
+                     const int64_t *bcol_global, const double *blocks_ri, Op *op) {
+    MGCR_CHECK(bs >= 1 && nbloc >= 0 && browptr && browptr[0] == 0, MGCR_ERR_INVALID, "dist_bcsr_create: bad argument");
+    std::vector<int64_t> rp((size_t)nbloc + 1);
+    for (int32_t r = 0; r <= nbloc; r++) rp[(size_t)r] = browptr[r];
+    Plan *B = nullptr;
+    MGCR_TRY(plan_build(c, nb_global, brow0, nbloc, rp.data(), bcol_global, &B));
+    const int64_t nhb = (int64_t)B->halo_gid.size();
+    MGCR_CHECK(((int64_t)nbloc + nhb) * bs < ((int64_t)1 << 31), MGCR_ERR_UNSUPPORTED, "row block too large");
+    std::vector<int32_t> bcol_local((size_t)B->nnz);
+    for (int64_t l = 0; l < B->nnz; l++) bcol_local[(size_t)l] = (int32_t)B->col_local[(size_t)l];
+    int rc = bcsr_build_device(nbloc, (int32_t)(nbloc + nhb), bs, browptr, bcol_local.data(), blocks_ri, &op->bcsr);
+    if (rc != MGCR_OK) { delete B; return rc; }
+    // element-level plan: block b -> elements b*bs .. b*bs + bs - 1, same order
+    Plan *P = new Plan();
+    P->comm = c; P->n_global = nb_global * bs; P->row0 = brow0 * bs; P->nloc = (int64_t)nbloc * bs; P->nnz = 0;
+    for (int64_t o : B->offsets) P->offsets.push_back(o * bs);
+    for (int64_t g : B->halo_gid) for (int32_t k = 0; k < bs; k++) P->halo_gid.push_back(g * bs + k);
+    P->peers = B->peers;
+    for (size_t p = 0; p < B->peers.size(); p++) {
+        P->recv_count.push_back(B->recv_count[p] * bs);
+        P->recv_off.push_back(B->recv_off[p] * bs);
+        std::vector<int64_t> rows;
+        for (int64_t r : B->send_rows[p]) for (int32_t k = 0; k < bs; k++) rows.push_back(r * bs + k);
+        P->send_rows.push_back(rows);
+    }
+    P->interior_begin = B->interior_begin * bs;
+    P->interior_end = B->interior_end * bs;
+    delete B;
+    DistCsr *d = nullptr;
+    rc = dist_attach(c, P, &d);
+    if (rc != MGCR_OK) { bcsr_free(&op->bcsr); return rc; }
     op->dist = d;
     op->comm = c;
     return MGCR_OK;
@@ -1146,6 +1197,22 @@ int mgcr_plan_halo_globals(mgcr_plan_t plan, int64_t *global_cols) {
 
 int mgcr_plan_destroy(mgcr_plan_t plan) {
     delete static_cast<mgcr::Plan *>(plan);
+    return MGCR_OK;
+}
+
+int mgcr_dbcsr_create(mgcr_comm_t comm, int64_t nb_global, int64_t brow0, int32_t nbrow_local, int32_t bs, const int32_t *browptr,
+                      const int64_t *bcol_global, const double *blocks_ri, mgcr_op_t *out) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(comm && out && browptr && (bcol_global || browptr[nbrow_local] == 0) && (blocks_ri || browptr[nbrow_local] == 0),
+               MGCR_ERR_INVALID, "mgcr_dbcsr_create: null argument");
+    LOCK();
+    mgcr_op_s *op = new mgcr_op_s();
+    op->kind = OP_BCSR;
+    op->dim = (int64_t)nbrow_local * bs;      // Fields of a distributed operator hold this rank's rows
+    op->nrow = (int64_t)nbrow_local * bs;
+    int rc = dist_bcsr_create(comm, nb_global, brow0, nbrow_local, bs, browptr, bcol_global, blocks_ri, op);
+    if (rc != MGCR_OK) { delete op; return rc; }
+    *out = op;
     return MGCR_OK;
 }
 

@@ -688,6 +688,12 @@ int op_apply_raw(Op *op, const cplx *x, cplx *y, int64_t n) {
             MGCR_CHECK(op->k.x != 0. || op->k.y != 0., MGCR_ERR_INVALID, "No k value supplied for Dirac Operator!");
             return csr_apply(op->base->csr, x, y, true, op->k, op->base->dist);
         case OP_BCSR:
+            if (op->dist) {   // row block of a distributed HierarchicalSparse: halo exchange, then the blocks read x or the halo segment
+                MGCR_CHECK((int64_t)op->bcsr.nbrow * op->bcsr.bs == n, MGCR_ERR_INVALID, "Sparse matrix dimension does not match Field dimension!");
+                MGCR_TRY(dist_halo_begin(op->dist, x));
+                MGCR_TRY(dist_halo_end(op->dist));
+                return bcsr_apply(op->bcsr, x, y, dist_halo_ptr(op->dist), op->bcsr.nbrow);
+            }
             MGCR_CHECK((int64_t)op->bcsr.nbcol * op->bcsr.bs == n, MGCR_ERR_INVALID,
                        "Sparse matrix dimension does not match Field dimension!");
             return bcsr_apply(op->bcsr, x, y);

@@ -1,6 +1,7 @@
 // Internal declarations of libmgcr_hip.so (gfx950 only; no compatibility layers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -128,7 +129,7 @@ struct Op {
     BcsrDev bcsr;        // OP_BCSR
     GcrState *gcr = nullptr;  // OP_GCR
     MgState *mg = nullptr;    // OP_MG
-    DistCsr *dist = nullptr;  // OP_CSR row block of a distributed matrix (comm.hip)
+    DistCsr *dist = nullptr;  // OP_CSR / OP_BCSR row block of a distributed matrix (comm.hip)
     Comm *comm = nullptr;     // communicator the operator's Fields are distributed over (borrowed)
 };
 
@@ -178,7 +179,8 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
 int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h_browptr, const int32_t *h_bcol,
                       const double *h_blocks, BcsrDev *out);
 void bcsr_free(BcsrDev *b);
-int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y);
+// xh / nb_own: row block of a distributed operator — block columns >= nb_own live in the halo segment xh
+int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y, const cplx *xh = nullptr, int32_t nb_own = INT32_MAX);
 
 // Device-side "this solve is over" predicate consulted by operator-apply kernels that run inside a
 // solver iteration: p points at {stop_at, base} of the solver's DevState (gcr.hip) and the kernel
@@ -204,6 +206,8 @@ int comm_allreduce_host_pub(Comm *c, double *buf, int64_t count);
 int dist_exchange_rows_host(DistCsr *d, const double *own, int w, double *halo);
 int dist_csr_create(Comm *c, int64_t n_global, int64_t row0, int64_t nloc, const int64_t *rowptr, const int64_t *col,
                     const double *val_ri, Op *op);
+int dist_bcsr_create(Comm *c, int64_t nb_global, int64_t brow0, int32_t nbloc, int32_t bs, const int32_t *browptr,
+                     const int64_t *bcol_global, const double *blocks_ri, Op *op);
 int comm_nranks(Comm *c);
 bool comm_collectives(Comm *c);
 int comm_allreduce_dev(Comm *c, double *dbuf, int count);

@@ -145,7 +145,7 @@ void mg_destroy(MgState *m) {
         gcr_state_destroy(L.pre); gcr_state_destroy(L.post); gcr_state_destroy(L.coarse);
         if (L.owns_A && L.A) {
             if (L.A->kind == OP_CSR) { csr_free(&L.A->csr); dist_free(L.A->dist); }
-            if (L.A->kind == OP_BCSR) bcsr_free(&L.A->bcsr);
+            if (L.A->kind == OP_BCSR) { bcsr_free(&L.A->bcsr); dist_free(L.A->dist); }
             delete static_cast<mgcr_op_s *>(L.A);
         }
     }

@@ -11,7 +11,8 @@
 // Distributed operators (row blocks): aggregates are formed inside the local block; the aggregate
 // ids and prolongator rows of the halo columns are fetched once over the SpMV's halo lists
 // (set-up-time host-level exchange), the Galerkin kernels then see owned + halo columns, and the
-// resulting row block of the coarse operator (global column ids) becomes a distributed Sparse.
+// resulting row block of the coarse operator (global column ids) becomes a distributed Sparse (one near-null
+// vector) or a distributed HierarchicalSparse (several: ne x ne blocks).
 #include <algorithm>
 
 #include "internal.h"
@@ -248,7 +249,7 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     hipStream_t st = ctx().stream;
     const Op *base = A->kind == OP_DIRAC ? A->base : A;
     const bool shift = A->kind == OP_DIRAC;
-    DistCsr *dist = base->kind == OP_CSR ? base->dist : nullptr;
+    DistCsr *dist = base->dist;   // row block of a distributed Sparse or HierarchicalSparse
     MeshDesc m;
     m.ndim = ndim; m.sub = sub;
     int64_t n = 1, nagg = 1, S = 1;
@@ -378,34 +379,39 @@ int mg_level_setup_device(Op *A, int ndim, const int64_t *dims, const int32_t *b
     const int64_t nc = nagg * ne;
     Ac->dim = Ac->nrow = nc;
     int rc = MGCR_OK;
-    if (dist) {
-        // this rank's row block [agg_off*ne, (agg_off+nagg)*ne) of the coarse operator, GLOBAL columns;
-        // the partition plan of the new distributed Sparse is host logic, so the blocks make one trip back
+    if (dist && ne > 1) {
+        // this rank's block rows [agg_off, agg_off + nagg) of the coarse operator as a distributed HierarchicalSparse
+        // (block columns GLOBAL).  The partition plan is host logic: the block columns make one trip back, the blocks
+        // themselves too (dist_bcsr_create uploads host arrays)
         std::vector<int32_t> h_bcol((size_t)nblk);
         std::vector<double> h_blk((size_t)nblk * ne * ne * 2);
         MGCR_HIP(hipMemcpy(h_bcol.data(), d_bcol, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
         MGCR_HIP(hipMemcpy(h_blk.data(), d_blocks, sizeof(cplx) * (size_t)nblk * ne * ne, hipMemcpyDeviceToHost));
         hipFree(d_browptr); hipFree(d_bcol); hipFree(d_blocks);
-        std::vector<int64_t> rp((size_t)nc + 1, 0), ci;
-        std::vector<double> va;
-        ci.reserve((size_t)nblk * ne * ne);
-        va.reserve((size_t)nblk * ne * ne * 2);
-        for (int64_t a = 0; a < nagg; a++)
-            for (int kp = 0; kp < ne; kp++) {
-                for (int32_t b = browptr[(size_t)a]; b < browptr[(size_t)a + 1]; b++) {
-                    int64_t ca = h_bcol[(size_t)b];
-                    int64_t gid = ca < nagg ? agg_off + ca : ext_gid[(size_t)(ca - nagg)];
-                    for (int k = 0; k < ne; k++) {
-                        ci.push_back(gid * ne + k);
-                        size_t e = ((size_t)b * ne * ne + (size_t)kp * ne + k) * 2;
-                        va.push_back(h_blk[e]);
-                        va.push_back(h_blk[e + 1]);
-                    }
-                }
-                rp[(size_t)(a * ne + kp) + 1] = (int64_t)ci.size();
-            }
+        std::vector<int64_t> gcol((size_t)nblk);
+        for (int64_t b = 0; b < nblk; b++) {
+            const int64_t ca = h_bcol[(size_t)b];
+            gcol[(size_t)b] = ca < nagg ? agg_off + ca : ext_gid[(size_t)(ca - nagg)];
+        }
+        Ac->kind = OP_BCSR;
+        rc = dist_bcsr_create(comm, nagg_glob, agg_off, (int32_t)nagg, ne, browptr.data(), gcol.data(), h_blk.data(), Ac);
+    } else if (dist) {
+        // ne == 1: this rank's row block [agg_off, agg_off + nagg) of the coarse operator, GLOBAL columns, as a distributed
+        // Sparse (row-pattern / stencil storage then applies to it); the partition plan is host logic, so the entries make
+        // one trip back
+        std::vector<int32_t> h_bcol((size_t)nblk);
+        std::vector<double> h_blk((size_t)nblk * 2);
+        MGCR_HIP(hipMemcpy(h_bcol.data(), d_bcol, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
+        MGCR_HIP(hipMemcpy(h_blk.data(), d_blocks, sizeof(cplx) * (size_t)nblk, hipMemcpyDeviceToHost));
+        hipFree(d_browptr); hipFree(d_bcol); hipFree(d_blocks);
+        std::vector<int64_t> rp((size_t)nc + 1, 0), ci((size_t)nblk);
+        for (int64_t a = 0; a <= nagg; a++) rp[(size_t)a] = browptr[(size_t)a];
+        for (int64_t b = 0; b < nblk; b++) {
+            const int64_t ca = h_bcol[(size_t)b];
+            ci[(size_t)b] = ca < nagg ? agg_off + ca : ext_gid[(size_t)(ca - nagg)];
+        }
         Ac->kind = OP_CSR;
-        rc = dist_csr_create(comm, nagg_glob * ne, agg_off * ne, nc, rp.data(), ci.data(), va.data(), Ac);
+        rc = dist_csr_create(comm, nagg_glob, agg_off, nc, rp.data(), ci.data(), h_blk.data(), Ac);
     } else if (ne == 1) {
         Ac->kind = OP_CSR;
         std::vector<int64_t> rp64(browptr.begin(), browptr.end());

@@ -968,8 +968,8 @@ int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistC
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
                                                        const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
-                                                       const cplx *__restrict__ x, cplx *__restrict__ y,
-                                                       const int *__restrict__ skip, int skip_it) {
+                                                       const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t nb_own,
+                                                       cplx *__restrict__ y, const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
@@ -981,7 +981,8 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs
     cplx acc0 = make_double2(0., 0.), acc1 = make_double2(0., 0.);
     for (int32_t l = beg; l < end; l++) {
         const cplx *m = blocks + (int64_t)l * bs2;
-        const cplx *xb = x + (int64_t)bcol[l] * bs;
+        const int32_t bc = bcol[l];
+        const cplx *xb = bc < nb_own ? x + (int64_t)bc * bs : xh + (int64_t)(bc - nb_own) * bs;
         for (int32_t e = lane; e < bs2; e += 64) {
             int32_t r = e / bs, cc = e - r * bs;
             prod[r * ld + cc] = cmul(m[e], xb[cc]);
@@ -1013,8 +1014,8 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs
 template <int TT, bool PREFETCH>
 __global__ void __launch_bounds__(64) bcsr_wave_kernel_t(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
                                                          const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
-                                                         const cplx *__restrict__ x, cplx *__restrict__ y,
-                                                         const int *__restrict__ skip, int skip_it) {
+                                                         const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t nb_own,
+                                                         cplx *__restrict__ y, const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
@@ -1036,7 +1037,8 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel_t(int32_t nbrow, int32_t 
     cplx mv[TT], xv[TT], mn[TT], xn[TT];
     auto fetch = [&](int32_t l, cplx (&mo)[TT], cplx (&xo)[TT]) {
         const cplx *m = blocks + (int64_t)l * bs2;
-        const cplx *xb = x + (int64_t)bcol[l] * bs;
+        const int32_t bc = bcol[l];
+        const cplx *xb = bc < nb_own ? x + (int64_t)bc * bs : xh + (int64_t)(bc - nb_own) * bs;
 #pragma unroll
         for (int t = 0; t < TT; t++) {
             mo[t] = live[t] ? m[lane + 64 * t] : make_double2(0., 0.);
@@ -1090,7 +1092,7 @@ int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h
     return MGCR_OK;
 }
 
-int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y) {
+int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y, const cplx *xh, int32_t nb_own) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "block SpMV cannot run in place");
     if (A.nbrow == 0) return MGCR_OK;
     size_t lds = sizeof(cplx) * (size_t)A.bs * (size_t)(A.bs + 1);
@@ -1103,10 +1105,10 @@ int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y) {
     const int tt = (A.bs * A.bs + 63) / 64;
 #define BT(T_)                                                                                                              \
     hipLaunchKernelGGL((bcsr_wave_kernel_t<T_, false>), dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr, \
-                       A.bcol, A.blocks, x, y, g_skip.p, g_skip.it)
+                       A.bcol, A.blocks, x, xh, nb_own, y, g_skip.p, g_skip.it)
     if (A.bs > 64 || tt > 16)  // rows beyond lane 63 / too many registers: generic kernel
         hipLaunchKernelGGL(bcsr_wave_kernel, dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr,
-                           A.bcol, A.blocks, x, y, g_skip.p, g_skip.it);
+                           A.bcol, A.blocks, x, xh, nb_own, y, g_skip.p, g_skip.it);
     else if (tt <= 1) BT(1);
     else if (tt <= 2) BT(2);
     else if (tt <= 4) BT(4);

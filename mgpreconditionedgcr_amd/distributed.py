@@ -175,3 +175,40 @@ class DistSparse(Operator):
         k = C.c_int32()
         check(_lib.lib().mgcr_op_halo_kind(self.h, C.byref(k)))
         return ("host", "rccl", "peer-write")[k.value]
+
+
+class DistHierarchicalSparse(Operator):
+    """Block rows [brow0, brow0 + nbrow_local) of a distributed HierarchicalSparse (block-CSR of dense bs x bs blocks,
+    src/HierarchicalSparse.h:22-48,101-161), from this rank's (block_row, block_col, block) triplets: block rows LOCAL
+    (0 .. nbrow_local), block columns GLOBAL; duplicates kept and summed at apply time, triplets sorted stably by
+    (row, col) like the single-GPU constructor.  Fields hold this rank's nbrow_local * bs entries."""
+
+    def __init__(self, comm, nb_global, brow0, nbrow_local, rows_local, cols_global, blocks):
+        super().__init__()
+        _lib.init()
+        rows_local = np.ascontiguousarray(rows_local, np.int64)
+        cols_global = np.ascontiguousarray(cols_global, np.int64)
+        blocks = np.ascontiguousarray(blocks, c128)
+        nt = rows_local.size
+        bs = int(round(np.sqrt(blocks.size // max(nt, 1)))) if nt else 1
+        if nt and bs * bs * nt != blocks.size:
+            raise _lib.MgcrError(1, "blocks must hold ntriplets square blocks")
+        order = np.argsort(rows_local * int(nb_global) + cols_global, kind="stable")
+        browptr = np.zeros(nbrow_local + 1, np.int32)
+        np.add.at(browptr, rows_local + 1, 1)
+        np.cumsum(browptr, out=browptr)
+        bcol = np.ascontiguousarray(cols_global[order])
+        blk = np.ascontiguousarray(blocks.reshape(nt, bs, bs)[order]) if nt else blocks
+        h = C.c_void_p()
+        check(_lib.lib().mgcr_dbcsr_create(comm.h, nb_global, brow0, nbrow_local, bs, browptr.ctypes.data, bcol.ctypes.data,
+                                           blk.ctypes.data, C.byref(h)))
+        self.h = h
+        self._keep.append(comm)
+        self.comm, self.bs = comm, bs
+        self.row0 = int(brow0) * bs
+
+    @property
+    def halo_kind(self):
+        k = C.c_int32()
+        check(_lib.lib().mgcr_op_halo_kind(self.h, C.byref(k)))
+        return ("host", "rccl", "peer-write")[k.value]

@@ -65,6 +65,25 @@ def unstructured_blocks(nb=24, bs=3, seed=5):
     return nb, bs, np.array(rp, np.int64), np.array(ci, np.int64), np.array(va, np.complex128)
 
 
+def unstructured_block_triplets(nb=24, bs=4, seed=15):
+    """The same kind of operator as (block_row, block_col, block) triplets — what HierarchicalSparse is built from — with a
+    duplicated (row, col) pair here and there (kept and summed at apply time, src/HierarchicalSparse.h:20-21,89-94)."""
+    rng = np.random.default_rng(seed)
+    rows, cols, blocks = [], [], []
+    for br in range(nb):
+        others = rng.choice([c for c in range(nb) if c != br], size=int(rng.integers(1, 6)), replace=False)
+        for c in [br] + [int(o) for o in others]:
+            blk = (rng.standard_normal((bs, bs)) + 1j * rng.standard_normal((bs, bs))) * 0.1
+            if c == br:
+                blk = blk + np.eye(bs) * 3.0
+            rows.append(br); cols.append(c); blocks.append(blk)
+        if br % 5 == 2:   # a duplicate of this row's first off-diagonal block position
+            rows.append(br); cols.append(int(others[0]))
+            blocks.append((rng.standard_normal((bs, bs)) + 1j * rng.standard_normal((bs, bs))) * 0.05)
+    order = rng.permutation(len(rows))   # triplets arrive unsorted
+    return nb, bs, np.array(rows, np.int64)[order], np.array(cols, np.int64)[order], np.array(blocks)[order]
+
+
 def local_block(rowptr, col, val, r0, r1):
     lp = rowptr[r0:r1 + 1] - rowptr[r0]
     return lp, col[rowptr[r0]:rowptr[r1]], val[rowptr[r0]:rowptr[r1]]
@@ -104,6 +123,44 @@ def main():
         outer.solve(Field(dims, b), x)
         results["mg"] = dict(y=y, x=x.to_numpy(), hist=outer.last_history, its=outer.last_iterations, conv=outer.last_converged,
                              levels=[M.level_info(l) for l in range(2)])
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if mode == "bcsr":
+        # BASELINE configs[4]'s operator as it is: a distributed HierarchicalSparse (block rows dealt to the ranks, block
+        # columns anywhere), its apply, GCR on it, and MG with aggregates of two block rows whose Galerkin coarse operator
+        # is a distributed HierarchicalSparse again
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistHierarchicalSparse, Field, GCR, GCR_Param, MG, MG_Param, Mesh
+        mg.init(0)
+        nb, bs, rows, cols, blocks = unstructured_block_triplets()
+        per = nb // world
+        b0, b1 = rank * per, (rank + 1) * per if rank + 1 < world else nb
+        sel = (rows >= b0) & (rows < b1)
+        H = DistHierarchicalSparse(comm, nb, b0, b1 - b0, rows[sel] - b0, cols[sel], blocks[sel])
+        N = nb * bs
+        r0, r1 = b0 * bs, b1 * bs
+        dims = (b1 - b0, bs)
+        xv = problems.rhs_grid(N, 3)[r0:r1]
+        y = H(Field(dims, xv)).to_numpy()
+        g = GCR(H, GCR_Param(0, 4, 30, 1e-30, False))
+        xs = Field(dims).set_zero()
+        g.solve(Field(dims, xv), xs)
+        vecs = np.random.default_rng(9).standard_normal((2, N)) + 1j * np.random.default_rng(10).standard_normal((2, N))
+        prm = MG_Param(Mesh(dims), 2, 2, None, GCR(GCR_Param(0, 10, 30, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                       1, None, None, spacetime=[True, False], null_vectors=vecs[:, r0:r1])
+        M = MG(H, prm)
+        ymg = M(Field(dims, xv)).to_numpy()
+        Ac = M.level_operator(1)
+        nc = M.level_info(1)["dim"]
+        wc = problems.rhs_grid(2 * (nb // 2), 6)[rank * nc: rank * nc + nc] if world > 1 else problems.rhs_grid(nc, 6)
+        outer = GCR(H, GCR_Param(0, 5, 60, 1e-10, False, None, M, flexible=True, check_every=3))
+        xo = Field(dims).set_zero()
+        outer.solve(Field(dims, xv), xo)
+        results["bcsr"] = dict(y=y, hist=g.last_history, x=xs.to_numpy(), halo=H.halo_kind, ymg=ymg, xo=xo.to_numpy(),
+                               hist_mg=outer.last_history, its=outer.last_iterations, conv=outer.last_converged,
+                               levels=[M.level_info(l) for l in range(2)], coarse_is_block=Ac.get_nrow() == nc)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
         dist.barrier()
         dist.destroy_process_group()

@@ -233,3 +233,51 @@ def test_distributed_mg_on_unstructured_blocks(tmp_path, world):
     xd = np.concatenate([res[r]["mg"]["x"] for r in range(world)])
     rr = Field(dims, b) - A(Field(dims, xd))
     assert rr.norm() / np.linalg.norm(b) <= 2e-10
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_hierarchical_sparse(tmp_path, world):
+    """BASELINE configs[4] with the operator as it is (reference apply: src/HierarchicalSparse.h:101-161): a distributed
+    HierarchicalSparse — block rows dealt to the ranks, block columns anywhere, halo at block granularity read in place by
+    the block kernel.  Apply bit-equal to the single-process operator (same block order in every row, duplicates kept);
+    GCR on it; MG with aggregates of two block rows whose Galerkin coarse operator is a distributed block-CSR again."""
+    from mgpreconditionedgcr_amd import HierarchicalSparse, MG, MG_Param, Mesh
+    from tests.dist_worker import unstructured_block_triplets
+    mg.init()
+    res = run_workers("bcsr", world, tmp_path, timeout=500)
+    nb, bs, rows, cols, blocks = unstructured_block_triplets()
+    N = nb * bs
+    H = HierarchicalSparse(nb, nb, rows.astype(np.int32), cols.astype(np.int32), blocks)
+    dims = (nb, bs)
+    xv = problems.rhs_grid(N, 3)
+    y = H(Field(dims, xv)).to_numpy()
+    yd = np.concatenate([res[r]["bcsr"]["y"] for r in range(world)])
+    assert np.array_equal(yd, y)                                   # bit for bit
+    want_h = "host" if os.environ.get("MGCR_PEER_HALO") == "0" or os.environ.get("MGCR_PEER_ALLREDUCE") == "0" else "peer-write"
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0":
+        assert all(res[r]["bcsr"]["halo"] == want_h for r in range(world))
+    g = GCR(H, GCR_Param(0, 4, 30, 1e-30, False))
+    xs = Field(dims).set_zero()
+    g.solve(Field(dims, xv), xs)
+    hd = res[0]["bcsr"]["hist"]
+    assert hd.size == g.last_history.size
+    assert np.abs(hd - g.last_history).max() <= 1e-9 * np.abs(g.last_history).max()
+    xd = np.concatenate([res[r]["bcsr"]["x"] for r in range(world)])
+    assert np.abs(xd - xs.to_numpy()).max() <= 1e-9 * np.abs(xs.to_numpy()).max()
+    vecs = np.random.default_rng(9).standard_normal((2, N)) + 1j * np.random.default_rng(10).standard_normal((2, N))
+    prm = MG_Param(Mesh(dims), 2, 2, None, GCR(GCR_Param(0, 10, 30, 1e-3, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   1, None, None, spacetime=[True, False], null_vectors=vecs)
+    M = MG(H, prm)
+    assert sum(res[r]["bcsr"]["levels"][1]["dim"] for r in range(world)) == M.level_info(1)["dim"]
+    assert all(res[r]["bcsr"]["coarse_is_block"] for r in range(world))
+    ymg = M(Field(dims, xv)).to_numpy()
+    ymgd = np.concatenate([res[r]["bcsr"]["ymg"] for r in range(world)])
+    assert np.abs(ymgd - ymg).max() <= 1e-9 * np.abs(ymg).max()
+    outer = GCR(H, GCR_Param(0, 5, 60, 1e-10, False, None, M, flexible=True))
+    xo = Field(dims).set_zero()
+    outer.solve(Field(dims, xv), xo)
+    for r in range(world):
+        assert res[r]["bcsr"]["conv"] and abs(res[r]["bcsr"]["its"] - outer.last_iterations) <= 1
+    xod = np.concatenate([res[r]["bcsr"]["xo"] for r in range(world)])
+    rr = Field(dims, xv) - H(Field(dims, xod))
+    assert rr.norm() / np.linalg.norm(xv) <= 2e-10
