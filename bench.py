@@ -785,7 +785,40 @@ def wl_sample(args):
             "note": "latency regime: 3 dependent kernels per iteration on 3072 rows"}
 
 
-WORKLOADS = {"poisson256_gcr": wl_poisson256_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
+def wl_poisson128_tol(args):
+    """configs[1] run to tolerance (not in the default line: it takes a second or so): GCR restart 5 to 1e-13 on Poisson
+    128^3, and the same solve with configs[2]'s 3-level MG as flexible right preconditioner."""
+    import numpy as np
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, MG, MG_Param, Mesh, Sparse, problems
+    mg.init(0)
+    n, tol = 128, 1e-13
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    dims = (n, n, n)
+    rhs, x = Field(dims).fill_rhs(0), Field(dims)
+    gcr = GCR(A, GCR_Param(0, 5, 200000, tol, False, check_every=50))
+    timed_solve(mg, gcr, rhs, x)
+    dt = timed_solve(mg, gcr, rhs, x)
+    out = {"workload": "3D 7-point Poisson 128^3, GCR restart 5 to 1e-13 (time to tolerance), then MG-preconditioned", "tol": tol,
+           "iterations": gcr.last_iterations, "converged": gcr.last_converged, "seconds_to_tol": dt, "it_per_s": gcr.last_iterations / dt,
+           "true_rel_residual": (rhs - A(x)).norm() / rhs.norm()}
+    t0 = time.perf_counter()
+    prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   2, None, None, null_vectors=np.ones((1, N), np.complex128))
+    M = MG(A, prm)
+    mg.lib().mgcr_synchronize()
+    out["mg_setup_seconds"] = time.perf_counter() - t0
+    outer = GCR(A, GCR_Param(0, 5, 500, tol, False, None, M, flexible=True, check_every=2))
+    timed_solve(mg, outer, rhs, x)
+    dt = timed_solve(mg, outer, rhs, x)
+    out.update(mg_parity=MG_PARITY_NOTE, mg_outer_iterations=outer.last_iterations, mg_converged=outer.last_converged, mg_seconds_to_tol=dt,
+               mg_true_rel_residual=(rhs - A(x)).norm() / rhs.norm())
+    return out
+
+
+WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
              "sample": wl_sample}
 
 

@@ -227,6 +227,11 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
                                                                 LeanCoef *__restrict__ lc) {
     __shared__ double lds[4 * 17];
     if (st->stop_at < st->base + it) return;
+    // the first trip's operands are requested BEFORE alpha is folded from the partials: one memory round trip of the
+    // kernel's prologue (partials -> alpha -> first loads) disappears behind the other
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    cplx r0 = make_double2(0., 0.), a0 = r0;
+    if (i0 < n) { r0 = r_in[i0]; a0 = ap[i0]; }
     double s[4];
     fold_partials<4>(partsA, nblkA, strideA, s, lds);
     const cplx num = make_double2(s[0], s[1]), den = make_double2(s[2], s[3]);
@@ -242,7 +247,8 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
     double v[1] = {0.};
     GRID_STRIDE(i, n) {
         if (!DEFER) x[i] = cadd(x[i], cmul(alpha, p[i]));
-        cplx rn = csub(r_in[i], cmul(alpha, ap[i]));
+        const bool first = i == i0;
+        cplx rn = csub(first ? r0 : r_in[i], cmul(alpha, first ? a0 : ap[i]));
         r_out[i] = rn;  // LEAN: the residual ring (r_out != r_in inside a cycle); else in place
         v[0] += rn.x * rn.x + rn.y * rn.y;
     }

@@ -46,6 +46,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // extra "finalise" launch is needed and results are reproducible run to run.
 constexpr int RED_THREADS = 1024;
 constexpr int RED_MAX_BLOCKS = 512;
+constexpr int STEN_TILE = 512;   // rows per workgroup of the stand-alone stencil SpMV
 constexpr int STEN_MAX = 9;   // slots of a stencil view (CsrDev::sten_*): kernels are instantiated for 7 and 9
 
 struct Context {
@@ -102,6 +103,8 @@ struct CsrDev {
     int32_t sten_off[16] = {};
     double sten_re[16] = {}, sten_im[16] = {};
     uint64_t *sten_planes = nullptr;
+    uint32_t sten_near = 0;       // slots within STEN_TILE / 2 rows of the diagonal: the stand-alone SpMV serves them from an LDS window
+    int32_t sten_halo = 0;        // largest |offset| among them (0: no window)
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]

@@ -451,6 +451,15 @@ static int sten_try(CsrDev &A) {
         if ((int64_t)counts[(size_t)s] * 16 < A.nrow) A.sten_rare |= 1u << s;
     }
     for (int s = ns; s < 16; s++) { A.sten_off[s] = 0; A.sten_re[s] = 0.; A.sten_im[s] = 0.; }
+    // slots close to the diagonal (|offset| <= STEN_TILE / 2, e.g. +-1 and +-n of a 3-D grid up to n = 256) are read by
+    // several rows of the same workgroup: the stand-alone kernel stages x once in an LDS window and serves them from there
+    A.sten_near = 0;
+    A.sten_halo = 0;
+    for (int s = 0; s < ns; s++) {
+        const int32_t a = S[(size_t)s] < 0 ? -S[(size_t)s] : S[(size_t)s];
+        if (a <= STEN_TILE / 2 && !(A.sten_rare >> s & 1u)) { A.sten_near |= 1u << s; A.sten_halo = std::max(A.sten_halo, a); }
+    }
+    if (A.sten_halo < 32) { A.sten_near = 0; A.sten_halo = 0; }   // only +-1-like neighbours: L1 serves those as well
     return MGCR_OK;
 }
 
@@ -761,6 +770,74 @@ __global__ void __launch_bounds__(BLK) sten_spmv(RowMat m, int64_t row_begin, in
     if (live) y[rloc] = SHIFT ? csub((w ? w : x)[rloc], cmul(m.k, sum)) : sum;
 }
 
+// The same with an LDS window: the workgroup's BLK entries of x plus sten_halo entries on either side are staged once
+// (one coalesced load per thread, the halo by the first 2 * sten_halo threads) and the slots close to the diagonal
+// (sten_near: +-1, +-n of a grid) are read from there; the far slots (+-n^2) are requested before the barrier.  A
+// 7-point row then costs ~3.5 loads through L1 / L2 instead of 7 — tools/spmv_lab.hip on MI355X, Poisson 256^3: 130
+// against 151 us with cold caches (the +-n neighbours, which the neighbouring workgroups fetch at the same time, are
+// the expensive ones), 128^3: 20.4 against 21.9 us.  Same slot order, same selects: same bits.  NEAR is a template
+// parameter (the kernel exists for the mask of a 3-D stencil, slots 1..5 of 7): with a run-time mask the compiler keeps
+// the gathered values in scratch memory and waits for every load in turn — 4x slower than no window at all.
+template <int NS, bool RARE, bool SHIFT, int BLK, unsigned NEAR>
+__global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begin, int64_t row_end, int64_t first, int64_t ntiles, int xcd,
+                                                      const cplx *__restrict__ x, cplx *__restrict__ y, const cplx *__restrict__ w,
+                                                      const int *__restrict__ skip, int skip_it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sten_smem[];
+    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
+    const int64_t tile = xcd ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
+    if (tile >= ntiles) return;
+    cplx *sx = reinterpret_cast<cplx *>(sten_smem);   // [H + BLK + H], entry e = column base - H + e
+    const int32_t H = m.sten_halo;
+    const int64_t base = first + tile * BLK;
+    const int64_t rloc = base + threadIdx.x;
+    const bool live = rloc >= row_begin && rloc < row_end;
+    // presence words of this wave (rows beyond the padded end of the matrix have none: the planes array ends with a zero row)
+    int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
+    wave = wave < m.sten_nwaves ? wave : m.sten_nwaves;
+    const uint64_t *pp = m.sten_planes + (int64_t)wave * m.sten_stride;
+    uint64_t pl[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) pl[c] = pp[c];
+    auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
+    cplx xv[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        xv[c] = make_double2(0., 0.);
+        if (!(NEAR >> c & 1u) && (!RARE || !(m.sten_rare >> c & 1u)))
+            xv[c] = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
+    }
+    const cplx own = gather_x(x, m.xh, m.n_own, clampj(rloc));
+    cplx halo = make_double2(0., 0.);
+    int hidx = -1;
+    if ((int)threadIdx.x < 2 * H) {
+        const int t = (int)threadIdx.x;
+        halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + BLK + (t - H)));
+        hidx = t < H ? t : BLK + t;
+    }
+    if (RARE) {
+#pragma unroll
+        for (int c = 0; c < NS; c++)
+            if ((m.sten_rare >> c & 1u) && pl[c] != 0ull) xv[c] = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first one is waited for
+    sx[H + threadIdx.x] = own;
+    if (hidx >= 0) sx[hidx] = halo;
+    __syncthreads();
+    const int lane = (int)(threadIdx.x & 63);
+    cplx sum = make_double2(0., 0.);
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        // a window entry outside the matrix is a clamped copy: only read by rows whose presence bit for the slot is clear
+        const cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : xv[c];
+        const bool on = (pl[c] >> lane & 1ull) != 0ull;
+        const cplx t = m.realv ? make_double2(m.sten_re[c] * v.x, m.sten_re[c] * v.y) : cmul(make_double2(m.sten_re[c], m.sten_im[c]), v);
+        const cplx nsum = cadd(sum, t);
+        sum.x = on ? nsum.x : sum.x;
+        sum.y = on ? nsum.y : sum.y;
+    }
+    if (live) y[rloc] = SHIFT ? csub((w ? w : x)[rloc], cmul(m.k, sum)) : sum;
+}
+
 // L in {2,4,8,16}: L consecutive lanes share a row; per chunk the (row, lane) pairs are contiguous
 template <int L, bool SHIFT, bool REALV>
 __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t row_count, int64_t npad, int32_t nchunk,
@@ -823,7 +900,7 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     Context &c = ctx();
     if (row_count <= 0) return MGCR_OK;
     if (csr_stencil_active(A)) {
-        constexpr int BLK = 512;
+        constexpr int BLK = STEN_TILE;
         const int64_t first = row_begin & ~(int64_t)63;
         const int64_t ntiles = (row_begin + row_count - first + BLK - 1) / BLK;
         const bool xcd = ntiles >= 64;
@@ -833,8 +910,16 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
 #define SL(NS, RARE)                                                                                                      \
     hipLaunchKernelGGL((sten_spmv<NS, RARE, SHIFT, BLK>), dim3(grid), dim3(BLK), 0, c.stream, m, row_begin, row_begin + row_count, \
                        first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
-        if (sten_slots(A) == 7) { if (A.sten_rare) SL(7, true); else SL(7, false); }
+#define SLT(NS, RARE)                                                                                                     \
+    hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * A.sten_halo) * sizeof(cplx), \
+                       c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
+        static const bool tile_on = !(getenv("MGCR_STENCIL_TILE") && atoi(getenv("MGCR_STENCIL_TILE")) == 0);
+        if (A.sten_halo > 0 && A.sten_near == 0x3eu && tile_on) {
+            if (sten_slots(A) == 7) { if (A.sten_rare) SLT(7, true); else SLT(7, false); }
+            else { if (A.sten_rare) SLT(9, true); else SLT(9, false); }
+        } else if (sten_slots(A) == 7) { if (A.sten_rare) SL(7, true); else SL(7, false); }
         else { if (A.sten_rare) SL(9, true); else SL(9, false); }
+#undef SLT
 #undef SL
         MGCR_HIP(hipGetLastError());
         return MGCR_OK;

@@ -3,9 +3,12 @@
 (MI355X_MICROARCH.md, HBM / rocprofv3 section: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs;
 units KiB per dispatch; gfx950 correction: bytes read = 2 x FETCH_SIZE).
 
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_hbm_traffic_v5.csv profiles/pmc_traffic.json
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_hbm_traffic.csv profiles/pmc_traffic.json
+
+The JSON is stamped with the fingerprint of the kernel sources it was measured on (bench.source_sha16): bench.py prints
+roofline.traffic only while that fingerprint matches the sources it runs.
 
 Writes the per-kernel table (CSV) and the JSON bench.py reads for roofline.traffic: average corrected
 HBM bytes per launch of the kernels of each phase of a GCR iteration (xr | apply+dots | build).
@@ -17,6 +20,8 @@ import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d, counter):
@@ -37,7 +42,7 @@ def phase_of(name):
         return "xr"
     if name.startswith(("step_apply_kernel", "multidot_kernel")):
         return "apply_dots"
-    if name.startswith(("pat_spmv", "ell_spmv", "csr_tail")):
+    if name.startswith(("pat_spmv", "ell_spmv", "csr_tail", "sten_spmv")):
         return "spmv"   # stand-alone applies (set-up, bench.py's replay / cold-cache loops)
     if name.startswith(("build_lean_kernel", "build_close_kernel", "build_kernel")):
         return "build"
@@ -63,12 +68,13 @@ def main():
             phases[ph][0] += calls
             phases[ph][1] += b * calls
     with open(out_csv, "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5\n")
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5\n")
         f.write("# MI355X, Poisson %d^3.  Units: KiB per dispatch as reported; gfx950 correction (MI355X_MICROARCH.md HBM section): reads = 2 x FETCH_SIZE\n" % n)
         f.write("kernel,dispatches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch_corrected\n")
         for name, calls, favg, wavg, b in rows:
             f.write('"%s",%d,%.1f,%.1f,%.0f\n' % (name, calls, favg, wavg, b))
-    js = {"n": n,
+    import bench
+    js = {"n": n, "src_sha16": bench.source_sha16(),
           "derivation": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch from %s (separate --pmc passes, gfx950 FETCH_SIZE x2 correction), "
                         "averaged over the launches of the kernels of each phase" % os.path.basename(out_csv),
           "phase_hbm_bytes_per_launch": {k: v[1] / v[0] for k, v in phases.items() if v[0]},

@@ -373,6 +373,58 @@ __global__ void __launch_bounds__(BLK) k_mask2(int64_t n, int64_t ntiles, Sup su
     if (live) y[row] = sum;
 }
 
+
+// ---- Lb: presence words (scalar loads) + LDS window for the near offsets ----
+template <int NS, int BLK, unsigned NEAR>
+__global__ void __launch_bounds__(BLK) k_planes_tile(int64_t n, int64_t ntiles, Sup sup, SlotVal sv, int32_t H, const uint64_t *__restrict__ planes,
+                                                     const cplx *__restrict__ x, cplx *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    cplx *sx = reinterpret_cast<cplx *>(smem);
+    const int64_t base = tile * BLK;
+    const int64_t rloc = base + threadIdx.x;
+    const bool live = rloc < n;
+    const int32_t row = (int32_t)(live ? rloc : n - 1);
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
+    const uint64_t *pp = planes + wave * 8;
+    uint64_t pl[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) pl[c] = pp[c];
+    cplx xv[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++)
+        if (!(NEAR >> c & 1u)) {
+            int32_t j = row + sup.off[c];
+            j = j < 0 ? 0 : j >= (int32_t)n ? (int32_t)n - 1 : j;
+            xv[c] = x[j];
+        }
+    cplx own = x[row];
+    cplx halo = make_double2(0., 0.);
+    int hidx = -1;
+    if ((int)threadIdx.x < 2 * H) {
+        const int t = threadIdx.x;
+        int64_t j = t < H ? base - H + t : base + BLK + (t - H);
+        j = j < 0 ? 0 : j >= n ? n - 1 : j;
+        halo = x[j];
+        hidx = t < H ? t : BLK + t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    sx[H + threadIdx.x] = own;
+    if (hidx >= 0) sx[hidx] = halo;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    cplx sum = make_double2(0., 0.);
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + sup.off[c]] : xv[c];
+        const bool on = (pl[c] >> lane & 1ull) != 0;
+        const double nx = sum.x + sv.v[c] * v.x, ny = sum.y + sv.v[c] * v.y;
+        sum.x = on ? nx : sum.x; sum.y = on ? ny : sum.y;
+    }
+    if (live) y[row] = sum;
+}
+
 __global__ void k_flush(int64_t n, const double4 *__restrict__ a, double4 *__restrict__ b) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
@@ -522,6 +574,15 @@ int main(int argc, char **argv) {
             vars.push_back({"Mb bit planes (scalar loads), 256", [&] { hipLaunchKernelGGL((k_mask2<7, 256, 2>), dim3(g256), dim3(256), 0, st, N, nt256, sup, sv, rmask, planes, x, y); }});
             vars.push_back({"Mb bit planes (scalar loads), 512", [&, nt512, g512] { hipLaunchKernelGGL((k_mask2<7, 512, 2>), dim3(g512), dim3(512), 0, st, N, nt512, sup, sv, rmask, planes, x, y); }});
             vars.push_back({"Mb bit planes (scalar loads), 1024", [&, nt1k, g1k] { hipLaunchKernelGGL((k_mask2<7, 1024, 2>), dim3(g1k), dim3(1024), 0, st, N, nt1k, sup, sv, rmask, planes, x, y); }});
+            {
+                const int H = n;
+                if (2 * H <= 512) {
+                    vars.push_back({"Lb planes + tile 1024 halo n", [&, H, nt1k, g1k] { hipLaunchKernelGGL((k_planes_tile<7, 1024, 0x3eu>), dim3(g1k), dim3(1024), (size_t)(1024 + 2 * H) * 16, st, N, nt1k, sup, sv, H, planes, x, y); }});
+                    vars.push_back({"Lb planes + tile 512 halo n", [&, H, nt512, g512] { hipLaunchKernelGGL((k_planes_tile<7, 512, 0x3eu>), dim3(g512), dim3(512), (size_t)(512 + 2 * H) * 16, st, N, nt512, sup, sv, H, planes, x, y); }});
+                    vars.push_back({"Lb planes + tile 1024 halo n (+-n only)", [&, H, nt1k, g1k] { hipLaunchKernelGGL((k_planes_tile<7, 1024, 0x22u>), dim3(g1k), dim3(1024), (size_t)(1024 + 2 * H) * 16, st, N, nt1k, sup, sv, H, planes, x, y); }});
+                }
+            }
+
         }
         const int H = n;
         if (2 * H <= 512) {
