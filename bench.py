@@ -194,8 +194,10 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(key, n):
-    """(HBM bytes per launch of phase `key` measured by PMC, note) — null unless measured on the current sources."""
+def pmc_traffic(key, n, lims=None, restart=0):
+    """(HBM bytes per launch of phase `key` measured by PMC, note) — null unless measured on the current sources.  With
+    `lims` (the number of stored directions of every timed iteration) the per-kernel figures are weighted by the kernels
+    those iterations launched, i.e. exactly the launches `achieved` is an average over."""
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(prof))
@@ -206,7 +208,29 @@ def pmc_traffic(key, n):
     if d.get("src_sha16") != source_sha16():
         return None, ("profiles/pmc_traffic.json was measured on other kernel sources (%s, now %s): not printed next to live timings"
                       % (d.get("src_sha16"), source_sha16()))
-    return d["phase_hbm_bytes_per_launch"].get(key), "PMC FETCH_SIZE / WRITE_SIZE passes of these sources (tools/pmc_traffic.py)"
+    note = "PMC FETCH_SIZE / WRITE_SIZE passes of these sources (tools/pmc_traffic.py)"
+    kern = d.get("kernel_hbm_bytes_per_launch")
+    if lims and kern:
+        import re
+
+        def of(l):
+            for name, b in kern.items():
+                if key == "xr" and name.startswith("xr_update_kernel"):
+                    return b
+                m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
+                if key == "apply_dots" and m and int(m.group(1)) == l:
+                    return b
+                m = re.match(r"build_lean_kernel<(\d+)>", name)
+                if key == "build" and l < restart and m and int(m.group(1)) == l:
+                    return b
+                m = re.match(r"build_close_kernel<(\d+)", name)
+                if key == "build" and l == restart and m and int(m.group(1)) == l:
+                    return b
+            return None
+        per = [of(l) for l in lims]
+        if all(v is not None for v in per):
+            return sum(per) / len(per), note + ", per kernel, weighted by the kernels the timed iterations launched"
+    return d["phase_hbm_bytes_per_launch"].get(key), note + ", average over the launches of the profiled run"
 
 
 def stats(samples):
@@ -466,7 +490,8 @@ def run_headline(args, with_cpu=True):
     keys = ["xr", "apply_dots", "build"]
     dom = max(range(3), key=lambda k: ph_us[k])
     achieved = b_phase[dom] / (ph_us[dom] * 1e-6) / 1e9
-    traffic, traffic_note = pmc_traffic(keys[dom], n) if world == 1 else (None, "N > 1")
+    lims_timed = [((k - 1) % R) + 1 for k in range(1, max(n_it.value, 1) + 1)]
+    traffic, traffic_note = pmc_traffic(keys[dom], n, lims_timed, R) if world == 1 else (None, "N > 1")
     b_spmv_survey = spmv_algorithmic_bytes(nnz, N, ncol)
     iter_bytes_survey = b_spmv_survey + (13 + 3 * mean_lim) * V   # SURVEY.md §8(d) accounting
     iter_bytes_ours = sum(b_phase)                                # what this implementation moves

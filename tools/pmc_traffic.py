@@ -78,7 +78,10 @@ def main():
           "derivation": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch from %s (separate --pmc passes, gfx950 FETCH_SIZE x2 correction), "
                         "averaged over the launches of the kernels of each phase" % os.path.basename(out_csv),
           "phase_hbm_bytes_per_launch": {k: v[1] / v[0] for k, v in phases.items() if v[0]},
-          "phase_launches": {k: v[0] for k, v in phases.items()}}
+          "phase_launches": {k: v[0] for k, v in phases.items()},
+          # per kernel too: bench.py weights these by the mix of kernels its timed iterations launched (iteration k of a restart
+          # cycle orthogonalises against k directions), so that `traffic` and `achieved` describe the same launches
+          "kernel_hbm_bytes_per_launch": {name: b for name, calls, favg, wavg, b in rows if phase_of(name)}}
     json.dump(js, open(out_json, "w"), indent=1)
     print(json.dumps(js, indent=1))
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel achieved-HBM-rate table from a rocprofv3 --kernel-trace --stats CSV of `bench.py`
 (Poisson n^3, restart 5).  Bytes are the models of DESIGN.md section 3 for the stored layout
-(row-pattern dictionary, lean restart cycles, fused SpMV + dots).
+(stencil view of the row-pattern dictionary, lean restart cycles, fused SpMV + dots).
 
     python tools/roofline_table.py profiles/r01_bench_kernel_stats_v3.csv [n]
 """
@@ -15,7 +15,7 @@ N = n ** 3
 nnz = 7 * N - 6 * n * n
 V = 16 * N
 slab = 7 * ((N + 63) // 64 * 64)
-B_pat = 2 * ((N + 63) // 64 * 64) + 27 * 7 * 12    # row-pattern dictionary: 2 B per row + the table
+B_pat = ((N + 63) // 64) * 8 * 8 + 7 * 20          # stencil view: 8 presence words of 8 B per wave of 64 rows + the slot table
 B_spmv = B_pat + 2 * V
 R = 5
 rows = list(csv.DictReader(open(path)))
@@ -45,7 +45,10 @@ for r in rows:
         b = 3 * V
     if name.startswith("xr_update_kernel<false"):
         b = 6 * V
-    if name.startswith(("ell_spmv_rowthread", "pat_spmv")):
+    m = re.match(r"init_apply_kernel", name)
+    if m:
+        b = B_spmv                                   # SpMV of step 0 + its dot products (no extra streams when b is r0)
+    if name.startswith(("ell_spmv_rowthread", "pat_spmv", "sten_spmv")):
         b = B_spmv
     if name.startswith("copy_kernel"):
         b = 2 * V
