@@ -561,7 +561,49 @@ public:
     GCR(GCR const &g) : A_operator(g.A_operator), param(g.param) { if (A_operator) this->dim = A_operator->get_dim(); }
     explicit GCR(Operator<num_type> *M, GCR_Param<num_type> *gcr_param) : A_operator(M), param(gcr_param) { this->dim = M->get_dim(); }
     GCR(GCR_Param<num_type> *gcr_param) : param(gcr_param) {}
-    ~GCR() override { if (op) mgcr_op_destroy(op); }
+    // the legacy dense form (src/GCR.h:27,70-75): a row-major dimension x dimension matrix, copied
+    GCR(const std::complex<double> *matrix, const num_type dimension) : dense(matrix, matrix + dimension * dimension) { this->dim = dimension; }
+    ~GCR() override { if (op) mgcr_op_destroy(op); if (dense_op) mgcr_op_destroy(dense_op); }
+
+    // Legacy raw-pointer solve (src/GCR.h:78-156): r0 = rhs - A x (x0 honoured), directions truncated to the last
+    // `truncation`, stops when |r|^2 <= tol — absolute, and tested BEFORE every step, so possibly after none — or after
+    // max_iter steps; prints the reference's lines.  On the device: the Dense operator, GCR in truncation mode with use_x0;
+    // the relative stopping rule of the Field solve is set to sqrt(tol) / |rhs|, which is the same test.
+    void solve(const std::complex<double> *rhs, std::complex<double> *x, const double tol, const int max_iter, const int truncation) {
+        if (dense.empty()) { std::fprintf(stderr, "GCR::solve(raw pointers) needs the GCR(matrix, dimension) constructor\n"); std::abort(); }
+        mgcr_detail::ensure_init();
+        const num_type d = this->dim;
+        if (!dense_op) {
+            int32_t bp[2] = {0, 1}, bc[1] = {0};
+            mgcr_detail::ok(mgcr_bcsr_create(1, 1, (int32_t)d, bp, bc, reinterpret_cast<const double *>(dense.data()), &dense_op), "GCR dense matrix");
+        }
+        num_type dims1[1] = {d};
+        Field<num_type> b(dims1, 1), xf(dims1, 1), r(dims1, 1);
+        for (num_type i = 0; i < d; i++) { b.mod_val_at(i, rhs[i]); xf.mod_val_at(i, x[i]); }
+        // the test that precedes the first step: |rhs - A x0|^2 > tol ?
+        mgcr_detail::ok(mgcr_op_apply(dense_op, xf.device(), r.device()), "GCR dense residual");
+        r.device_written();
+        Field<num_type> r0 = b - r;
+        const double bn2 = b.squarednorm();
+        int it = 0;
+        double rr = r0.squarednorm();
+        if (rr > tol && max_iter > 0 && bn2 > 0.) {
+            mgcr_gcr_param p;
+            std::memset(&p, 0, sizeof(p));
+            p.truncation = truncation; p.restart = 0; p.max_iter = max_iter; p.tol = std::sqrt(tol) / std::sqrt(bn2); p.use_x0 = 1;
+            std::vector<double> hist((size_t)max_iter + 1, 0.);
+            int32_t n = 0, conv = 0;
+            mgcr_detail::ok(mgcr_gcr_solve(dense_op, &p, b.device(), xf.device(), hist.data(), max_iter + 1, &n, &conv), "GCR dense solve");
+            xf.device_written();
+            it = n;
+            const double bn = std::sqrt(bn2);
+            for (int k = 1; k <= it; k++) std::printf("Step %d residual norm = %.10e\n", k, hist[(size_t)k] * bn);
+            rr = (hist[(size_t)it] * bn) * (hist[(size_t)it] * bn);
+            for (num_type i = 0; i < d; i++) x[i] = xf.val_at(i);
+        }
+        if (it == max_iter) std::printf("GCR did not converge after %d steps! Residual norm = %.10e\n", max_iter, rr);
+        iterations = it;
+    }
     void initialise(Operator<num_type> *M) override { A_operator = M; this->dim = M->get_dim(); if (op) mgcr_detail::ok(mgcr_gcr_set_operator(op, M->handle()), "GCR::initialise"); }
     GCR_Param<num_type> *get_param() const { return param; }
 
@@ -624,6 +666,8 @@ private:
     Operator<num_type> *A_operator = nullptr;
     GCR_Param<num_type> *param = nullptr;
     mgcr_op_t op = nullptr;
+    std::vector<std::complex<double>> dense;   // legacy GCR(matrix, dimension)
+    mgcr_op_t dense_op = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------

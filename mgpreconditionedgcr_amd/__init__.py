@@ -6,7 +6,7 @@ include/mgcr.h; this package is the Python mirror of the reference's host interf
 """
 from ._lib import MgcrError, finalize, init, lib  # noqa: F401
 from .api import (Dense, DiracOp, Field, GCR, GCR_Param, HierarchicalSparse, MG, MG_Param, Mesh,  # noqa: F401
-                  Operator, Sparse, gamma5, read_data, set_option, vec_double)
+                  Operator, Sparse, gamma5, legacy_dense_gcr, read_data, set_option, vec_double)
 from . import problems  # noqa: F401
 from .distributed import Comm, DistHierarchicalSparse, DistSparse, Plan  # noqa: F401
 from . import experiments  # noqa: F401

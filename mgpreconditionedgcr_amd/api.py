@@ -383,6 +383,32 @@ class GCR(Operator):
         return x
 
 
+def legacy_dense_gcr(matrix, rhs, x, tol, max_iter, truncation, verbose=True):
+    """GCR(matrix, dimension).solve(rhs, x, tol, max_iter, truncation) — the reference's legacy raw-pointer dense solve
+    (src/GCR.h:70-156): r0 = rhs - A x (x0 honoured), directions truncated to the last `truncation`, stops when
+    |r|^2 <= tol — absolute, tested BEFORE every step, so possibly after none — or after max_iter steps.  On the device:
+    the Dense operator, GCR in truncation mode with use_x0; sqrt(tol) / |rhs| as relative tolerance is the same test.
+    Returns (x, absolute residual norms per step) and prints the reference's lines when verbose."""
+    A = Dense(matrix)
+    d = A.mat.shape[0]
+    b = Field((d,), rhs)
+    xf = Field((d,), x)
+    r0 = b - A(xf)
+    bn2, rr = b.squarednorm(), r0.squarednorm()
+    norms = np.zeros(0)
+    if rr > tol and max_iter > 0 and bn2 > 0.:
+        g = GCR(A, GCR_Param(int(truncation), 0, int(max_iter), float(np.sqrt(tol) / np.sqrt(bn2)), False, use_x0=True))
+        g.solve(b, xf)
+        norms = g.last_history[1:] * np.sqrt(bn2)
+        rr = float(norms[-1] ** 2)
+    if verbose:
+        for k, v in enumerate(norms):
+            print("Step %d residual norm = %.10e" % (k + 1, v))
+        if norms.size == max_iter:
+            print("GCR did not converge after %d steps! Residual norm = %.10e" % (max_iter, rr))
+    return xf.to_numpy(), norms
+
+
 class Mesh:
     """Mesh<num_type> (src/Mesh.h:13-64): row-major N-D index algebra (host side)."""
 

@@ -456,9 +456,63 @@ static void case_arnoldi() {
     delete Dirac; delete D;
 }
 
+// G16: the legacy raw-pointer dense GCR (src/GCR.h:70-156) and the utils BLAS it is written with (src/utils.cpp:8-90):
+// r0 = rhs - A x0 (x0 honoured), truncated directions, stops when |r|^2 <= tol (absolute, tested BEFORE every step) or
+// after max_iter steps.  It keeps no history: the golden holds the final x at full precision and the printed norms
+// (`Step %d residual norm = %.10e`, captured from stdout by make_golden.py).
+static void case_legacy() {
+    const long d = 24;
+    std::mt19937_64 rng(321);
+    std::uniform_real_distribution<double> U(-1., 1.);
+    std::vector<cplx> A(d * d, cplx(0., 0.)), rhs(d), x(d);
+    for (long i = 0; i < d; i++) {
+        A[i * d + i] = cplx(4. + 0.1 * U(rng), 0.3 * U(rng));
+        if (i > 0) A[i * d + i - 1] = cplx(-1., 0.2 * U(rng));
+        if (i + 1 < d) A[i * d + i + 1] = cplx(-1. + 0.1 * U(rng), 0.);
+        if (i + 5 < d) A[i * d + i + 5] = cplx(0.25 * U(rng), 0.25 * U(rng));
+        rhs[i] = cplx(U(rng), U(rng));
+        x[i] = cplx(0.5 * U(rng), 0.5 * U(rng));
+    }
+    dump_vec("g16_A", A); dump_vec("g16_rhs", rhs); dump_vec("g16_x0", x);
+    {
+        GCR<long> g(A.data(), d);
+        std::vector<cplx> xs(x);
+        printf("LEGACY trunc3\n");
+        g.solve(rhs.data(), xs.data(), 1e-20, 40, 3);
+        dump_vec("g16_x_trunc3", xs);
+    }
+    {
+        GCR<long> g(A.data(), d);
+        std::vector<cplx> xs(x);
+        printf("LEGACY trunc8_tol\n");
+        g.solve(rhs.data(), xs.data(), 1e-12, 200, 8);       // stops on the tolerance
+        dump_vec("g16_x_trunc8", xs);
+    }
+    {   // |r0|^2 below the tolerance: zero steps, x untouched
+        GCR<long> g(A.data(), d);
+        std::vector<cplx> xs(x);
+        printf("LEGACY zero_steps\n");
+        g.solve(rhs.data(), xs.data(), 1e6, 10, 2);
+        dump_vec("g16_x_zero", xs);
+    }
+    printf("LEGACY end\n");
+    // utils BLAS on the same data
+    std::vector<cplx> z(d), y(d), Ax(d), nrm(rhs), sc(4);
+    cplx a(0.3, -0.7), b(-1.2, 0.4);
+    vec_add(a, rhs.data(), b, x.data(), z.data(), (int)d);
+    vec_amult(a, rhs.data(), y.data(), (int)d);
+    sc[0] = vec_innprod(rhs.data(), x.data(), (int)d);
+    sc[1] = vec_squarednorm(rhs.data(), (int)d);
+    vec_normalise(nrm.data(), (int)d);
+    mat_vec(A.data(), x.data(), Ax.data(), (int)d);
+    sc[2] = a; sc[3] = b;
+    dump_vec("g16_u_add", z); dump_vec("g16_u_amult", y); dump_vec("g16_u_scalars", sc); dump_vec("g16_u_normalised", nrm);
+    dump_vec("g16_u_matvec", Ax);
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s <outdir> sample|hsparse|mg|arnoldi|builders [file.mtx]|poisson <n> <iters> <tag> [trunc restart tol]|bench <n> <iters>\n", argv[0]);
+        fprintf(stderr, "usage: %s <outdir> sample|hsparse|mg|arnoldi|legacy|builders [file.mtx]|poisson <n> <iters> <tag> [trunc restart tol]|bench <n> <iters>\n", argv[0]);
         return 1;
     }
     char absout[4096];
@@ -475,6 +529,7 @@ int main(int argc, char **argv) {
     else if (c == "hsparse") case_hsparse();
     else if (c == "mg") case_mg();
     else if (c == "arnoldi") case_arnoldi();
+    else if (c == "legacy") case_legacy();
     else if (c == "builders") case_builders(argc >= 4 ? argv[3] : "");
     else if (c == "poisson" && argc >= 9) case_poisson(atol(argv[3]), atoi(argv[4]), argv[5], false, atoi(argv[6]), atoi(argv[7]), atof(argv[8]));
     else if (c == "poisson" && argc >= 6) case_poisson(atol(argv[3]), atoi(argv[4]), argv[5], false);

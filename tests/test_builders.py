@@ -130,3 +130,66 @@ def test_operator_classes_apply_what_the_algebra_built(gold):
     for op, ref in ((A * B, An @ Bn), (A + B, An + Bn), (A.dagger(), An.conj().T)):
         assert np.abs(op(Field((d,), z)).to_numpy() - ref @ z).max() <= 1e-13 * np.abs(ref).sum()
     assert np.array_equal((A * B).mat.ravel(), g["dense_AB"])
+
+
+@pytest.fixture(scope="module")
+def legacy_gold():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "legacy_dense.npz")))
+
+
+def _legacy_inputs(g, d):
+    for name, key in (("A", "A"), ("rhs", "rhs"), ("x0", "x0")):
+        np.asarray(g[key], np.complex128).tofile(os.path.join(d, name + ".bin"))
+    np.asarray(g["u_scalars"][2:4], np.complex128).tofile(os.path.join(d, "ab.bin"))
+
+
+def test_utils_blas_matches_reference(legacy_gold, tmp_path):
+    """src/utils.cpp:8-90 through include/mgcr/utils.h (host loops, index order): bit for bit."""
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    g, d = legacy_gold, str(tmp_path)
+    _legacy_inputs(g, d)
+    p = subprocess.run([os.path.join(ROOT, "examples", "build", "legacy_check"), d, "utils-only"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rd = lambda n: np.fromfile(os.path.join(d, "out_u_" + n + ".bin"), dtype=np.complex128)  # noqa: E731
+    assert np.array_equal(rd("add"), g["u_add"]) and np.array_equal(rd("amult"), g["u_amult"])
+    assert np.array_equal(rd("scalars"), g["u_scalars"][:2])
+    assert np.array_equal(rd("normalised"), g["u_normalised"]) and np.array_equal(rd("matvec"), g["u_matvec"])
+
+
+@pytest.mark.gpu
+def test_legacy_dense_gcr_matches_reference(legacy_gold, tmp_path):
+    """The legacy raw-pointer dense GCR (src/GCR.h:70-156) on the device, through both mirrors, against the real
+    reference: the printed norms (11 digits) and the final x.  The dot products are summed by wave trees instead of in
+    index order, so agreement is to rounding amplified by the recurrence (stated: 1e-9 on the printed norms while they
+    are >= 1e-6 of the first, 1e-7 relative to |x| on x), the step counts exactly."""
+    import re
+    import mgpreconditionedgcr_amd as mg
+    mg.init()
+    g, d = legacy_gold, str(tmp_path)
+    _legacy_inputs(g, d)
+    p = subprocess.run([os.path.join(ROOT, "examples", "build", "legacy_check"), d], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    printed, cur = {}, None
+    for line in p.stdout.splitlines():
+        if line.startswith("LEGACY "):
+            cur = line.split()[1]
+            printed[cur] = []
+        elif line.startswith("Step ") and cur:
+            printed[cur].append(float(line.split("=")[1]))
+    n = int(g["rhs"].size)
+    for tag, tol, max_iter, trunc in (("trunc3", 1e-20, 40, 3), ("trunc8", 1e-12, 200, 8), ("zero", 1e6, 10, 2)):
+        ref = g["printed_" + tag]
+        xr = g["x_" + tag]
+        x_py, norms = mg.legacy_dense_gcr(g["A"].reshape(n, n), g["rhs"], g["x0"], tol, max_iter, trunc, verbose=False)
+        x_cpp = np.fromfile(os.path.join(d, "out_x_" + tag + ".bin"), dtype=np.complex128)
+        for who, hist, x in (("python", norms, x_py), ("c++", np.array(printed[tag]), x_cpp)):
+            assert hist.size == ref.size, (tag, who, hist.size, ref.size)      # same number of steps (0 for `zero`)
+            if ref.size:
+                big = ref >= 1e-6 * ref[0]
+                assert np.abs(hist[big] - ref[big]).max() <= 1e-9 * ref[0] + 5e-11 * ref[big].max(), (tag, who)
+                assert np.abs(hist - ref).max() <= 1e-6 * ref[0], (tag, who)
+            assert np.abs(x - xr).max() <= 1e-7 * np.abs(xr).max(), (tag, who)
+        if tag == "zero":
+            assert np.array_equal(x_py, g["x0"]) and np.array_equal(x_cpp, g["x0"])     # untouched
+    assert re.search(r"GCR did not converge after 40 steps! Residual norm = ", p.stdout)
