@@ -774,3 +774,81 @@ def test_solver_object_is_reusable_and_reads_params_at_solve_time():
     x4 = Field((N,)).set_zero()
     gcr.solve(b, x4)
     assert np.array_equal(gcr.last_history, h1) and np.array_equal(x4.to_numpy(), x1.to_numpy())  # run-to-run reproducible
+
+
+def _stencil_csr(dims, offsets_nd, vals):
+    """Constant-coefficient stencil on a row-major grid with truncated boundaries: entry (p, p + o) exists iff p + o stays
+    inside the grid in every dimension; columns ascending within a row."""
+    dims = tuple(int(d) for d in dims)
+    N = int(np.prod(dims))
+    idx = np.indices(dims).reshape(len(dims), -1)
+    strides = np.array([int(np.prod(dims[d + 1:])) for d in range(len(dims))], np.int64)
+    lin = [(int(np.dot(o, strides)), o, v) for o, v in zip(offsets_nd, vals)]
+    lin.sort(key=lambda t: t[0])
+    masks, cols, vs = [], [], []
+    rows = np.arange(N, dtype=np.int64)
+    for lo, o, v in lin:
+        ok = np.ones(N, bool)
+        for d in range(len(dims)):
+            ok &= (idx[d] + o[d] >= 0) & (idx[d] + o[d] < dims[d])
+        masks.append(ok)
+        cols.append(rows + lo)
+        vs.append(v)
+    mask = np.stack(masks, axis=1)
+    rowptr = np.zeros(N + 1, np.int64)
+    np.cumsum(mask.sum(axis=1), out=rowptr[1:])
+    col = np.stack(cols, axis=1)[mask]
+    val = np.broadcast_to(np.array(vs, np.complex128), mask.shape)[mask]
+    return N, rowptr, col, val
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_stencil_view_random_stencils_bit_exact(seed):
+    """The stencil view (format 3) on random constant-coefficient stencils: 1 to 3 dimensions, 2 to 9 slots, complex or
+    real values, grids whose row count is no multiple of the wave, tile or workgroup sizes, near offsets that do / do not
+    reach the LDS window's threshold.  y must equal the oracle's CSR row loop bit for bit — stand-alone apply (window and
+    plain kernel), DiracOp epilogue, and inside a solve (fused apply, one-workgroup path excluded by the size) — and the
+    dictionary kernels (stencil view off) must give the same bits."""
+    rng = np.random.default_rng(900 + seed)
+    nd = int(rng.integers(1, 4))
+    if nd == 1:
+        dims = (int(rng.integers(40000, 70000)),)
+    elif nd == 2:
+        dims = (int(rng.integers(190, 300)), int(rng.integers(190, 300)))
+    else:
+        dims = (int(rng.integers(33, 46)), int(rng.integers(33, 46)), int(rng.integers(33, 46)))
+    ns = int(rng.integers(2, 10))
+    offs = {tuple([0] * nd)}
+    while len(offs) < ns:
+        offs.add(tuple(int(v) for v in rng.integers(-2 if nd > 1 else -40, 3 if nd > 1 else 41, nd)))
+    offs = sorted(offs)
+    real = seed % 3 == 0
+    vals = [complex(rng.uniform(-1, 1), 0. if real else rng.uniform(-1, 1)) for _ in offs]
+    vals[offs.index(tuple([0] * nd))] = 4.0 * ns          # dominant diagonal: the solve below converges
+    N, rowptr, col, val = _stencil_csr(dims, offs, vals)
+    assert N >= 2 ** 15
+    x = problems.rhs_grid(N, seed)
+    O = orc.csr(N, N, rowptr, col, val)
+    ref = O(x)
+    k = 0.11 - 0.07j
+    refd = orc.dirac(O, k)(x)
+    xf = Field((N,), x)
+    b = Field((N,), problems.rhs_grid(N, seed + 50))
+    outs = []
+    for stencil in (1, 0):
+        prev = mg.set_option("stencil_storage", stencil)
+        try:
+            A = Sparse(N, N, rowptr, col, val)
+            fmt, npat = A.storage_format()
+            assert fmt == (3 if stencil else 1), (fmt, npat, dims, offs)
+            if stencil:
+                assert npat == ns
+            assert np.array_equal(A(xf).to_numpy(), ref), (dims, offs)
+            assert np.array_equal(DiracOp(A, k)(xf).to_numpy(), refd), (dims, offs)
+            g = GCR(A, GCR_Param(0, 4, 12, 1e-30, False))
+            xs = Field((N,)).set_zero()
+            g.solve(b, xs)
+            outs.append((g.last_history.copy(), xs.to_numpy()))
+        finally:
+            mg.set_option("stencil_storage", prev)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
