@@ -413,7 +413,7 @@ static int sten_try(CsrDev &A) {
             pmask[(size_t)p] |= (uint16_t)(1u << s);
         }
     }
-    const int32_t stride = ns <= 8 ? 8 : 16;
+    const int32_t stride = ns <= 7 ? 8 : 16;   // the kernels are instantiated for 7 and 9 slots and read that many words per wave
     const int64_t nwaves = A.npad / 64;
     uint16_t *d_pmask = nullptr;
     unsigned long long *d_counts = nullptr;
