@@ -161,7 +161,7 @@ int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width
         const CsrDev &A = o->csr;
         int64_t slab = (int64_t)A.nchunk * A.npad * A.L;
         int64_t ell_bytes = slab * (A.ell_val_re ? 12 : 20);
-        if (csr_stencil_active(A)) ell_bytes = (A.npad / 64) * A.sten_stride * 8 + A.sten_ns * 20;   // presence words + slot table
+        if (csr_stencil_active(A)) ell_bytes = (A.npad / 64) * A.sten_stride * 8 + A.sten_kernel_ns * 20;   // presence words + slot table
         else if (A.pat_mode == 1) ell_bytes = A.npad * 2 + (int64_t)A.npat * A.W * (A.pat_real ? 12 : 20);
         else if (A.pat_mode == 2) ell_bytes = A.npad * 2 + (int64_t)A.npat * A.W * 4 + slab * (A.ell_val_re ? 8 : 16);
         if (matrix_bytes) *matrix_bytes = ell_bytes + A.tail_nnz * 20 + A.n_tail_rows * 8 + (A.n_tail_rows ? 4 : 0);

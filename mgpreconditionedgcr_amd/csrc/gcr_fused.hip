@@ -33,7 +33,7 @@ struct DotVecs {
 };
 
 template <int MODE, int WT, int NDT>
-__global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <= 7)) && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+__global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <= 7) || MODE == 4) && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                  DotVecs d, int64_t n, int nlogical, RowMap rm,
                                                                  double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
     __shared__ double lds[2 * NDT * 17];
@@ -263,12 +263,12 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm); \
         else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm);          \
     } while (0)
-#define ST_S(MODE)                                                                                   \
-    do {                                                                                             \
-        if (sten_slots(A) == 7) launch_nd<MODE, 7>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm); \
-        else launch_nd<MODE, 9>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm);                    \
-    } while (0)
-    if (csr_stencil_active(A)) { if (A.sten_rare) ST_S(4); else ST_S(3); }
+#define ST_S(MODE, NS) launch_nd<MODE, NS>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm)
+    if (csr_stencil_active(A)) {   // MODE 4: rare-tail layout (7 common + 2 rare slots)
+        if (A.sten_rare) ST_S(4, 9);
+        else if (sten_slots(A) == 7) ST_S(3, 7);
+        else ST_S(3, 9);
+    }
     else if (A.pat_mode == 1) ST_W(1);
     else if (A.pat_mode == 2) ST_W(2);
     else ST_W(0);
@@ -328,14 +328,13 @@ int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r
         else launch_xr_nd<MODE, 0>(nd, grid, lds_bytes, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,  \
                                    den_slot, slot, lc);                                                                                    \
     } while (0)
-#define SXS(MODE)                                                                                                                          \
-    do {                                                                                                                                   \
-        if (sten_slots(A) == 7) launch_xr_nd<MODE, 7>(nd, grid, 0, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, \
-                                                      strideA, den_slot, slot, lc);                                                        \
-        else launch_xr_nd<MODE, 9>(nd, grid, 0, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,     \
-                                   den_slot, slot, lc);                                                                                    \
-    } while (0)
-    if (csr_stencil_active(A)) { if (A.sten_rare) SXS(4); else SXS(3); }
+#define SXS(MODE, NS) launch_xr_nd<MODE, NS>(nd, grid, 0, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA, \
+                                             den_slot, slot, lc)
+    if (csr_stencil_active(A)) {
+        if (A.sten_rare) SXS(4, 9);
+        else if (sten_slots(A) == 7) SXS(3, 7);
+        else SXS(3, 9);
+    }
     else if (A.pat_mode == 1) SXW(1);
     else if (A.pat_mode == 2) SXW(2);
     else SXW(0);
@@ -367,8 +366,9 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
     if (csr_stencil_active(A)) {
 #define IAS(MODE, NS) hipLaunchKernelGGL((init_apply_kernel<MODE, NS>), dim3(grid), dim3(RED_THREADS), 0, ctx().stream, m, r0, aps0, b, A.nrow, g, \
                                          rm, partsA, partsR, partsN, sk.p, sk.it)
-        if (A.sten_rare) { if (sten_slots(A) == 7) IAS(4, 7); else IAS(4, 9); }
-        else { if (sten_slots(A) == 7) IAS(3, 7); else IAS(3, 9); }
+        if (A.sten_rare) IAS(4, 9);
+        else if (sten_slots(A) == 7) IAS(3, 7);
+        else IAS(3, 9);
 #undef IAS
     }
     else if (A.pat_mode == 1) { if (A.W == 7) IA(1, 7); else IA(1, 0); }

@@ -98,8 +98,10 @@ struct CsrDev {
     // ascending superset of all patterns' column offsets (sten_ns <= STEN_MAX slots), ONE value per slot, and per
     // wave of 64 rows one 64-bit presence word per slot (sten_planes[wave * sten_stride + slot], bit l = row
     // 64 * wave + l has the slot).  A row's x loads then depend on nothing but the row number.
-    int32_t sten_ns = 0, sten_stride = 0;
-    uint32_t sten_rare = 0;       // slots fewer than 1/16 of the rows have: loaded only by waves whose presence word is not 0
+    int32_t sten_ns = 0, sten_stride = 0;   // sten_ns: slots the operator has (reporting); the arrays below are in KERNEL layout:
+    int32_t sten_kernel_ns = 0;             // 7 or 9 slots (unused ones: offset 0, value 0, no presence bits)
+    uint32_t sten_rare = 0;       // non-zero: rare-tail layout — slots 0..6 common, slots 7, 8 present in fewer than 1/16 of the rows and
+                                  // behind every common slot in column order: loaded only by waves whose presence word is not 0
     int32_t sten_off[16] = {};
     double sten_re[16] = {}, sten_im[16] = {};
     uint64_t *sten_planes = nullptr;

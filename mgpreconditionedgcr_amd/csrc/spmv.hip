@@ -397,7 +397,8 @@ static int sten_try(CsrDev &A) {
     S.erase(std::unique(S.begin(), S.end()), S.end());
     const int ns = (int)S.size();
     if (ns < 1 || ns > STEN_MAX) return MGCR_OK;
-    std::vector<uint16_t> pmask((size_t)A.npat, 0);
+    // per pattern: which of the ns slots it has (bit s = slot s of the ascending list)
+    std::vector<uint16_t> pbits((size_t)A.npat, 0);
     std::vector<char> have((size_t)ns, 0);
     double sre[16] = {}, sim[16] = {};
     for (int p = 0; p < A.npat; p++) {
@@ -410,29 +411,53 @@ static int sten_try(CsrDev &A) {
             last = s;
             if (!have[(size_t)s]) { have[(size_t)s] = 1; sre[s] = re[e]; sim[s] = im[e]; }
             else if (memcmp(&sre[s], &re[e], sizeof(double)) || memcmp(&sim[s], &im[e], sizeof(double))) return MGCR_OK;  // value differs between patterns
-            pmask[(size_t)p] |= (uint16_t)(1u << s);
+            pbits[(size_t)p] |= (uint16_t)(1u << s);
         }
     }
-    const int32_t stride = ns <= 7 ? 8 : 16;   // the kernels are instantiated for 7 and 9 slots and read that many words per wave
     const int64_t nwaves = A.npad / 64;
     uint16_t *d_pmask = nullptr;
     unsigned long long *d_counts = nullptr;
     uint64_t *planes = nullptr;
-    std::vector<unsigned long long> counts(16, 0);
     bool ok = hipMalloc((void **)&d_pmask, sizeof(uint16_t) * (size_t)A.npat) == hipSuccess &&
               hipMalloc((void **)&d_counts, sizeof(unsigned long long) * 16) == hipSuccess &&
-              hipMalloc((void **)&planes, sizeof(uint64_t) * (size_t)(nwaves + 1) * stride) == hipSuccess;
-    if (ok) {
-        ok = hipMemcpyAsync(d_pmask, pmask.data(), sizeof(uint16_t) * (size_t)A.npat, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
-             hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * 16, c.stream) == hipSuccess &&
-             hipMemsetAsync(planes + (size_t)nwaves * stride, 0, sizeof(uint64_t) * stride, c.stream) == hipSuccess;
-        if (ok && nwaves) {
-            hipLaunchKernelGGL(sten_planes_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, c.stream, A.nrow, nwaves, ns,
+              hipMalloc((void **)&planes, sizeof(uint64_t) * (size_t)(nwaves + 1) * 16) == hipSuccess;
+    // presence words for the slot numbering `pm` (pattern -> mask), `stride` words per wave; counts[k] = rows that have slot k
+    auto build = [&](const std::vector<uint16_t> &pm, int nslots, int32_t stride, std::vector<unsigned long long> &counts) -> bool {
+        counts.assign(16, 0);
+        bool g = hipMemcpyAsync(d_pmask, pm.data(), sizeof(uint16_t) * (size_t)A.npat, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+                 hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * 16, c.stream) == hipSuccess &&
+                 hipMemsetAsync(planes + (size_t)nwaves * stride, 0, sizeof(uint64_t) * stride, c.stream) == hipSuccess;
+        if (g && nwaves) {
+            hipLaunchKernelGGL(sten_planes_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, c.stream, A.nrow, nwaves, nslots,
                                stride, (const uint16_t *)A.pat_id, (const uint16_t *)d_pmask, planes, d_counts);
-            ok = hipGetLastError() == hipSuccess;
+            g = hipGetLastError() == hipSuccess;
         }
-        ok = ok && hipMemcpyAsync(counts.data(), d_counts, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
-             hipStreamSynchronize(c.stream) == hipSuccess;
+        return g && hipMemcpyAsync(counts.data(), d_counts, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+               hipStreamSynchronize(c.stream) == hipSuccess;
+    };
+    std::vector<unsigned long long> counts;
+    if (ok) ok = build(pbits, ns, 16, counts);   // first pass: how many rows have each slot
+    // Layout the kernels read (spmv_dev.h sten_row_product).  Rare tail: the slots fewer than 1/16 of the rows have are the
+    // LAST one or two of the list (halo columns of a slab's first / last plane: local column nloc + slot lies behind
+    // every owned column) and at most 7 common ones remain: common slots -> 0..6, rare ones -> 7, 8.  Otherwise every slot
+    // is treated as common, 7 or 9 of them.
+    int nrare = 0;
+    while (ok && nrare < 2 && nrare < ns - 1 && (int64_t)counts[(size_t)(ns - 1 - nrare)] * 16 < A.nrow) nrare++;
+    bool tail = nrare > 0 && ns - nrare <= STEN_COMMON;
+    for (int s = 0; ok && tail && s < ns - nrare; s++)
+        if ((int64_t)counts[(size_t)s] * 16 < A.nrow) tail = false;   // a rare slot among the common ones: no special treatment
+    const bool force = ns <= STEN_COMMON && getenv("MGCR_TEST_FORCE_RARE") && atoi(getenv("MGCR_TEST_FORCE_RARE")) != 0;
+    if (force) { tail = true; nrare = 0; }   // measurement aid: a single-GPU operator through the kernels of a distributed row block
+    int slot_of[16];
+    for (int s = 0; s < ns; s++) slot_of[s] = tail && s >= ns - nrare ? STEN_COMMON + (s - (ns - nrare)) : s;
+    const int kernel_ns = tail ? 9 : ns <= 7 ? 7 : 9;
+    const int32_t stride = kernel_ns == 7 ? 8 : 16;
+    if (ok) {
+        std::vector<uint16_t> pm((size_t)A.npat, 0);
+        for (int p = 0; p < A.npat; p++)
+            for (int s = 0; s < ns; s++)
+                if (pbits[(size_t)p] >> s & 1u) pm[(size_t)p] |= (uint16_t)(1u << slot_of[s]);
+        ok = build(pm, kernel_ns, stride, counts);
     }
     hipFree(d_pmask); hipFree(d_counts);
     if (!ok) {  // no memory for the view: the dictionary kernels stay
@@ -441,23 +466,24 @@ static int sten_try(CsrDev &A) {
         return MGCR_OK;
     }
     A.sten_ns = ns;
+    A.sten_kernel_ns = kernel_ns;
     A.sten_stride = stride;
     A.sten_planes = planes;
-    A.sten_rare = 0;
+    A.sten_rare = tail ? 3u << STEN_COMMON : 0u;
+    for (int k = 0; k < 16; k++) { A.sten_off[k] = 0; A.sten_re[k] = 0.; A.sten_im[k] = 0.; }
     for (int s = 0; s < ns; s++) {
-        A.sten_off[s] = S[(size_t)s];
-        A.sten_re[s] = sre[s];
-        A.sten_im[s] = sim[s];
-        if ((int64_t)counts[(size_t)s] * 16 < A.nrow) A.sten_rare |= 1u << s;
+        A.sten_off[slot_of[s]] = S[(size_t)s];
+        A.sten_re[slot_of[s]] = sre[s];
+        A.sten_im[slot_of[s]] = sim[s];
     }
-    for (int s = ns; s < 16; s++) { A.sten_off[s] = 0; A.sten_re[s] = 0.; A.sten_im[s] = 0.; }
     // slots close to the diagonal (|offset| <= STEN_TILE / 2, e.g. +-1 and +-n of a 3-D grid up to n = 256) are read by
     // several rows of the same workgroup: the stand-alone kernel stages x once in an LDS window and serves them from there
     A.sten_near = 0;
     A.sten_halo = 0;
     for (int s = 0; s < ns; s++) {
+        if (tail && s >= ns - nrare) continue;
         const int32_t a = S[(size_t)s] < 0 ? -S[(size_t)s] : S[(size_t)s];
-        if (a <= STEN_TILE / 2 && !(A.sten_rare >> s & 1u)) { A.sten_near |= 1u << s; A.sten_halo = std::max(A.sten_halo, a); }
+        if (a <= STEN_TILE / 2) { A.sten_near |= 1u << slot_of[s]; A.sten_halo = std::max(A.sten_halo, a); }
     }
     if (A.sten_halo < 32) { A.sten_near = 0; A.sten_halo = 0; }   // only +-1-like neighbours: L1 serves those as well
     return MGCR_OK;
@@ -783,6 +809,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
                                                       const cplx *__restrict__ x, cplx *__restrict__ y, const cplx *__restrict__ w,
                                                       const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sten_smem[];
+    constexpr int NC = RARE ? STEN_COMMON : NS;   // rare-tail layout: slots NC.. are looked at after the common sum
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     const int64_t tile = xcd ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
@@ -799,12 +826,11 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
 #pragma unroll
     for (int c = 0; c < NS; c++) pl[c] = pp[c];
     auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
-    cplx xv[NS];
+    cplx xv[NC];
 #pragma unroll
-    for (int c = 0; c < NS; c++) {
+    for (int c = 0; c < NC; c++) {
         xv[c] = make_double2(0., 0.);
-        if (!(NEAR >> c & 1u) && (!RARE || !(m.sten_rare >> c & 1u)))
-            xv[c] = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
+        if (!(NEAR >> c & 1u)) xv[c] = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
     }
     const cplx own = gather_x(x, m.xh, m.n_own, clampj(rloc));
     cplx halo = make_double2(0., 0.);
@@ -814,11 +840,6 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
         halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + BLK + (t - H)));
         hidx = t < H ? t : BLK + t;
     }
-    if (RARE) {
-#pragma unroll
-        for (int c = 0; c < NS; c++)
-            if ((m.sten_rare >> c & 1u) && pl[c] != 0ull) xv[c] = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
-    }
     __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first one is waited for
     sx[H + threadIdx.x] = own;
     if (hidx >= 0) sx[hidx] = halo;
@@ -826,7 +847,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
     const int lane = (int)(threadIdx.x & 63);
     cplx sum = make_double2(0., 0.);
 #pragma unroll
-    for (int c = 0; c < NS; c++) {
+    for (int c = 0; c < NC; c++) {
         // a window entry outside the matrix is a clamped copy: only read by rows whose presence bit for the slot is clear
         const cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : xv[c];
         const bool on = (pl[c] >> lane & 1ull) != 0ull;
@@ -834,6 +855,18 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
         const cplx nsum = cadd(sum, t);
         sum.x = on ? nsum.x : sum.x;
         sum.y = on ? nsum.y : sum.y;
+    }
+    if (RARE) {
+#pragma unroll
+        for (int c = NC; c < NS; c++)
+            if (pl[c] != 0ull) {   // wave-uniform: a wave of a boundary plane
+                const cplx xr = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
+                const bool on = (pl[c] >> lane & 1ull) != 0ull;
+                const cplx t = m.realv ? make_double2(m.sten_re[c] * xr.x, m.sten_re[c] * xr.y) : cmul(make_double2(m.sten_re[c], m.sten_im[c]), xr);
+                const cplx nsum = cadd(sum, t);
+                sum.x = on ? nsum.x : sum.x;
+                sum.y = on ? nsum.y : sum.y;
+            }
     }
     if (live) y[rloc] = SHIFT ? csub((w ? w : x)[rloc], cmul(m.k, sum)) : sum;
 }
@@ -915,10 +948,12 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
                        c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
         static const bool tile_on = !(getenv("MGCR_STENCIL_TILE") && atoi(getenv("MGCR_STENCIL_TILE")) == 0);
         if (A.sten_halo > 0 && A.sten_near == 0x3eu && tile_on) {
-            if (sten_slots(A) == 7) { if (A.sten_rare) SLT(7, true); else SLT(7, false); }
-            else { if (A.sten_rare) SLT(9, true); else SLT(9, false); }
-        } else if (sten_slots(A) == 7) { if (A.sten_rare) SL(7, true); else SL(7, false); }
-        else { if (A.sten_rare) SL(9, true); else SL(9, false); }
+            if (A.sten_rare) SLT(9, true);
+            else if (sten_slots(A) == 7) SLT(7, false);
+            else SLT(9, false);
+        } else if (A.sten_rare) SL(9, true);
+        else if (sten_slots(A) == 7) SL(7, false);
+        else SL(9, false);
 #undef SLT
 #undef SL
         MGCR_HIP(hipGetLastError());

@@ -89,7 +89,7 @@ inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
     return m;
 }
 // slots the stencil kernels are instantiated for (0: no stencil view)
-inline int sten_slots(const CsrDev &A) { return A.sten_ns == 0 ? 0 : A.sten_ns <= 7 ? 7 : 9; }
+inline int sten_slots(const CsrDev &A) { return A.sten_ns == 0 ? 0 : A.sten_kernel_ns; }
 inline size_t row_mat_lds_bytes(const CsrDev &A) { return A.pat_mode == 1 ? (size_t)A.npat * A.W * (A.pat_real ? 12 : 20) : 0; }
 
 // pattern table -> LDS (MODE 1); call from every thread of the workgroup, ends with a barrier
@@ -148,38 +148,38 @@ __device__ __forceinline__ cplx row_product(const RowMat &m, int64_t row, int32_
     return sum;
 }
 
-// MODE 3.  Row `row` of A times x through the stencil view: slot c is column row + sten_off[c] (clamped into the matrix;
+// MODE 3 / 4.  Row `row` of A times x through the stencil view: slot c is column row + sten_off[c] (clamped into the matrix;
 // a clamped load is never used), present in this row iff bit (row & 63) of the wave's presence word c is set.  Slots
 // are in ascending column order = CSR order and absent ones are skipped, so the sum is the one row_product forms minus
 // its "+ 0 * x" padding terms: same bits for finite x.  The x loads depend on the row number alone — the presence
 // words arrive through the scalar cache meanwhile — where the dictionary kernels chain id -> table -> gather.
-// All 64 lanes of a wave must hold consecutive rows starting at a multiple of 64.  RARE: some slots (halo columns of
-// a distributed row block) are loaded only when the wave's presence word is not 0.
-template <int NS, bool RARE, class XF>
-__device__ __forceinline__ cplx sten_row_product(const RowMat &m, int64_t row, XF xf) {
+// All 64 lanes of a wave must hold consecutive rows starting at a multiple of 64.
+// RARE (NS = 9): slots 0..6 are the common ones, slots 7 and 8 are rarely present and lie BEHIND every common slot in
+// column order (the halo columns of a slab's first and last plane).  They are looked at after the common sum, and
+// loaded only by the waves whose presence word is not 0 — the other waves run exactly the 7-slot kernel, registers
+// included (a 9-slot kernel with all loads up front costs 3.3 us of 36 per fused apply at 128^3).
+constexpr int STEN_COMMON = 7;
+// REALV: 1 real values, 0 complex, -1 decided per slot at run time (m.realv, a uniform branch)
+template <int REALV>
+__device__ __forceinline__ cplx sten_term(const RowMat &m, int c, cplx xv) {
+    if (REALV > 0 || (REALV < 0 && m.realv)) return make_double2(m.sten_re[c] * xv.x, m.sten_re[c] * xv.y);
+    return cmul(make_double2(m.sten_re[c], m.sten_im[c]), xv);
+}
+template <int NS, bool RARE, int REALV, class XF>
+__device__ __forceinline__ cplx sten_row_product_t(const RowMat &m, int64_t row, XF xf) {
+    static_assert(!RARE || NS == 9, "the rare-tail layout has 7 common + 2 rare slots");
+    constexpr int NC = RARE ? STEN_COMMON : NS;
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(row >> 6));
     const uint64_t *pp = m.sten_planes + (int64_t)wave * m.sten_stride;
     uint64_t pl[NS];
 #pragma unroll
     for (int c = 0; c < NS; c++) pl[c] = pp[c];
-    cplx xv[NS];
+    cplx xv[NC];
 #pragma unroll
-    for (int c = 0; c < NS; c++) {
-        xv[c] = make_double2(0., 0.);
-        if (!RARE || !(m.sten_rare >> c & 1u)) {
-            int32_t j = (int32_t)row + m.sten_off[c];
-            j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
-            xv[c] = xf(j);
-        }
-    }
-    if (RARE) {
-#pragma unroll
-        for (int c = 0; c < NS; c++)
-            if ((m.sten_rare >> c & 1u) && pl[c] != 0ull) {
-                int32_t j = (int32_t)row + m.sten_off[c];
-                j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
-                xv[c] = xf(j);
-            }
+    for (int c = 0; c < NC; c++) {
+        int32_t j = (int32_t)row + m.sten_off[c];
+        j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
+        xv[c] = xf(j);
     }
     // the presence bits must not be looked at before every load is in flight (the scheduler would otherwise
     // wait for them first and serialise the two round trips)
@@ -187,15 +187,34 @@ __device__ __forceinline__ cplx sten_row_product(const RowMat &m, int64_t row, X
     const int lane = (int)(threadIdx.x & 63);
     cplx sum = make_double2(0., 0.);
 #pragma unroll
-    for (int c = 0; c < NS; c++) {
+    for (int c = 0; c < NC; c++) {
         const bool on = (pl[c] >> lane & 1ull) != 0ull;
-        const cplx t = m.realv ? make_double2(m.sten_re[c] * xv[c].x, m.sten_re[c] * xv[c].y)
-                               : cmul(make_double2(m.sten_re[c], m.sten_im[c]), xv[c]);
-        const cplx nsum = cadd(sum, t);
+        const cplx nsum = cadd(sum, sten_term<REALV>(m, c, xv[c]));
         sum.x = on ? nsum.x : sum.x;
         sum.y = on ? nsum.y : sum.y;
     }
+    if (RARE) {
+#pragma unroll
+        for (int c = NC; c < NS; c++)
+            if (pl[c] != 0ull) {   // wave-uniform
+                int32_t j = (int32_t)row + m.sten_off[c];
+                j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
+                const cplx xr = xf(j);
+                const bool on = (pl[c] >> lane & 1ull) != 0ull;
+                const cplx nsum = cadd(sum, sten_term<REALV>(m, c, xr));
+                sum.x = on ? nsum.x : sum.x;
+                sum.y = on ? nsum.y : sum.y;
+            }
+    }
     return sum;
+}
+template <int NS, bool RARE, class XF>
+__device__ __forceinline__ cplx sten_row_product(const RowMat &m, int64_t row, XF xf) {
+    // Real or complex slot values: the rare-tail kernels branch once per row (two copies of the body: 37.3 against 38.6 us
+    // per fused apply at 128^3); the plain ones decide per slot — with two copies of THEIR body the fused kernels spill
+    // (188 B of scratch, 128 us instead of 36).
+    if constexpr (RARE) return m.realv ? sten_row_product_t<NS, RARE, 1>(m, row, xf) : sten_row_product_t<NS, RARE, 0>(m, row, xf);
+    else return sten_row_product_t<NS, RARE, -1>(m, row, xf);
 }
 
 // the row product of the GCR step kernels (gcr_fused.hip): MODE 0..2 as above, 3 / 4 = stencil view without / with

@@ -852,3 +852,26 @@ def test_stencil_view_random_stencils_bit_exact(seed):
         finally:
             mg.set_option("stencil_storage", prev)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_rare_tail_stencil_kernels_same_bits(monkeypatch):
+    """The kernels a distributed row block uses (stencil view in its rare-tail layout: 7 common slots + 2 rarely present
+    ones looked at after the common sum — MODE 4 of the fused apply, sten_spmv<9, true>) run here on a single-GPU operator
+    (MGCR_TEST_FORCE_RARE: the two extra slots have no presence bits): apply, DiracOp epilogue and a whole solve must
+    have the bits of the 7-slot kernels.  (With real rare slots they are exercised by tests/test_gpu_dist.py, 48^3.)"""
+    n = 40
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    val = val * (0.9 + 0.3j)
+    x = Field((N,), problems.rhs_grid(N, 4))
+    b = Field((N,), problems.rhs_grid(N, 5))
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("MGCR_TEST_FORCE_RARE", force)
+        A = Sparse(N, ncol, rowptr, col, val)
+        assert A.storage_format() == (3, 7)
+        g = GCR(A, GCR_Param(0, 5, 23, 1e-30, False))
+        xs = Field((N,)).set_zero()
+        g.solve(b, xs)
+        out.append((A(x).to_numpy(), DiracOp(A, 0.2 - 0.1j)(x).to_numpy(), g.last_history.copy(), xs.to_numpy()))
+    for a, c in zip(out[0], out[1]):
+        assert np.array_equal(a, c)
