@@ -75,13 +75,41 @@ struct LeanCoef {
 struct RowMap {
     int64_t band;  // rows per band (multiple of RED_THREADS); 0 = not banded
     int per;       // logical workgroups per band
+    int xg;        // not banded: consecutive logical workgroups per XCD (0: one contiguous run of grid / 8 per XCD and trip)
 };
+// Logical workgroup of physical workgroup b (the hardware deals workgroups round-robin over the 8 XCDs, b & 7) for the
+// fused apply kernels (gcr_fused.hip); partial sums are indexed by the logical number, so results do not depend on it.
+// xg = 0: XCD x owns the contiguous run [x * per, (x + 1) * per) of every trip.  xg = G > 0: XCDs take turns, G logical
+// workgroups at a time — a row's far neighbours (rows +- n^2 of a 3-D grid = +- 16 workgroups at 128^3) then belong to
+// the SAME XCD when (workgroups per plane / G) is a multiple of 8, and only the +- n rows at the ends of a run of G
+// workgroups are fetched by two L2s.
+__device__ __forceinline__ int logical_workgroup(const RowMap &rm, int b, int grid) {
+    if (grid & 7) return b;
+    const int x = b & 7, q = b >> 3;
+    if (rm.xg > 0 && !rm.band) return (q / rm.xg) * (8 * rm.xg) + x * rm.xg + (q % rm.xg);
+    return x * (grid >> 3) + q;
+}
 // `reach` = how far a row's gathers go (CsrDev::reach; 0 = unknown).  Banding pays when that is a sizeable part of
 // what one XCD covers per trip of a plain grid-stride (Poisson 256^3: 65536 of 65536 rows — 1 170 against 1 130 it/s);
 // when the neighbours mostly stay inside the XCD's slice anyway (128^3: 16384 of 65536) the single sweep front of
 // the plain map is faster (9.8 k against 9.4 k it/s).
 inline RowMap make_row_map(int64_t n, int g, int64_t reach) {
-    RowMap m{0, 0};
+    RowMap m{0, 0, 0};
+    if (g >= 64 && g % 8 == 0) {
+        // XCDs take turns G logical workgroups at a time, G chosen so that a row's farthest neighbours (reach rows away =
+        // P workgroups) belong to the same XCD: P a multiple of 8 G.  Poisson 128^3 (P = 16, G = 2), fused apply + dots:
+        // 34.8 us against 35.9 with one contiguous run per XCD and trip (G = 64), 35.0 with G = 1, 37.1 / 40.5 with G = 4 / 8.
+        // MGCR_XCD_GROUP overrides (0 = contiguous run).
+        static const int xg_env = getenv("MGCR_XCD_GROUP") ? atoi(getenv("MGCR_XCD_GROUP")) : -1;
+        const int per = g / 8;
+        if (xg_env >= 0) {
+            if (xg_env == 0 || per % xg_env == 0) m.xg = xg_env;
+        } else if (reach > 0 && reach % RED_THREADS == 0 && (reach / RED_THREADS) % 8 == 0) {
+            int64_t a = reach / RED_THREADS / 8, b = per;   // G = gcd(P / 8, per)
+            while (b) { const int64_t t = a % b; a = b; b = t; }
+            m.xg = (int)a;
+        }
+    }
     const int64_t slice = (int64_t)g * RED_THREADS / 8;
     const bool wide = reach > 0 ? 2 * reach >= slice : n >= ((int64_t)1 << 23);
     if (g >= 64 && g % 8 == 0 && wide) {

@@ -40,8 +40,7 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     if (skip && skip[0] < skip[1] + skip_it) return;
     // logical workgroup number: XCD x (physical b & 7) owns the band [x * per, (x + 1) * per)
-    const int per = (int)(gridDim.x >> 3);
-    const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     if (lb >= nlogical) return;
     const int32_t W = WT ? WT : m.W;
     // rows of this logical workgroup's threads: RowMap (gcr_dev.h), the map multidot_kernel uses
@@ -98,8 +97,7 @@ __global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m,
     __shared__ double lds[(2 * NDT + 1) * 17 > 4 * 17 ? (2 * NDT + 1) * 17 : 4 * 17];
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     if (st->stop_at < st->base + it) return;
-    const int per = (int)(gridDim.x >> 3);
-    const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     // alpha and its bookkeeping: xr_update_kernel<true, true>'s prologue
     double sa[4];
     fold_partials<4>(partsA, nblkA, strideA, sa, lds);
@@ -159,8 +157,7 @@ __global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, co
     __shared__ double lds[6 * 17];
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     if (skip && skip[0] < skip[1] + skip_it) return;
-    const int per = (int)(gridDim.x >> 3);
-    const int lb = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     if (lb >= nlogical) return;
     const int32_t W = WT ? WT : m.W;
     int64_t i, end, stride;

@@ -486,6 +486,12 @@ static int sten_try(CsrDev &A) {
         if (a <= STEN_TILE / 2) { A.sten_near |= 1u << slot_of[s]; A.sten_halo = std::max(A.sten_halo, a); }
     }
     if (A.sten_halo < 32) { A.sten_near = 0; A.sten_halo = 0; }   // only +-1-like neighbours: L1 serves those as well
+    if (tail) {
+        // how far a row's gathers reach decides the row -> workgroup map of the GCR step kernels (gcr_dev.h): the two
+        // rare slots (halo columns, "nloc rows away") concern one plane each and must not count
+        A.reach = 0;
+        for (int s = 0; s < ns - nrare; s++) A.reach = std::max<int64_t>(A.reach, S[(size_t)s] < 0 ? -(int64_t)S[(size_t)s] : (int64_t)S[(size_t)s]);
+    }
     return MGCR_OK;
 }
 
