@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
     // presence words of this wave (rows beyond the padded end of the matrix have none: the planes array ends with a zero row)
     int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
     wave = wave < m.sten_nwaves ? wave : m.sten_nwaves;
-    const uint64_t *pp = m.sten_planes + (int64_t)wave * m.sten_stride;
+    const sten_planes_ptr pp = sten_wave_planes(m, wave);
     uint64_t pl[NS];
 #pragma unroll
     for (int c = 0; c < NS; c++) pl[c] = pp[c];

@@ -159,6 +159,14 @@ __device__ __forceinline__ cplx row_product(const RowMat &m, int64_t row, int32_
 // loaded only by the waves whose presence word is not 0 — the other waves run exactly the 7-slot kernel, registers
 // included (a 9-slot kernel with all loads up front costs 3.3 us of 36 per fused apply at 128^3).
 constexpr int STEN_COMMON = 7;
+// The presence words never change while a kernel runs: read them through the CONSTANT address space, which makes the
+// compiler use scalar loads (s_load) everywhere.  From a plain global pointer it does so only where it can prove that no
+// store of the kernel precedes the load — in the fused step kernels that held for some direction counts and not for
+// others (vector loads of 14 VGPRs instead).
+typedef const uint64_t __attribute__((address_space(4))) *sten_planes_ptr;
+__device__ __forceinline__ sten_planes_ptr sten_wave_planes(const RowMat &m, int32_t wave) {
+    return (sten_planes_ptr)(uintptr_t)(m.sten_planes + (int64_t)wave * m.sten_stride);
+}
 // REALV: 1 real values, 0 complex, -1 decided per slot at run time (m.realv, a uniform branch)
 template <int REALV>
 __device__ __forceinline__ cplx sten_term(const RowMat &m, int c, cplx xv) {
@@ -170,7 +178,7 @@ __device__ __forceinline__ cplx sten_row_product_t(const RowMat &m, int64_t row,
     static_assert(!RARE || NS == 9, "the rare-tail layout has 7 common + 2 rare slots");
     constexpr int NC = RARE ? STEN_COMMON : NS;
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(row >> 6));
-    const uint64_t *pp = m.sten_planes + (int64_t)wave * m.sten_stride;
+    const sten_planes_ptr pp = sten_wave_planes(m, wave);
     uint64_t pl[NS];
 #pragma unroll
     for (int c = 0; c < NS; c++) pl[c] = pp[c];
