@@ -79,6 +79,109 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <
 }
 
 
+// The same step for an operator with a stencil view whose near slots are slots 1..5 of 7 (a 3-D grid up to n = 256: +-1, +-n
+// within STEN_TILE / 2 rows; spmv.hip sten_try), with the workgroup's 1024 entries of x per trip staged in an LDS window
+// (+ halo) that serves those five slots: a row then issues ONE coalesced load of its own entry, the two far gathers and
+// — registers now allowing it — its direction streams TOGETHER, i.e. one memory round trip per trip instead of two, and
+// 3.5 instead of 7 loads per row go through L1 / L2.  Two window buffers alternate, so one barrier per trip suffices (a
+// thread can only start writing trip k + 1's buffer — trip k - 1's — after every thread has passed trip k's barrier, i.e.
+// finished reading trip k - 1).  Same row arithmetic and the same per-thread accumulation order as step_apply_kernel:
+// same bits.  Measured on MI355X (fused apply + dots, microseconds): Poisson 256^3 275 against 312 — every plane of x is
+// otherwise fetched about twice there —, 128^3 35.7 against 34.1: the window is used where rows reach at least 2^15 rows
+// (csr_step_apply).  EARLY (the direction streams requested together with the gathers, one memory round trip per
+// trip) spills at 64 VGPRs and loses: 42 us at 128^3; kept as a switch.
+template <int NS, bool RARE, int NDT>
+__global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                                                        DotVecs d, int64_t n, int nlogical, RowMap rm,
+                                                                                        double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
+    __shared__ double lds[2 * NDT * 17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
+    constexpr unsigned NEAR = 0x3eu;
+    constexpr int NC = STEN_COMMON;
+    constexpr bool EARLY = false;
+    static_assert(NS == 7 || (RARE && NS == 9), "7 common slots, optionally 2 rare ones behind them");
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
+    if (lb >= nlogical) return;
+    int64_t i, end, stride;
+    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    const int32_t H = m.sten_halo_f;
+    cplx *win = reinterpret_cast<cplx *>(step_smem);   // 2 x [H + RED_THREADS + H]
+    const int wlen = RED_THREADS + 2 * H;
+    auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
+    const int lane = (int)(threadIdx.x & 63);
+    double v[2 * NDT];
+#pragma unroll
+    for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
+    int buf = 0;
+    for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {   // uniform trip count per workgroup
+        const bool live = i < end;
+        const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
+        const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
+        uint64_t pl[NS];
+#pragma unroll
+        for (int c = 0; c < NS; c++) pl[c] = pp[c];
+        const cplx own = gather_x(x, m.xh, m.n_own, clampj(i));
+        const cplx far0 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
+        const cplx far6 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[6]));
+        cplx halo = make_double2(0., 0.);
+        int hidx = -1;
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + RED_THREADS + (t - H)));
+            hidx = t < H ? t : RED_THREADS + t;
+        }
+        cplx b[NDT];
+        if (EARLY) {
+#pragma unroll
+            for (int j = 0; j < NDT; j++) b[j] = live ? ld_stream<true>(d.v[j] + i) : make_double2(0., 0.);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before anything is waited for
+        cplx *sx = win + buf * wlen;
+        sx[H + threadIdx.x] = own;
+        if (hidx >= 0) sx[hidx] = halo;
+        __syncthreads();
+        cplx sum = make_double2(0., 0.);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? far0 : far6);
+            const bool on = (pl[c] >> lane & 1ull) != 0ull;
+            const cplx nsum = cadd(sum, sten_term<-1>(m, c, xv));
+            sum.x = on ? nsum.x : sum.x;
+            sum.y = on ? nsum.y : sum.y;
+        }
+        if (RARE) {
+#pragma unroll
+            for (int c = NC; c < NS; c++)
+                if (pl[c] != 0ull) {   // wave-uniform: a wave of a boundary plane
+                    const cplx xr = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[c]));
+                    const bool on = (pl[c] >> lane & 1ull) != 0ull;
+                    const cplx nsum = cadd(sum, sten_term<-1>(m, c, xr));
+                    sum.x = on ? nsum.x : sum.x;
+                    sum.y = on ? nsum.y : sum.y;
+                }
+        }
+        const cplx yi = m.shift ? csub(own, cmul(m.k, sum)) : sum;
+        if (live) y[i] = yi;
+        if (!EARLY) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NDT; j++) b[j] = live ? ld_stream<true>(d.v[j] + i) : make_double2(0., 0.);
+        }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NDT; j++) {
+                cplx t = cconj_mul(yi, b[j]);
+                v[2 * j] += t.x;
+                v[2 * j + 1] += t.y;
+            }
+        }
+    }
+    const double mine = block_sum_owner<2 * NDT>(v, lds);
+    if (threadIdx.x < 2 * NDT) parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+}
+
+
 // Latency regime (systems of up to 2^19 rows: every kernel is one wave of workgroups and costs its launch, a fold,
 // one memory round trip and a reduction, ~5 us, whatever it moves): the residual update of the step runs INSIDE the
 // apply kernel.  alpha is folded from the <r,Ap>, <Ap,Ap> partials, r' = r - alpha Ap is formed for the row itself
@@ -195,6 +298,96 @@ __global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, co
     if (threadIdx.x == 5 && b) partsN[lb] = mine;
 }
 
+
+// init_apply_kernel with the LDS window of step_apply_tile_kernel (same conditions, same bits)
+template <int NS, bool RARE>
+__global__ void __launch_bounds__(RED_THREADS, 4) init_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                                         const cplx *__restrict__ b, int64_t n, int nlogical, RowMap rm,
+                                                                         double *__restrict__ partsA, double *__restrict__ partsR,
+                                                                         double *__restrict__ partsN, const int *__restrict__ skip, int skip_it) {
+    __shared__ double lds[6 * 17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
+    constexpr unsigned NEAR = 0x3eu;
+    constexpr int NC = STEN_COMMON;
+    static_assert(NS == 7 || (RARE && NS == 9), "7 common slots, optionally 2 rare ones behind them");
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
+    if (lb >= nlogical) return;
+    int64_t i, end, stride;
+    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    const int32_t H = m.sten_halo_f;
+    cplx *win = reinterpret_cast<cplx *>(step_smem);
+    const int wlen = RED_THREADS + 2 * H;
+    auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
+    const int lane = (int)(threadIdx.x & 63);
+    double v[6] = {0., 0., 0., 0., 0., 0.};
+    int buf = 0;
+    for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
+        const bool live = i < end;
+        const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
+        const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
+        uint64_t pl[NS];
+#pragma unroll
+        for (int c = 0; c < NS; c++) pl[c] = pp[c];
+        const cplx own = gather_x(x, m.xh, m.n_own, clampj(i));
+        const cplx far0 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
+        const cplx far6 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[6]));
+        cplx halo = make_double2(0., 0.);
+        int hidx = -1;
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + RED_THREADS + (t - H)));
+            hidx = t < H ? t : RED_THREADS + t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cplx *sx = win + buf * wlen;
+        sx[H + threadIdx.x] = own;
+        if (hidx >= 0) sx[hidx] = halo;
+        __syncthreads();
+        cplx sum = make_double2(0., 0.);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? far0 : far6);
+            const bool on = (pl[c] >> lane & 1ull) != 0ull;
+            const cplx nsum = cadd(sum, sten_term<-1>(m, c, xv));
+            sum.x = on ? nsum.x : sum.x;
+            sum.y = on ? nsum.y : sum.y;
+        }
+        if (RARE) {
+#pragma unroll
+            for (int c = NC; c < NS; c++)
+                if (pl[c] != 0ull) {
+                    const cplx xr = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[c]));
+                    const bool on = (pl[c] >> lane & 1ull) != 0ull;
+                    const cplx nsum = cadd(sum, sten_term<-1>(m, c, xr));
+                    sum.x = on ? nsum.x : sum.x;
+                    sum.y = on ? nsum.y : sum.y;
+                }
+        }
+        if (live) {
+            const cplx rv = own;
+            const cplx yi = m.shift ? csub(rv, cmul(m.k, sum)) : sum;
+            y[i] = yi;
+            v[4] += rv.x * rv.x + rv.y * rv.y;
+            const cplx t = cconj_mul(rv, yi);
+            v[0] += t.x; v[1] += t.y;
+            const cplx u = cconj_mul(yi, yi);
+            v[2] += u.x; v[3] += u.y;
+            if (b) {
+                const cplx bv = ld_stream<true>(b + i);
+                v[5] += bv.x * bv.x + bv.y * bv.y;
+            }
+        }
+    }
+    const double mine = block_sum_owner<6>(v, lds);
+    if (threadIdx.x < 4) partsA[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    if (threadIdx.x == 4) {
+        partsR[lb] = mine;
+        if (!b) partsN[lb] = mine;
+    }
+    if (threadIdx.x == 5 && b) partsN[lb] = mine;
+}
+
 static int g_fuse = -1;
 static bool fuse_enabled() {
     if (g_fuse < 0) g_fuse = !(getenv("MGCR_FUSE") && atoi(getenv("MGCR_FUSE")) == 0);
@@ -234,6 +427,42 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
 #undef SK
 }
 
+template <int NS, bool RARE>
+static void launch_tile_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *x, cplx *y, const DotVecs &d, int64_t n,
+                           int g, double *parts, SkipRef sk, const RowMap &rm) {
+#define SKT(NDT)                                                                                                              \
+    do {                                                                                                                      \
+        static bool big_lds = false;   /* up to 2 x 2048 x 16 B of window + the reduction scratch: above the 64 KiB default */ \
+        if (!big_lds) {                                                                                                       \
+            hipFuncSetAttribute((const void *)step_apply_tile_kernel<NS, RARE, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            big_lds = true;                                                                                                   \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((step_apply_tile_kernel<NS, RARE, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
+                           g, rm, parts, sk.p, sk.it);                                                                        \
+    } while (0)
+    switch (nd) {
+        case 1: SKT(1); break;
+        case 2: SKT(2); break;
+        case 3: SKT(3); break;
+        case 4: SKT(4); break;
+        case 5: SKT(5); break;
+        case 6: SKT(6); break;
+        case 7: SKT(7); break;
+        case 8: SKT(8); break;
+        case 9: SKT(9); break;
+        default: SKT(10); break;
+    }
+#undef SKT
+}
+static int64_t fused_tile_min_reach() {
+    static const int64_t r = getenv("MGCR_FUSED_TILE_REACH") ? atoll(getenv("MGCR_FUSED_TILE_REACH")) : (int64_t)1 << 15;
+    return r;
+}
+static bool fused_tile_enabled() {
+    static const bool on = !(getenv("MGCR_FUSED_TILE") && atoi(getenv("MGCR_FUSED_TILE")) == 0);
+    return on;
+}
+
 // y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= FND, laid out like gcr.hip's partsB;
 // dist: A is this rank's row block, the halo exchange of x is enqueued first
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
@@ -261,7 +490,13 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm);          \
     } while (0)
 #define ST_S(MODE, NS) launch_nd<MODE, NS>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm)
-    if (csr_stencil_active(A)) {   // MODE 4: rare-tail layout (7 common + 2 rare slots)
+    if (csr_stencil_active(A) && A.sten_near_f == 0x3eu && A.sten_halo_f > 0 && (A.sten_rare || sten_slots(A) == 7) && fused_tile_enabled() &&
+        A.reach >= fused_tile_min_reach()) {
+        // 3-D stencil: x staged in an LDS window per trip (step_apply_tile_kernel)
+        const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
+        if (A.sten_rare) launch_tile_nd<9, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
+        else launch_tile_nd<7, false>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
+    } else if (csr_stencil_active(A)) {   // MODE 4: rare-tail layout (7 common + 2 rare slots)
         if (A.sten_rare) ST_S(4, 9);
         else if (sten_slots(A) == 7) ST_S(3, 7);
         else ST_S(3, 9);
@@ -360,7 +595,22 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
 #define IA(MODE, WT)                                                                                                            \
     hipLaunchKernelGGL((init_apply_kernel<MODE, WT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r0, aps0, b, A.nrow, g, \
                        rm, partsA, partsR, partsN, sk.p, sk.it)
-    if (csr_stencil_active(A)) {
+    if (csr_stencil_active(A) && A.sten_near_f == 0x3eu && A.sten_halo_f > 0 && (A.sten_rare || sten_slots(A) == 7) && fused_tile_enabled() &&
+        A.reach >= fused_tile_min_reach()) {
+        const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
+#define IAT(NS, RARE)                                                                                                               \
+    do {                                                                                                                            \
+        static bool big_lds = false;                                                                                                \
+        if (!big_lds) {                                                                                                             \
+            hipFuncSetAttribute((const void *)init_apply_tile_kernel<NS, RARE>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            big_lds = true;                                                                                                         \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((init_apply_tile_kernel<NS, RARE>), dim3(grid), dim3(RED_THREADS), win, ctx().stream, m, r0, aps0, b, A.nrow, g, rm, \
+                           partsA, partsR, partsN, sk.p, sk.it);                                                                    \
+    } while (0)
+        if (A.sten_rare) IAT(9, true); else IAT(7, false);
+#undef IAT
+    } else if (csr_stencil_active(A)) {
 #define IAS(MODE, NS) hipLaunchKernelGGL((init_apply_kernel<MODE, NS>), dim3(grid), dim3(RED_THREADS), 0, ctx().stream, m, r0, aps0, b, A.nrow, g, \
                                          rm, partsA, partsR, partsN, sk.p, sk.it)
         if (A.sten_rare) IAS(4, 9);

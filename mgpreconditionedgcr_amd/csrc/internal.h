@@ -107,6 +107,8 @@ struct CsrDev {
     uint64_t *sten_planes = nullptr;
     uint32_t sten_near = 0;       // slots within STEN_TILE / 2 rows of the diagonal: the stand-alone SpMV serves them from an LDS window
     int32_t sten_halo = 0;        // largest |offset| among them (0: no window)
+    uint32_t sten_near_f = 0;     // the same for the fused GCR step kernels, whose window spans RED_THREADS rows: within RED_THREADS / 2
+    int32_t sten_halo_f = 0;
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]

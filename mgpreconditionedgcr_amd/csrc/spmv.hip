@@ -486,6 +486,14 @@ static int sten_try(CsrDev &A) {
         if (a <= STEN_TILE / 2) { A.sten_near |= 1u << slot_of[s]; A.sten_halo = std::max(A.sten_halo, a); }
     }
     if (A.sten_halo < 32) { A.sten_near = 0; A.sten_halo = 0; }   // only +-1-like neighbours: L1 serves those as well
+    A.sten_near_f = 0;
+    A.sten_halo_f = 0;
+    for (int s = 0; s < ns; s++) {
+        if (tail && s >= ns - nrare) continue;
+        const int32_t a = S[(size_t)s] < 0 ? -S[(size_t)s] : S[(size_t)s];
+        if (a <= RED_THREADS / 2) { A.sten_near_f |= 1u << slot_of[s]; A.sten_halo_f = std::max(A.sten_halo_f, a); }
+    }
+    if (A.sten_halo_f < 32) { A.sten_near_f = 0; A.sten_halo_f = 0; }
     if (tail) {
         // how far a row's gathers reach decides the row -> workgroup map of the GCR step kernels (gcr_dev.h): the two
         // rare slots (halo columns, "nloc rows away") concern one plane each and must not count

@@ -68,7 +68,7 @@ struct RowMat {
     // MODE 3: stencil view (CsrDev::sten_*)
     int32_t sten_ns, sten_stride, sten_last;   // slots, presence words per wave, last column (clamp)
     uint32_t sten_rare, sten_near;
-    int32_t sten_halo, sten_nwaves;   // sten_planes holds sten_nwaves rows + one all-zero row
+    int32_t sten_halo, sten_halo_f, sten_nwaves;   // sten_planes holds sten_nwaves rows + one all-zero row
     int32_t sten_off[STEN_MAX];
     double sten_re[STEN_MAX], sten_im[STEN_MAX];
     const uint64_t *sten_planes;
@@ -83,7 +83,7 @@ inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
     m.shift = shift ? 1 : 0; m.k = k;
     m.xh = nullptr; m.n_own = INT32_MAX;
     m.sten_ns = A.sten_ns; m.sten_stride = A.sten_stride; m.sten_last = (int32_t)A.ncol - 1; m.sten_rare = A.sten_rare;
-    m.sten_near = A.sten_near; m.sten_halo = A.sten_halo; m.sten_nwaves = (int32_t)(A.npad / 64);
+    m.sten_near = A.sten_near; m.sten_halo = A.sten_halo; m.sten_halo_f = A.sten_halo_f; m.sten_nwaves = (int32_t)(A.npad / 64);
     for (int c = 0; c < STEN_MAX; c++) { m.sten_off[c] = A.sten_off[c]; m.sten_re[c] = A.sten_re[c]; m.sten_im[c] = A.sten_im[c]; }
     m.sten_planes = A.sten_planes;
     return m;
