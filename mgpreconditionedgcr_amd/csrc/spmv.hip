@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv(RowMat m, int64_t row_begin, in
 // parameter (the kernel exists for the mask of a 3-D stencil, slots 1..5 of 7): with a run-time mask the compiler keeps
 // the gathered values in scratch memory and waits for every load in turn — 4x slower than no window at all.
 template <int NS, bool RARE, bool SHIFT, int BLK, unsigned NEAR>
-__global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begin, int64_t row_end, int64_t first, int64_t ntiles, int xcd,
+__global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int32_t H, int64_t row_begin, int64_t row_end, int64_t first, int64_t ntiles, int xcd,
                                                       const cplx *__restrict__ x, cplx *__restrict__ y, const cplx *__restrict__ w,
                                                       const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sten_smem[];
@@ -828,7 +828,6 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
     const int64_t tile = xcd ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
     cplx *sx = reinterpret_cast<cplx *>(sten_smem);   // [H + BLK + H], entry e = column base - H + e
-    const int32_t H = m.sten_halo;
     const int64_t base = first + tile * BLK;
     const int64_t rloc = base + threadIdx.x;
     const bool live = rloc >= row_begin && rloc < row_end;
@@ -947,24 +946,32 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     Context &c = ctx();
     if (row_count <= 0) return MGCR_OK;
     if (csr_stencil_active(A)) {
-        constexpr int BLK = STEN_TILE;
+        static const bool tile_on = !(getenv("MGCR_STENCIL_TILE") && atoi(getenv("MGCR_STENCIL_TILE")) == 0);
+        // window variants: 512 rows + halo <= 256 (grids up to n = 256), or 1024 rows + halo <= 512 when that catches
+        // near slots the smaller one cannot (+-n of planes up to 512 wide)
+        const bool big = tile_on && A.sten_near_f == 0x3eu && A.sten_halo_f > 0 && (A.sten_near != 0x3eu || A.sten_halo == 0);
+        const bool small = tile_on && !big && A.sten_near == 0x3eu && A.sten_halo > 0;
+        const int BLKr = big ? RED_THREADS : STEN_TILE;
         const int64_t first = row_begin & ~(int64_t)63;
-        const int64_t ntiles = (row_begin + row_count - first + BLK - 1) / BLK;
+        const int64_t ntiles = (row_begin + row_count - first + BLKr - 1) / BLKr;
         const bool xcd = ntiles >= 64;
         const unsigned grid = (unsigned)(xcd ? ((ntiles + 7) / 8) * 8 : ntiles);
         RowMat m = row_mat(A, SHIFT, k);
         m.xh = xh; m.n_own = n_own;
 #define SL(NS, RARE)                                                                                                      \
-    hipLaunchKernelGGL((sten_spmv<NS, RARE, SHIFT, BLK>), dim3(grid), dim3(BLK), 0, c.stream, m, row_begin, row_begin + row_count, \
+    hipLaunchKernelGGL((sten_spmv<NS, RARE, SHIFT, STEN_TILE>), dim3(grid), dim3(STEN_TILE), 0, c.stream, m, row_begin, row_begin + row_count, \
                        first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
-#define SLT(NS, RARE)                                                                                                     \
-    hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * A.sten_halo) * sizeof(cplx), \
-                       c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
-        static const bool tile_on = !(getenv("MGCR_STENCIL_TILE") && atoi(getenv("MGCR_STENCIL_TILE")) == 0);
-        if (A.sten_halo > 0 && A.sten_near == 0x3eu && tile_on) {
-            if (A.sten_rare) SLT(9, true);
-            else if (sten_slots(A) == 7) SLT(7, false);
-            else SLT(9, false);
+#define SLT(NS, RARE, BLK, HH)                                                                                            \
+    hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * (HH)) * sizeof(cplx), \
+                       c.stream, m, (int32_t)(HH), row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
+        if (big) {
+            if (A.sten_rare) SLT(9, true, RED_THREADS, A.sten_halo_f);
+            else if (sten_slots(A) == 7) SLT(7, false, RED_THREADS, A.sten_halo_f);
+            else SLT(9, false, RED_THREADS, A.sten_halo_f);
+        } else if (small) {
+            if (A.sten_rare) SLT(9, true, STEN_TILE, A.sten_halo);
+            else if (sten_slots(A) == 7) SLT(7, false, STEN_TILE, A.sten_halo);
+            else SLT(9, false, STEN_TILE, A.sten_halo);
         } else if (A.sten_rare) SL(9, true);
         else if (sten_slots(A) == 7) SL(7, false);
         else SL(9, false);

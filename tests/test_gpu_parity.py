@@ -875,3 +875,37 @@ def test_rare_tail_stencil_kernels_same_bits(monkeypatch):
         out.append((A(x).to_numpy(), DiracOp(A, 0.2 - 0.1j)(x).to_numpy(), g.last_history.copy(), xs.to_numpy()))
     for a, c in zip(out[0], out[1]):
         assert np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("n,planes", [(300, 4), (512, 2), (200, 5)])
+def test_wide_plane_window_kernels_bit_exact(n, planes):
+    """Grids whose lines are longer than 256 points: the +-n neighbours are served by the 1024-row LDS window (halo up to 512)
+    of the stand-alone SpMV and of the fused apply + dots / fused step 0 (rows reach >= 2^15 rows away), n = 200 by the
+    512-row window.  y equals the oracle's CSR row loop bit for bit, and a solve through the fused kernels has the bits of
+    the solve through the separate SpMV + dot-product kernels and of the dictionary storage."""
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, 0, planes, ni=planes)
+    val = val * (1.0 - 0.5j)
+    x = problems.rhs_grid(N, 2)
+    O = orc.csr(N, ncol, rowptr, col, val)
+    xf = Field((N,), x)
+    b = Field((N,), problems.rhs_grid(N, 3))
+    A = Sparse(N, ncol, rowptr, col, val)
+    assert A.storage_format() == (3, 7)
+    assert np.array_equal(A(xf).to_numpy(), O(x))
+    assert np.array_equal(DiracOp(A, 0.1 + 0.05j)(xf).to_numpy(), orc.dirac(O, 0.1 + 0.05j)(x))
+    out = []
+    for fused, stencil in ((1, 1), (0, 1), (1, 0)):
+        p1, p2 = mg.set_option("fused_apply", fused), mg.set_option("stencil_storage", stencil)
+        try:
+            B = A if stencil else Sparse(N, ncol, rowptr, col, val)
+            for prm in (GCR_Param(0, 4, 11, 1e-30, False), GCR_Param(0, 10, 2, 1e-30, False)):   # restart cycles; a smoother-shaped solve (fused step 0)
+                g = GCR(B, prm)
+                xs = Field((N,)).set_zero()
+                g.solve(b, xs)
+                out.append((fused, stencil, g.last_history.copy(), xs.to_numpy()))
+        finally:
+            mg.set_option("fused_apply", p1)
+            mg.set_option("stencil_storage", p2)
+    for k in (0, 1):
+        for o in out[2 + k::2]:
+            assert np.array_equal(out[k][2], o[2]) and np.array_equal(out[k][3], o[3]), (n, o[0], o[1])
