@@ -184,6 +184,10 @@ typedef struct mgcr_mg_param {
     mgcr_gcr_param smoother; /* GCR_Param of MG_Param::smoother_solver (max_iter = sweeps) */
     mgcr_gcr_param coarse;   /* GCR_Param of MG_Param::coarse_solver (coarsest level) */
     double damping;          /* x += damping * P x_c; the reference hard-codes 0.1 (src/MG.h:426) */
+    /* extension (0 = the reference's behaviour: the coarsest system goes to `coarse`, src/MG.h:424): when the coarsest
+     * level has at most this many unknowns (limit 2048) it is solved DIRECTLY — its operator is inverted once at set-up
+     * (dense Gauss-Jordan with partial pivoting on the device) and every cycle applies the inverse with one mat-vec */
+    int32_t coarse_direct_rows;
 } mgcr_mg_param;
 
 /* MG(Operator*, MG_Param*) + initialise (src/MG.h:131-285): aggregates, block-local prolongator

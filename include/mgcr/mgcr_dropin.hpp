@@ -541,6 +541,7 @@ public:
     bool spinor[6] = {false, false, false, false, true, false};
     int n_level = 1;
     double damping = 1.0;  // the reference hard-codes 0.1 (src/MG.h:426)
+    int coarse_direct_rows = 0;  // extension: > 0 = a coarsest level of at most this many unknowns (<= 2048) is solved directly
     // extension: use these near-null vectors instead of computing n_eigen of them by inverse iteration
     // (e.g. the constant vector: piecewise-constant aggregation for Poisson-like operators)
     const std::vector<Field<num_type>> *null_vectors = nullptr;
@@ -709,6 +710,7 @@ public:
         p.smoother = solver_param(param->smoother_solver);
         p.coarse = solver_param(param->coarse_solver);
         p.damping = param->damping;
+        p.coarse_direct_rows = param->coarse_direct_rows;
         if (op) mgcr_op_destroy(op);
         mgcr_detail::ok(mgcr_mg_create(M->handle(), &p, &op), "MG::initialise");
         std::printf("Adaptive Multigrid precomputation completed.\n");

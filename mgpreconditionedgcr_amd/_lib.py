@@ -32,7 +32,8 @@ class MgParamC(C.Structure):
     """struct mgcr_mg_param (include/mgcr.h) — mirror of MG_Param (src/SolverParam.h:38-59)."""
     _fields_ = [("ndim", C.c_int32), ("dims", C.c_int64 * 8), ("blocked", C.c_int32 * 8),
                 ("subblock_dim", C.c_int64), ("n_vec", C.c_int32), ("vecs_ri", C.c_void_p),
-                ("n_level", C.c_int32), ("smoother", GcrParamC), ("coarse", GcrParamC), ("damping", C.c_double)]
+                ("n_level", C.c_int32), ("smoother", GcrParamC), ("coarse", GcrParamC), ("damping", C.c_double),
+                ("coarse_direct_rows", C.c_int32)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)

@@ -511,10 +511,11 @@ class MG_Param:
     solver_coarse / solver_smooth are GCR objects created with `GCR(GCR_Param)` exactly as in the
     reference (src/main.cpp:851-853); MG takes their GCR_Param.  Extras the reference lacks:
     `null_vectors` (use these near-null vectors instead of computing n_eigen of them),
-    `spacetime` mask for meshes that are not 6-D, `damping` (reference literal: 0.1)."""
+    `spacetime` mask for meshes that are not 6-D, `damping` (reference literal: 0.1), `coarse_direct` (solve a
+    coarsest level of at most that many unknowns directly instead of by solver_coarse; 0 = never, like the reference)."""
 
     def __init__(self, m, subblock, eigenvecs, eigen_param, solver_coarse, solver_smooth, levels=1,
-                 solver_l=None, solver_r=None, spacetime=None, spinor=None, null_vectors=None, damping=1.0):
+                 solver_l=None, solver_r=None, spacetime=None, spinor=None, null_vectors=None, damping=1.0, coarse_direct=0):
         self.mesh = m if isinstance(m, Mesh) else Mesh(m)
         self.subblock_dim = int(subblock)
         self.n_eigen = int(eigenvecs)
@@ -528,6 +529,7 @@ class MG_Param:
         self.left_precond, self.right_precond = solver_l, solver_r
         self.null_vectors = null_vectors
         self.damping = float(damping)
+        self.coarse_direct = int(coarse_direct)   # > 0: a coarsest level of at most this many unknowns (<= 2048) is inverted at set-up
 
 
 class MG(Operator):
@@ -608,6 +610,7 @@ class MG(Operator):
         pc.smoother = prm.smoother_solver.param._c()
         pc.coarse = prm.coarse_solver.param._c()
         pc.damping = prm.damping
+        pc.coarse_direct_rows = prm.coarse_direct
         h = C.c_void_p()
         check(_lib.lib().mgcr_mg_create(M.h, C.byref(pc), C.byref(h)))
         if self.h:

@@ -223,6 +223,11 @@ int comm_check(Comm *c);
 int comm_check_all();   // every live communicator; called where results are handed back to the host
 constexpr int PW_MAX_RANKS = 16;  // peer-write all-reduce (comm.hip): one lane per rank
 
+// ---- dense.hip -------------------------------------------------------------------------------
+constexpr int DENSE_MAX_ROWS = 2048;   // direct coarsest solve: the inverse is n x n complex fp64 (64 MiB at the limit)
+int dense_inverse_of(Op *A, int64_t n, cplx **inv_out);
+int dense_apply(const cplx *inv, int64_t n, const cplx *b, cplx *x);
+
 // ---- mg.hip ----------------------------------------------------------------------------------
 int mg_create(Op *A, const mgcr_mg_param *p, MgState **out);
 void mg_destroy(MgState *m);

@@ -117,6 +117,7 @@ struct MgLevel {
     cplx *d_pv = nullptr;
     cplx *x = nullptr, *b = nullptr, *r = nullptr;  // work vectors (x, b: levels >= 1)
     GcrState *pre = nullptr, *post = nullptr, *coarse = nullptr;
+    cplx *inv = nullptr;   // coarsest level, direct solve (dense.hip): the inverse of A, n x n
 };
 
 struct MgState {
@@ -141,7 +142,7 @@ void mg_destroy(MgState *m) {
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     for (MgLevel &L : m->lev) {
         hipFree(L.d_agg); hipFree(L.d_aptr); hipFree(L.d_amem); hipFree(L.d_pv);
-        hipFree(L.x); hipFree(L.b); hipFree(L.r);
+        hipFree(L.x); hipFree(L.b); hipFree(L.r); hipFree(L.inv);
         gcr_state_destroy(L.pre); gcr_state_destroy(L.post); gcr_state_destroy(L.coarse);
         if (L.owns_A && L.A) {
             if (L.A->kind == OP_CSR) { csr_free(&L.A->csr); dist_free(L.A->dist); }
@@ -225,6 +226,10 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         cp.verbose = 0; cp.left_precond = cp.right_precond = nullptr; cp.flexible = 0; cp.use_x0 = 0; cp.profile_spmv = 0;
         rc = gcr_state_create(Z.A, &cp, 1, &Z.coarse);
         if (rc == MGCR_OK) gcr_set_discard_residual(Z.coarse, true);
+        // opt-in: a small coarsest level is inverted once and solved by one mat-vec per cycle (dense.hip)
+        const Op *zb = Z.A->kind == OP_DIRAC ? Z.A->base : Z.A;
+        if (rc == MGCR_OK && p->coarse_direct_rows > 0 && Z.n <= p->coarse_direct_rows && Z.n <= DENSE_MAX_ROWS && !zb->dist)
+            rc = dense_inverse_of(Z.A, Z.n, &Z.inv);
     }
     if (rc != MGCR_OK) { mg_destroy(m); return rc; }
     *out = m;
@@ -271,6 +276,7 @@ static int mg_cycle(MgState *m, int l, const cplx *b, cplx *x) {
     MgLevel &L = m->lev[(size_t)l];
     const int nlev = (int)m->lev.size();
     if (l == nlev - 1) {
+        if (L.inv) return dense_apply(L.inv, L.n, b, x);
         return gcr_run_from_zero(L.coarse, b, x);
     }
     MGCR_TRY(gcr_run_from_zero(L.pre, b, x));

@@ -415,3 +415,46 @@ def test_arnoldi_vs_reference(sample_matrix_path):
     # near-null vector — it must NOT be mistaken for the reference's
     plain = MG(None, prm).near_null_vectors(dirac, start=g["start"], alias_rhs_x=False, double=False)
     assert np.abs(plain[0] - g["vec0"]).max() > 1e-3
+
+
+def test_direct_coarsest_solve():
+    """MG_Param(coarse_direct=N) (extension; BASELINE north_star: "the coarsest-level dense solve if it degenerates"): a
+    coarsest level of at most N unknowns is inverted once at set-up (dense Gauss-Jordan with partial pivoting on the
+    device) and every cycle applies the inverse.  The cycle then equals the cycle whose coarsest GCR is run to machine
+    precision, the outer solve needs no more iterations than with the paper's sloppy coarsest solve (tol 1e-2 / 50), and
+    a larger coarsest level than N keeps the GCR."""
+    n = 16
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    dims = (n, n, n)
+    ones = np.ones((1, N), np.complex128)
+    smooth = GCR(GCR_Param(0, 10, 2, 1e-30, False))
+
+    def mg_with(coarse_param, direct, levels=1):
+        return MG(A, MG_Param(Mesh(dims), 2, 1, None, GCR(coarse_param), smooth, levels, None, None, null_vectors=ones, coarse_direct=direct))
+
+    b = Field(dims).fill_rhs(3)
+    exact = mg_with(GCR_Param(0, 40, 2000, 1e-15, False), 0)          # coarsest level 8^3 = 512 unknowns, solved to 1e-15 by GCR
+    direct = mg_with(GCR_Param(0, 10, 50, 1e-2, False), 1024)
+    sloppy = mg_with(GCR_Param(0, 10, 50, 1e-2, False), 0)
+    ye, yd, ys = exact(b).to_numpy(), direct(b).to_numpy(), sloppy(b).to_numpy()
+    assert np.abs(yd - ye).max() <= 1e-11 * np.abs(ye).max()
+    assert np.abs(ys - ye).max() > 1e-6 * np.abs(ye).max()             # the sloppy solve really is a different cycle
+    kept = mg_with(GCR_Param(0, 10, 50, 1e-2, False), 100)              # 512 > 100: the GCR stays
+    assert np.array_equal(kept(b).to_numpy(), ys)
+    its = {}
+    for tag, M in (("direct", direct), ("sloppy", sloppy)):
+        g = GCR(A, GCR_Param(0, 5, 100, 1e-10, False, None, M, flexible=True))
+        x = Field(dims).set_zero()
+        g.solve(b, x)
+        assert g.last_converged and (b - A(x)).norm() / b.norm() <= 2e-10
+        its[tag] = g.last_iterations
+    assert its["direct"] <= its["sloppy"], its
+    # three coarse levels: 16^3 -> 8^3 -> 4^3 -> 2^3 = 8 unknowns at the coarsest, complex shift on top
+    D = DiracOp(A, 0.02 + 0.01j)
+    M3 = MG(D, MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), smooth, 3, None, None, null_vectors=ones, coarse_direct=64))
+    assert M3.level_info(3)["dim"] == 8
+    g = GCR(D, GCR_Param(0, 5, 100, 1e-10, False, None, M3, flexible=True))
+    x = Field(dims).set_zero()
+    g.solve(b, x)
+    assert g.last_converged and (b - D(x)).norm() / b.norm() <= 2e-10
