@@ -115,8 +115,13 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  *   "graph_replay"    ($MGCR_GRAPH, default OFF): restart cycles of systems of <= 2^18 rows are captured in a
  *                      hipGraph once and replayed (same kernels, same results; measured slower than eager
  *                      launches since the iteration shrank to 3 kernels, see gcr.hip).
+ *   "resident_solver" ($MGCR_RESIDENT): a lean restarted GCR solve on a stencil-view Sparse / DiracOp of at most one row per
+ *                      thread of the chip (<= 262 144 rows) runs as ONE launch with its vectors in registers
+ *                      (csrc/gcr_resident.hip; same iterates, bit for bit, as the multi-kernel path).
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);
+/* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init. */
+int mgcr_stat(const char *name, int64_t *value);
 
 /* ---- GCR: src/GCR.h, src/SolverParam.h ---------------------------------------------------- */
 typedef struct mgcr_gcr_param {

@@ -82,6 +82,7 @@ _SIGS = {
     "mgcr_op_stored_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "mgcr_op_storage_format": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mgcr_set_option": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "mgcr_stat": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "mgcr_gcr_solve": (C.c_int, [_vp, C.POINTER(GcrParamC), _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mgcr_gcr_create": (C.c_int, [_vp, C.POINTER(GcrParamC), C.c_int32, C.POINTER(_vp)]),
     "mgcr_gcr_set_operator": (C.c_int, [_vp, _vp]),

@@ -28,6 +28,13 @@ def set_option(name, value):
     return prev.value
 
 
+def stat(name):
+    """mgcr_stat: a counter of the library ("resident_solves")."""
+    v = C.c_int64()
+    check(_lib.lib().mgcr_stat(name.encode(), C.byref(v)))
+    return v.value
+
+
 class Field:
     """Field<num_type> (src/Fields.h:29-71): complex-fp64 vector tagged with mesh dimensions."""
 

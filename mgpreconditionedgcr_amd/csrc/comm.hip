@@ -933,6 +933,11 @@ int comm_check(Comm *c) {
     return MGCR_OK;
 }
 
+int comm_live_count() {
+    std::lock_guard<std::mutex> lk(live_comms_mtx());
+    return (int)live_comms().size();
+}
+
 int comm_check_all() {
     std::lock_guard<std::mutex> lk(live_comms_mtx());
     int rc = MGCR_OK;

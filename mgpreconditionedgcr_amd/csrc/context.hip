@@ -77,6 +77,7 @@ int mgcr_finalize(void) {
     std::lock_guard<std::recursive_mutex> lk(c.mtx);
     if (!c.ready) return MGCR_OK;
     hipStreamSynchronize(c.stream);
+    resident_shutdown();
     hipEventDestroy(c.ev0);
     hipEventDestroy(c.ev1);
     hipHostFree(c.h_mail);
@@ -99,7 +100,8 @@ int mgcr_device_info(char *name, int name_cap, int *n_cu, int64_t *mem_bytes) {
 int mgcr_synchronize(void) {
     MGCR_TRY(require_ctx());
     MGCR_HIP(hipStreamSynchronize(ctx().stream));
-    return comm_check_all();   // a peer-write wait that timed out in any kernel enqueued so far
+    MGCR_TRY(comm_check_all());   // a peer-write wait that timed out in any kernel enqueued so far
+    return resident_check();      // a one-launch solve that was not co-resident and gave up
 }
 
 int mgcr_timer_start(void) {
@@ -164,7 +166,8 @@ int mgcr_vec_download(mgcr_vec_t v, double *host_ri) {
     LOCK();
     MGCR_HIP(hipMemcpyAsync(host_ri, v->d, sizeof(cplx) * (size_t)v->n, hipMemcpyDeviceToHost, ctx().stream));
     MGCR_HIP(hipStreamSynchronize(ctx().stream));
-    return comm_check_all();
+    MGCR_TRY(comm_check_all());
+    return resident_check();
 }
 
 int mgcr_vec_copy(mgcr_vec_t dst, mgcr_vec_t src) {
@@ -211,7 +214,8 @@ static int dot_to_host(const cplx *a, const cplx *b, int64_t n, double out[2]) {
     MGCR_HIP(hipStreamSynchronize(c.stream));
     out[0] = c.h_mail[0];
     out[1] = c.h_mail[1];
-    return comm_check_all();
+    MGCR_TRY(comm_check_all());
+    return resident_check();
 }
 
 int mgcr_dot(mgcr_vec_t a, mgcr_vec_t b, double out_ri[2]) {

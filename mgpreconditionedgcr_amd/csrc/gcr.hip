@@ -87,6 +87,7 @@ struct GcrState {
     std::vector<cplx *> ps, aps;
     cplx *r = nullptr, *ar = nullptr, *z = nullptr, *tmp = nullptr, *accp = nullptr, *accap = nullptr;
     cplx *x0 = nullptr;
+    cplx *res_ring = nullptr;   // gcr_resident.hip
     DevState *st = nullptr;
     double *partsA = nullptr, *partsR = nullptr, *partsN = nullptr, *partsB = nullptr;
     cplx *den = nullptr;  // cached <Aps[i],Aps[i]> per slot
@@ -487,13 +488,27 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT];
     if (st->stop_at < st->base + it) return;
+    // the first trip's operands are requested BEFORE the betas are folded from the partials (as in xr_update_kernel):
+    // partials -> beta -> first loads becomes one memory round trip instead of two; small systems have one trip only
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    cplx aj0[NDT], av0 = make_double2(0., 0.), rv0 = av0;
+#pragma unroll
+    for (int j = 0; j < NDT; j++) aj0[j] = av0;
+    if (i0 < n) {
+#pragma unroll
+        for (int j = 0; j < NDT; j++) aj0[j] = ld_stream<NTS>(d.aps[j] + i0);
+        av0 = ar[i0];
+        rv0 = r[i0];
+    }
     double s[2 * NDT];
     fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
+#ifndef MGCR_EXP_NOBOOK
     if (blockIdx.x == 0) {
         double rr[1];
         fold_partials<1>(partsR, nblkR, strideR, rr, lds);
         if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, closing != 0);
     }
+#endif
     if (threadIdx.x < NDT) {
         cplx num = make_double2(0., 0.);
 #pragma unroll
@@ -504,7 +519,11 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     __syncthreads();
     // closing (restart > 8: the cycle-closing step is close_x_kernel + this kernel with NDT = restart, writing
     // Ap_0' over slot 0 in place): no table row — the next cycle starts a new table
+#ifndef MGCR_EXP_NOBOOK
     if constexpr (NDT < LND)   // NDT == LND only ever runs as the closing step of a restart-16 cycle
+#else
+    if constexpr (false)
+#endif
     if (!closing && blockIdx.x == 0 && (int)threadIdx.x <= NDT) {
         // one thread per column of the new table row (thread 0: t_k, thread k: the unit diagonal), so that the
         // loads of a column are independent and the whole row costs one memory round trip, not k^2 / 2 of them —
@@ -527,10 +546,11 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
     double v[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
+        const bool first = i == i0;
         cplx aj[NDT];
 #pragma unroll
-        for (int j = 0; j < NDT; j++) aj[j] = ld_stream<NTS>(d.aps[j] + i);
-        const cplx av = ar[i], rv = r[i];
+        for (int j = 0; j < NDT; j++) aj[j] = first ? aj0[j] : ld_stream<NTS>(d.aps[j] + i);
+        const cplx av = first ? av0 : ar[i], rv = first ? rv0 : r[i];
         cplx ac = make_double2(0., 0.);
 #pragma unroll
         for (int j = 0; j < NDT; j++) ac = csub(ac, cmul(beta[j], aj[j]));
@@ -746,7 +766,8 @@ static void gcr_free_vectors(GcrState *s) {
     for (cplx *p : s->aps) hipFree(p);
     s->ps.clear(); s->aps.clear();
     hipFree(s->r); hipFree(s->ar); hipFree(s->z); hipFree(s->tmp); hipFree(s->accp); hipFree(s->accap);
-    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB); hipFree(s->dRB); hipFree(s->alphas);
+    hipFree(s->den); hipFree(s->hist); hipFree(s->partsB); hipFree(s->dRB); hipFree(s->alphas); hipFree(s->res_ring);
+    s->res_ring = nullptr;
     s->r = s->ar = s->z = s->tmp = s->accp = s->accap = nullptr;
     s->den = nullptr; s->hist = nullptr; s->partsB = nullptr; s->dRB = nullptr; s->alphas = nullptr;
     s->n = 0; s->partsB_dirs = 0; s->hist_cap = 0;
@@ -1088,6 +1109,20 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         return gcr_finish(s, hist, hist_cap, n_iter, converged);
     }
 
+    // systems of at most one row per thread of the chip: the whole solve in one launch, vectors in registers (gcr_resident.hip)
+    {
+        const bool lean0 = p.restart != 0 && s->storage <= LND && lean_enabled() && !p.left_precond && (!p.right_precond || flex);
+        const bool handoff = nested && (s->keep_pending || s->defer_residual);   // callers that take x or r in pieces (V-cycle pre-smoother)
+        if (!graphs_enabled() && gcr_resident_eligible(s->A, p, s->storage, s->restart, n, lean0, handoff)) {
+            if (!s->res_ring) MGCR_TRY(dalloc(&s->res_ring, (size_t)11 * n));   // the residual ring + P0 (freed with the other vectors)
+            MGCR_TRY(gcr_resident_run(s->A, p, s->storage, s->restart, rhs, x, from_zero, nested && s->discard_residual, s->st, s->hist,
+                                      s->hist_cap, s->res_ring, outer));
+            s->r_after.clear();
+            if (nested) return MGCR_OK;
+            MGCR_TRY(gcr_finish(s, hist, hist_cap, n_iter, converged));
+            return resident_check();
+        }
+    }
     hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, c.stream, s->st, outer.p, outer.it, p.tol * p.tol);
     MGCR_HIP(hipGetLastError());
     SkipGuard guard(SkipRef{&s->st->stop_at, 0});

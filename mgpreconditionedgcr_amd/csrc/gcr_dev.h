@@ -144,4 +144,9 @@ __device__ __forceinline__ void lean_pending_update(LeanCoef *lc, int slot, cplx
     }
 }
 
+// gcr_resident.hip: a lean restarted solve on a small stencil-view operator in one launch
+bool gcr_resident_eligible(const Op *A, const mgcr_gcr_param &p, int storage, int restart, int64_t n, bool lean, bool nested_handoff);
+int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, const cplx *rhs, cplx *x, bool from_zero, bool alpha_only_last,
+                     DevState *st, double *hist, int hist_cap, cplx *ring /* 11 n entries */, SkipRef outer);
+
 }  // namespace mgcr

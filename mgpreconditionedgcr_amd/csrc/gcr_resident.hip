@@ -1,0 +1,640 @@
+// Resident GCR: a whole lean restarted solve (src/GCR.h:158-302) in ONE launch, for systems of at most one row per
+// thread of the chip (<= 256 workgroups x 1024 threads = 262 144 rows on MI355X) — the latency regime, where every
+// kernel of gcr.hip's path costs its launch (~4.5 us in a dependent chain) plus a pass over 4 MB vectors that live in
+// the Infinity Cache: 49 iterations of the coarsest solve of a 256^3 V-cycle took 49 x (13.6 + 12.2) us.
+//
+// What makes one launch possible (tools/barrier_lab.hip, tools/coherent_lab.hip, profiles/r02_barrier_lab.txt):
+//   * a device-wide rendezvous costs 1.7 us when every workgroup only STORES a flag of its own and POLLS the others
+//     with relaxed atomics — the 21-57 us of a counter barrier with release / acquire fences are the fences (256
+//     workgroups each writing back and invalidating their XCD's L2) and the contended counter;
+//   * without fences the data that crosses workgroups has to be coherent by itself: it is written with
+//     buffer_store ... sc1 (write-through to the memory side) and read with buffer_load ... sc1 (misses the
+//     non-coherent caches), the agent-scope cache policy of a relaxed atomic, which the compiler schedules like any
+//     other load (no inline assembly, no hand-placed waits).  tools/coherent_lab.hip checks exactly this on the part.
+//
+// Data layout: thread t of logical workgroup b owns row i = 1024 b + t for the whole solve.  Its entries of the
+// stored images Ap_0..Ap_{R-1}, of r, of P0 and of x are REGISTERS (4 VGPRs each); the only vector that crosses
+// threads is the residual a step hands to the operator apply (the residual ring D_1..D_{R-1} of gcr.hip's lean
+// cycle, in memory anyway: the step that closes a cycle reads its own rows back).  Reductions: every workgroup
+// stores its partial sums as 16-byte {value, generation} slots and folds ALL workgroups' slots itself, in the order
+// and with the tree of reduce.h's fold_partials — the scalars, hence every iterate, have the bits of gcr.hip's
+// kernels (tests/test_gpu_resident.py compares the two paths bit for bit).  Three such exchanges per iteration
+// (|r|^2 + the residual hand-over; the beta numerators; <r,Ap>, <Ap,Ap>), each one store and one polled load deep.
+//
+// Scope: single GPU, a Sparse / DiracOp in the stencil view (spmv_dev.h MODE 3), lean restart cycles of 5 or 10
+// (or solves that end before their first cycle closes), no preconditioner hooks, x0 = 0 or ignored.  Everything else
+// takes gcr.hip's path.  A workgroup that waits longer than ~4 s for another one (the launch was not co-resident:
+// foreign work on the device) raises the abort flag, every workgroup leaves, x is poisoned with NaN and the next
+// host synchronisation reports the failure — no wave spins forever.
+#include <climits>
+#include <cmath>
+
+#include "internal.h"
+#include "reduce.h"
+#include "gcr_dev.h"
+#include "spmv_dev.h"
+
+namespace mgcr {
+
+constexpr int RES_NV = 24;          // scalars per exchange kind (<= 2 * 10 beta numerators, 5 at step 0)
+constexpr int RES_BLK = 256;        // workgroups at most (one per CU)
+constexpr int RES_CHUNK = 8;        // scalars folded at a time (register footprint of the shuffle tree)
+constexpr int RES_SPIN_LIMIT = 1 << 22;
+constexpr int RES_COPIES = 16;      // copies of every group sum (workgroup b reads copy b % 16)
+constexpr int RES_L1_BYTES = 3 * RES_NV * RES_BLK * 16;            // {value, generation} per (kind, scalar, workgroup)
+constexpr int RES_L2_BASE = RES_L1_BYTES;                          // then [copy][kind][scalar][group of 64 workgroups]
+constexpr int RES_SLOT_BYTES = RES_L1_BYTES + RES_COPIES * 3 * RES_NV * 4 * 16;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct ResidentArgs {
+    RowMat m;
+    const cplx *rhs;
+    cplx *x;
+    int64_t n;
+    int nlogical;
+    RowMap rm;
+    DevState *st;
+    const int *inherit;
+    int inherit_it;
+    double tol2;
+    int max_it, storage;
+    int from_zero, alpha_only_last;
+    double *hist;
+    int hist_cap;
+    cplx *ring;          // (R + 1) slots of n rows: 0 = the residual a closing step starts the next cycle from, m = D_m, R = P0 after the first cycle
+    v4i *slots;          // RES_SLOT_BYTES: {value, generation} slots of both hops
+    unsigned gen0;
+    unsigned *abort_dev; // raised by a workgroup that gave up waiting; polled by the others
+    int *abort_host;     // host-mapped copy for resident_check()
+    unsigned long long *dbg;   // MGCR_RES_TIMING: ticks (100 MHz) spent per phase, summed over the steps (workgroup 0)
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+constexpr int RES_SC1 = 16;   // cache-policy operand of the buffer intrinsics on gfx94x / gfx950: sc1
+// row idx of the vector that starts soff bytes into the buffer (soff wave-uniform)
+__device__ __forceinline__ cplx ld_coh(__amdgpu_buffer_rsrc_t r, int idx, int soff) {
+    const v4i w = __builtin_amdgcn_raw_buffer_load_b128(r, idx * 16, soff, RES_SC1);
+    return make_double2(__hiloint2double(w.y, w.x), __hiloint2double(w.w, w.z));
+}
+__device__ __forceinline__ void st_coh(__amdgpu_buffer_rsrc_t r, int idx, int soff, cplx v) {
+    const v4i w = {__double2loint(v.x), __double2hiint(v.x), __double2loint(v.y), __double2hiint(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, idx * 16, soff, RES_SC1);
+}
+
+__device__ __forceinline__ void res_tick(const unsigned long long *dbg_on, unsigned long long *acc, unsigned long long &t_prev, int phase) {
+    if (dbg_on) {
+        const unsigned long long t = wall_clock64();
+        acc[phase] += t - t_prev;
+        t_prev = t;
+    }
+}
+
+struct ResSync {
+    __amdgpu_buffer_rsrc_t slots;
+    unsigned gen;        // generation of the NEXT exchange
+    int nblk, lb;
+    unsigned *abort_dev;
+    double *pw;          // [RES_NV][17] this workgroup's wave sums of the exchange being posted
+    double *ws;          // [RES_NV][4]  sums over 64 workgroups each of the exchange being collected
+    int *gave_up;        // LDS flag
+};
+
+// An exchange = contribute (every wave: its 64 rows' terms -> LDS), publish (one barrier; thread k adds the 16 wave
+// sums of scalar k in wave order — reduce.h block_sum_owner — and stores {sum, generation} into this workgroup's
+// slot), collect (every wave polls a share of the slots — 64 workgroups x a few scalars — and sums them with the
+// shuffle tree of reduce.h fold_partials; one barrier), total (any thread: the <= 4 group sums in order).  Same
+// operands, same order, same bits as the per-workgroup partial slabs of gcr.hip's kernels; 2 barriers per exchange.
+template <int NV>
+__device__ __forceinline__ void res_contrib(ResSync &s, int k0, double (&v)[NV]) {
+    static_assert(NV <= RES_CHUNK, "chunk");
+    constexpr int NVP = WaveMulti<NV>::NVP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double t;
+    const int k = wave_multi_sum<NV>(v, t);
+    if ((lane & (64 / NVP - 1)) == 0 && k < NV) s.pw[(k0 + k) * 17 + wave] = t;
+}
+template <int NVT>
+__device__ __forceinline__ void res_publish(ResSync &s, int kind) {
+    __syncthreads();
+    if ((int)threadIdx.x < NVT) {
+        double t = 0.;
+#pragma unroll
+        for (int w = 0; w < RED_THREADS / 64; w++) t += s.pw[threadIdx.x * 17 + w];
+        const v4i w4 = {__double2loint(t), __double2hiint(t), (int)s.gen, 0};
+        __builtin_amdgcn_raw_buffer_store_b128(w4, s.slots, ((kind * RES_NV + (int)threadIdx.x) * RES_BLK + s.lb) * 16, 0, RES_SC1);
+    }
+}
+// Collect in two hops, so that no slot is read by more than a few workgroups at a time (256 workgroups polling the same
+// 4 KB took 5-6 us per exchange: one memory channel serves it all).  Hop 1: the (group g of 64 workgroups, scalar k) sums
+// are TASKS dealt over the waves of the first workgroups; a task's wave polls the 64 slots, sums them with the shuffle
+// tree of reduce.h fold_partials and stores the group sum, RES_COPIES times (4.5 KB apart: other channels).  Hop 2:
+// thread (k, g) of every workgroup polls its copy of group sum (k, g) into LDS.  false: somebody did not show up in
+// time (abort).
+template <int NVT>
+__device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
+    static_assert(NVT <= RES_NV, "scalars per exchange");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = (s.nblk + 63) >> 6;   // groups that hold workgroups
+    for (int task = wave * s.nblk + s.lb; task < ng * NVT; task += (RED_THREADS / 64) * s.nblk) {   // wave-uniform
+        const int g = task / NVT, k = task - g * NVT;
+        const int blk = g * 64 + lane;
+        double v = 0.;
+        if (blk < s.nblk) {
+            int spins = 0;
+            for (;;) {
+                const v4i w = __builtin_amdgcn_raw_buffer_load_b128(s.slots, ((kind * RES_NV + k) * RES_BLK + blk) * 16, 0, RES_SC1);
+                v = __hiloint2double(w.y, w.x);
+                if ((unsigned)w.z == s.gen) break;
+                spins++;
+                if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    *s.gave_up = 1;
+                    v = 0.;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        double t = wave_sum(v);
+        t = __shfl(t, 0, 64);
+        if (lane < RES_COPIES) {
+            const v4i w4 = {__double2loint(t), __double2hiint(t), (int)s.gen, 0};
+            __builtin_amdgcn_raw_buffer_store_b128(w4, s.slots, RES_L2_BASE + ((lane * 3 + kind) * RES_NV + k) * 4 * 16 + g * 16, 0, RES_SC1);
+        }
+    }
+    if ((int)threadIdx.x < 4 * NVT) {
+        const int k = threadIdx.x >> 2, g = threadIdx.x & 3;
+        double v = 0.;
+        if (g < ng) {
+            const int copy = s.lb & (RES_COPIES - 1);
+            int spins = 0;
+            for (;;) {
+                const v4i w = __builtin_amdgcn_raw_buffer_load_b128(s.slots, RES_L2_BASE + ((copy * 3 + kind) * RES_NV + k) * 4 * 16 + g * 16, 0, RES_SC1);
+                v = __hiloint2double(w.y, w.x);
+                if ((unsigned)w.z == s.gen) break;
+                spins++;
+                if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    *s.gave_up = 1;
+                    v = 0.;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        s.ws[k * 4 + g] = v;
+    }
+    __syncthreads();
+    s.gen++;
+    return *s.gave_up == 0;
+}
+// sum over all workgroups of scalar k of the exchange collected last (reduce.h block_sum_bcast: waves in index order from 0.;
+// the waves past the fourth hold no workgroup and would add + 0.0)
+__device__ __forceinline__ double res_total(const ResSync &s, int k) {
+    double t = 0.;
+#pragma unroll
+    for (int g = 0; g < 4; g++) t += s.ws[k * 4 + g];
+    return t;
+}
+
+template <int R>
+struct ResState {
+    cplx Ap[R];          // images of the cycle's directions, this thread's row
+    cplx rv;
+    cplx num, den;       // <r,Ap_cur>, <Ap_cur,Ap_cur>
+    double bnorm2, rr;
+    int it, npend, stop_at, iter;
+    bool x_live;         // x holds something to add to (else: x0 = 0 that was never written)
+    bool p0_rhs;         // first cycle: P0 is the right-hand side itself
+    bool aborted;
+    unsigned long long tacc[8], tprev;
+};
+
+template <int R>
+struct ResTables {       // LDS: gcr_dev.h LeanCoef with rows of R, plus the per-slot denominators and the step's coefficients
+    cplx T[R * R], t[R], cx[R], den[R], beta[R], cp[R];
+};
+
+// One step at cycle position K (direction K is the current one, lim = K + 1 directions are stored).  Returns false when the
+// solve is over (converged, last iteration, abort).
+template <int MODE, int NS, int R, int K>
+__device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, ResTables<R> &tb, ResSync &sy, __amdgpu_buffer_rsrc_t ring, int i, bool act, bool owner0) {
+    constexpr int lim = K + 1;
+    constexpr bool closing = K + 1 == R;
+    constexpr int nxt = closing ? 0 : K + 1;
+    S.it++;
+    const int it = S.it;
+    res_tick(a.dbg, S.tacc, S.tprev, 7);   // (whatever ran since the last tick: loop overhead)
+    const bool last = it == a.max_it;
+    // alpha and its bookkeeping (gcr.hip xr_update_kernel<true, true> / alpha_only_kernel)
+    const cplx alpha = to_sgpr(cdiv(S.num, S.den));
+    if (threadIdx.x == 0) tb.den[K] = S.den;
+    if ((int)threadIdx.x < R) {   // gcr_dev.h lean_pending_update, slot = K
+        const int m = threadIdx.x;
+        if (K == 0) tb.cx[m] = m == 0 ? alpha : make_double2(0., 0.);
+        else if (m == 0) tb.cx[0] = cadd(tb.cx[0], cmul(alpha, tb.t[K]));
+        else if (m <= K) tb.cx[m] = cadd(tb.cx[m], cmul(alpha, tb.T[K * R + m]));
+    }
+    S.npend = K + 1;
+    if (last && a.alpha_only_last) {   // the caller only wants x: no residual, no history entry (alpha_only_kernel)
+        S.iter = it;
+        return false;
+    }
+    const cplx rn = csub(S.rv, cmul(alpha, S.Ap[K]));
+    S.rv = rn;
+    const int vbytes = (int)a.n * 16;   // one ring slot
+    if (act && !last) st_coh(ring, i, nxt * vbytes, rn);
+    {   // |r|^2; the residual has reached memory when the workgroup's slot says so (every wave waits for its store first)
+        double v[1] = {0.};
+        if (act) v[0] += rn.x * rn.x + rn.y * rn.y;
+        __builtin_amdgcn_s_waitcnt(0);
+        res_contrib<1>(sy, 0, v);
+        res_publish<1>(sy, 0);
+        res_tick(a.dbg, S.tacc, S.tprev, 0);
+        if (!res_collect<1>(sy, 0)) { S.aborted = true; return false; }
+        res_tick(a.dbg, S.tacc, S.tprev, 1);
+    }
+    {   // the step's bookkeeping (gcr.hip close_step)
+        const double rr = to_sgpr(res_total(sy, 0));
+        S.iter = it;
+        S.rr = rr;
+        if (owner0 && it < a.hist_cap) a.hist[it] = sqrt(rr) / sqrt(S.bnorm2);
+        if (!((rr / S.bnorm2) > a.tol2)) { S.stop_at = it; return false; }
+        if (last) return false;
+    }
+    // Ar = A r (or r - k A r) from the neighbours' rows, <Ar, Ap_j> for the stored directions
+    cplx ar = make_double2(0., 0.);
+    if (act) {
+        const PatLds pl{nullptr, nullptr, nullptr};
+        const cplx sum = fused_row_product<MODE, NS>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); });
+        ar = a.m.shift ? csub(rn, cmul(a.m.k, sum)) : sum;
+    }
+    res_tick(a.dbg, S.tacc, S.tprev, 2);
+    {
+        constexpr int NVB = 2 * lim;
+#pragma unroll
+        for (int c0 = 0; c0 + RES_CHUNK <= NVB; c0 += RES_CHUNK) {
+            double v[RES_CHUNK];
+#pragma unroll
+            for (int q = 0; q < RES_CHUNK / 2; q++) {
+                const cplx t = act ? cconj_mul(ar, S.Ap[c0 / 2 + q]) : make_double2(0., 0.);
+                v[2 * q] = 0. + t.x;
+                v[2 * q + 1] = 0. + t.y;
+            }
+            res_contrib<RES_CHUNK>(sy, c0, v);
+        }
+        constexpr int tail = NVB % RES_CHUNK;
+        if constexpr (tail > 0) {
+            constexpr int c0 = NVB - tail;
+            double v[tail];
+#pragma unroll
+            for (int q = 0; q < tail / 2; q++) {
+                const cplx t = act ? cconj_mul(ar, S.Ap[c0 / 2 + q]) : make_double2(0., 0.);
+                v[2 * q] = 0. + t.x;
+                v[2 * q + 1] = 0. + t.y;
+            }
+            res_contrib<tail>(sy, c0, v);
+        }
+        res_publish<NVB>(sy, 1);
+        res_tick(a.dbg, S.tacc, S.tprev, 3);
+        if (!res_collect<NVB>(sy, 1)) { S.aborted = true; return false; }
+        res_tick(a.dbg, S.tacc, S.tprev, 4);
+    }
+    // beta_j, the coefficient table, the new image (gcr.hip build_lean_kernel / close_x_kernel / build_close_kernel)
+    if ((int)threadIdx.x < lim) tb.beta[threadIdx.x] = cdiv(make_double2(res_total(sy, 2 * threadIdx.x), res_total(sy, 2 * threadIdx.x + 1)), tb.den[threadIdx.x]);
+    __syncthreads();
+    if constexpr (!closing) {
+        if ((int)threadIdx.x <= lim) {   // table row k = lim
+            constexpr int k = lim;
+            const int m = threadIdx.x;
+            cplx c = make_double2(0., 0.);
+            if (m == 0) {
+                for (int j = 0; j < k; j++) c = csub(c, cmul(tb.beta[j], j == 0 ? make_double2(1., 0.) : tb.t[j]));
+                tb.t[k] = c;
+            } else if (m < k) {
+                for (int j = m; j < k; j++) c = csub(c, cmul(tb.beta[j], j == m ? make_double2(1., 0.) : tb.T[j * R + m]));
+                tb.T[k * R + m] = c;
+            } else {
+                tb.T[k * R + k] = make_double2(1., 0.);
+            }
+        }
+    } else {
+        if ((int)threadIdx.x < lim) {
+            const int m = threadIdx.x;
+            cplx c = make_double2(0., 0.);
+            if (m == 0) {
+                for (int j = 0; j < lim; j++) c = cadd(c, cmul(tb.beta[j], j == 0 ? make_double2(1., 0.) : tb.t[j]));
+            } else {
+                for (int j = m; j < lim; j++) c = cadd(c, cmul(tb.beta[j], j == m ? make_double2(1., 0.) : tb.T[j * R + m]));
+            }
+            tb.cp[m] = c;
+        }
+        __syncthreads();
+    }
+    cplx ac = make_double2(0., 0.);
+#pragma unroll
+    for (int j = 0; j < lim; j++) ac = csub(ac, cmul(to_sgpr(tb.beta[j]), S.Ap[j]));
+    const cplx an = cadd(ar, ac);
+    if constexpr (closing) {
+        // x += cx_0 P0 + sum_m cx_m D_m;  P0' = D_R - cp_0 P0 - sum_m cp_m D_m  (D_R = this step's residual); own rows only,
+        // five vectors at a time (all ten in flight do not fit the registers next to the ten images)
+        cplx xv = (act && S.x_live) ? a.x[i] : make_double2(0., 0.);
+        cplx pc = make_double2(0., 0.);
+#pragma unroll
+        for (int j0 = 0; j0 < R; j0 += 5) {
+            cplx pj[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int j = j0 + q;
+                pj[q] = make_double2(0., 0.);
+                if (act && j < R) pj[q] = j == 0 ? (S.p0_rhs ? a.rhs[i] : ld_coh(ring, i, R * vbytes)) : ld_coh(ring, i, j * vbytes);
+            }
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                if (j0 + q < R) xv = cadd(xv, cmul(to_sgpr(tb.cx[j0 + q]), pj[q]));
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                if (j0 + q < R) pc = csub(pc, cmul(to_sgpr(tb.cp[j0 + q]), pj[q]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (act) {
+            a.x[i] = xv;
+            st_coh(ring, i, R * vbytes, cadd(rn, pc));
+        }
+        S.x_live = true;
+        S.p0_rhs = false;
+        S.npend = 0;
+    }
+    S.Ap[nxt] = an;
+    {
+        double v[4] = {0., 0., 0., 0.};
+        if (act) {
+            const cplx t = cconj_mul(rn, an);
+            v[0] += t.x; v[1] += t.y;
+            const cplx u = cconj_mul(an, an);
+            v[2] += u.x; v[3] += u.y;
+        }
+        res_contrib<4>(sy, 0, v);
+        res_publish<4>(sy, 2);
+        res_tick(a.dbg, S.tacc, S.tprev, 5);
+        if (!res_collect<4>(sy, 2)) { S.aborted = true; return false; }
+        res_tick(a.dbg, S.tacc, S.tprev, 6);
+        S.num = to_sgpr(make_double2(res_total(sy, 0), res_total(sy, 1)));
+        S.den = to_sgpr(make_double2(res_total(sy, 2), res_total(sy, 3)));
+    }
+    return true;
+}
+
+template <int MODE, int NS, int R, int K>
+__device__ __forceinline__ bool res_cycle(const ResidentArgs &a, ResState<R> &S, ResTables<R> &tb, ResSync &sy, __amdgpu_buffer_rsrc_t ring, int i, bool act, bool owner0) {
+    if constexpr (K < R) {
+        if (K >= a.storage) return false;   // (never reached: a solve whose cycle cannot close ends by max_it before)
+        if (!res_step<MODE, NS, R, K>(a, S, tb, sy, ring, i, act, owner0)) return false;
+        return res_cycle<MODE, NS, R, K + 1>(a, S, tb, sy, ring, i, act, owner0);
+    } else {
+        return true;
+    }
+}
+
+template <int MODE, int NS, int R>
+__global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentArgs a) {
+    __shared__ double lds_pw[RES_NV * 17], lds_ws[RES_NV * 4];
+    __shared__ int gave_up;
+    __shared__ ResTables<R> tb;
+    const int lb = logical_workgroup(a.rm, (int)blockIdx.x, (int)gridDim.x);
+    const bool owner0 = lb == 0 && threadIdx.x == 0;
+    // an outer solve that is over silences this one (gcr.hip reset_kernel)
+    if (a.inherit && a.inherit[0] < a.inherit[1] + a.inherit_it) {
+        if (owner0) {
+            a.st->stop_at = -1; a.st->base = 0; a.st->iter = 0; a.st->npend = 0; a.st->bnorm2 = 0.; a.st->rr = 0.; a.st->tol2 = a.tol2;
+        }
+        return;
+    }
+    if (lb >= a.nlogical) return;
+    const int i = lb * RED_THREADS + (int)threadIdx.x;
+    const bool act = i < a.n;
+    const int vbytes = (int)a.n * 16;
+    const __amdgpu_buffer_rsrc_t ring = res_rsrc(a.ring, (unsigned)(R + 1) * (unsigned)vbytes);
+    ResSync sy;
+    sy.slots = res_rsrc(a.slots, (unsigned)RES_SLOT_BYTES);
+    sy.gen = a.gen0;
+    sy.nblk = a.nlogical;
+    sy.lb = lb;
+    sy.abort_dev = a.abort_dev;
+    sy.pw = lds_pw;
+    sy.ws = lds_ws;
+    sy.gave_up = &gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    __syncthreads();
+    ResState<R> S;
+#pragma unroll
+    for (int j = 0; j < R; j++) S.Ap[j] = make_double2(0., 0.);
+    S.rv = act ? a.rhs[i] : make_double2(0., 0.);
+    S.x_live = !a.from_zero;
+    S.p0_rhs = true;
+    S.it = 0; S.npend = 0; S.stop_at = INT_MAX; S.iter = 0; S.rr = 0.; S.bnorm2 = 0.;
+    S.aborted = false;
+    for (int q = 0; q < 8; q++) S.tacc[q] = 0;
+    S.tprev = a.dbg ? wall_clock64() : 0ull;
+    // step 0: Ap_0 = A r_0 and <r_0,Ap_0>, <Ap_0,Ap_0>, |r_0|^2 = |b|^2 (gcr_fused.hip init_apply_kernel, gcr.hip init_kernel)
+    {
+        double v[5] = {0., 0., 0., 0., 0.};
+        if (act) {
+            const PatLds pl{nullptr, nullptr, nullptr};
+            const cplx sum = fused_row_product<MODE, NS>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return a.rhs[j]; });
+            const cplx yi = a.m.shift ? csub(S.rv, cmul(a.m.k, sum)) : sum;
+            S.Ap[0] = yi;
+            v[4] += S.rv.x * S.rv.x + S.rv.y * S.rv.y;
+            const cplx t = cconj_mul(S.rv, yi);
+            v[0] += t.x; v[1] += t.y;
+            const cplx u = cconj_mul(yi, yi);
+            v[2] += u.x; v[3] += u.y;
+        }
+        res_contrib<5>(sy, 0, v);
+        res_publish<5>(sy, 2);
+        if (!res_collect<5>(sy, 2)) S.aborted = true;
+        S.num = to_sgpr(make_double2(res_total(sy, 0), res_total(sy, 1)));
+        S.den = to_sgpr(make_double2(res_total(sy, 2), res_total(sy, 3)));
+        S.rr = to_sgpr(res_total(sy, 4));
+        S.bnorm2 = S.rr;
+        if (owner0 && !S.aborted) a.hist[0] = sqrt(S.rr) / sqrt(S.bnorm2);
+    }
+    if (!S.aborted)
+        while (res_cycle<MODE, NS, R, 0>(a, S, tb, sy, ring, i, act, owner0)) {}
+    __syncthreads();
+    if (S.aborted) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.abort_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (act) a.x[i] = make_double2(__builtin_nan(""), __builtin_nan(""));
+        if (owner0) { a.st->stop_at = S.it; a.st->base = 0; a.st->iter = S.it; a.st->npend = 0; a.st->bnorm2 = S.bnorm2; a.st->rr = __builtin_nan(""); a.st->tol2 = a.tol2; }
+        return;
+    }
+    // the x updates still pending (gcr.hip flush_x_kernel): x += cx_0 P0 + sum_{1 <= m < npend} cx_m D_m
+    {
+        cplx xv = (act && S.x_live) ? a.x[i] : make_double2(0., 0.);
+        const int np = S.npend;
+#pragma unroll
+        for (int j0 = 0; j0 < R; j0 += 5) {
+            cplx pj[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int j = j0 + q;
+                pj[q] = make_double2(0., 0.);
+                if (act && j < R && j < np) pj[q] = j == 0 ? (S.p0_rhs ? a.rhs[i] : ld_coh(ring, i, R * vbytes)) : ld_coh(ring, i, j * vbytes);
+            }
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                if (j0 + q < R && j0 + q < np) xv = cadd(xv, cmul(to_sgpr(tb.cx[j0 + q]), pj[q]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (act) a.x[i] = xv;
+    }
+    if (owner0 && a.dbg)
+        for (int q = 0; q < 8; q++) a.dbg[q] = S.tacc[q];
+    if (owner0) {
+        a.st->stop_at = S.stop_at; a.st->base = 0; a.st->iter = S.iter; a.st->npend = 0; a.st->bnorm2 = S.bnorm2; a.st->rr = S.rr; a.st->tol2 = a.tol2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int64_t g_resident_solves = 0;
+int64_t resident_solve_count() { return g_resident_solves; }
+static int g_resident = -1;
+static bool resident_enabled() {
+    if (g_resident < 0) g_resident = !(getenv("MGCR_RESIDENT") && atoi(getenv("MGCR_RESIDENT")) == 0);
+    return g_resident != 0;
+}
+bool set_resident_enabled(bool on) {
+    bool prev = resident_enabled();
+    g_resident = on ? 1 : 0;
+    return prev;
+}
+
+struct ResidentShared {
+    v4i *slots = nullptr;
+    unsigned *abort_dev = nullptr;
+    int *abort_host = nullptr;   // host-mapped
+    unsigned gen = 1;
+    int cus = 0;
+};
+static ResidentShared &res_shared() {
+    static ResidentShared s;
+    return s;
+}
+static int res_shared_init() {
+    ResidentShared &s = res_shared();
+    if (s.slots) return MGCR_OK;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    MGCR_HIP(hipGetDevice(&dev));
+    MGCR_HIP(hipGetDeviceProperties(&prop, dev));
+    s.cus = prop.multiProcessorCount;
+    const size_t bytes = RES_SLOT_BYTES;
+    MGCR_HIP(hipMalloc((void **)&s.slots, bytes));
+    MGCR_HIP(hipMemset(s.slots, 0, bytes));
+    MGCR_HIP(hipMalloc((void **)&s.abort_dev, sizeof(unsigned)));
+    MGCR_HIP(hipMemset(s.abort_dev, 0, sizeof(unsigned)));
+    MGCR_HIP(hipHostMalloc((void **)&s.abort_host, sizeof(int), hipHostMallocMapped));
+    *s.abort_host = 0;
+    return MGCR_OK;
+}
+void resident_shutdown() {
+    ResidentShared &s = res_shared();
+    if (s.slots) hipFree(s.slots);
+    if (s.abort_dev) hipFree(s.abort_dev);
+    if (s.abort_host) hipHostFree(s.abort_host);
+    s = ResidentShared();
+}
+// did a resident solve give up since the last look?  (called where results are handed back to the host)
+int resident_check() {
+    ResidentShared &s = res_shared();
+    if (s.abort_host && *(volatile int *)s.abort_host != 0) {
+        *(volatile int *)s.abort_host = 0;
+        hipMemsetAsync(s.abort_dev, 0, sizeof(unsigned), ctx().stream);
+        set_error("resident GCR solve: a workgroup waited too long for the others (the launch was not co-resident); its x was poisoned with NaN");
+        return MGCR_ERR_HIP;
+    }
+    return MGCR_OK;
+}
+
+bool gcr_resident_eligible(const Op *A, const mgcr_gcr_param &p, int storage, int restart, int64_t n, bool lean, bool nested_handoff) {
+    if (!resident_enabled() || !lean || nested_handoff) return false;
+    if (p.use_x0 || p.flexible || p.left_precond || p.right_precond || p.profile_spmv) return false;
+    if (comm_live_count() > 0) return false;   // several processes may share this GPU: a launch that needs the whole chip could wait on another one
+    const Op *b0 = A->kind == OP_DIRAC ? A->base : A;
+    if (!b0 || b0->kind != OP_CSR || b0->dist || A->comm) return false;
+    const CsrDev &M = b0->csr;
+    if (!csr_fusable(M, nullptr) || M.nrow != n || !csr_stencil_active(M) || M.sten_rare) return false;
+    if (sten_slots(M) != 7 && sten_slots(M) != 9) return false;
+    const int max_it = p.max_iter > 0 ? p.max_iter : 1;
+    const bool never_closes = max_it < restart;
+    if (storage > 10) return false;
+    if (!never_closes && !(restart == storage && (restart == 5 || restart == 10))) return false;
+    if (res_shared_init() != MGCR_OK) return false;
+    const int g = red_grid(n);
+    const int grid = g >= 64 ? (g + 7) / 8 * 8 : g;
+    int cus = res_shared().cus;
+    if (cus > RES_BLK) cus = RES_BLK;
+    return (int64_t)g * RED_THREADS >= n && grid <= cus;
+}
+
+int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, const cplx *rhs, cplx *x, bool from_zero, bool alpha_only_last,
+                     DevState *st, double *hist, int hist_cap, cplx *ring, SkipRef outer) {
+    MGCR_TRY(res_shared_init());
+    ResidentShared &sh = res_shared();
+    const Op *b0 = A->kind == OP_DIRAC ? A->base : A;
+    const CsrDev &M = b0->csr;
+    const int64_t n = M.nrow;
+    ResidentArgs a;
+    a.m = row_mat(M, A->kind == OP_DIRAC, A->k);
+    a.rhs = rhs; a.x = x; a.n = n;
+    const int g = red_grid(n);
+    a.nlogical = g;
+    a.rm = make_row_map(n, g, M.reach);
+    a.st = st; a.inherit = outer.p; a.inherit_it = outer.it; a.tol2 = p.tol * p.tol;
+    a.max_it = p.max_iter > 0 ? p.max_iter : 1;
+    a.storage = storage;
+    a.from_zero = from_zero ? 1 : 0;
+    a.alpha_only_last = alpha_only_last ? 1 : 0;
+    a.hist = hist; a.hist_cap = hist_cap;
+    a.ring = ring;
+    a.slots = sh.slots; a.abort_dev = sh.abort_dev; a.abort_host = sh.abort_host;
+    static const bool timing = getenv("MGCR_RES_TIMING") && atoi(getenv("MGCR_RES_TIMING")) != 0;
+    static unsigned long long *dbg = nullptr;
+    if (timing && !dbg) { MGCR_HIP(hipMalloc((void **)&dbg, 8 * sizeof(unsigned long long))); }
+    a.dbg = timing ? dbg : nullptr;
+    const unsigned need = 3u * (unsigned)a.max_it + 4u;
+    if (sh.gen > 0xffffffffu - need - 1u) {   // generations never repeat: start over on cleared slots
+        MGCR_HIP(hipMemsetAsync(sh.slots, 0, RES_SLOT_BYTES, ctx().stream));
+        sh.gen = 1;
+    }
+    a.gen0 = sh.gen;
+    sh.gen += need;
+    const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
+    const int R = storage <= 5 && (restart == 5 || a.max_it < restart) ? 5 : 10;
+    const int ns = sten_slots(M);
+#define RES_LAUNCH(NS, RR) hipLaunchKernelGGL((gcr_resident_kernel<3, NS, RR>), dim3(grid), dim3(RED_THREADS), 0, ctx().stream, a)
+    if (ns == 7) { if (R == 5) RES_LAUNCH(7, 5); else RES_LAUNCH(7, 10); }
+    else { if (R == 5) RES_LAUNCH(9, 5); else RES_LAUNCH(9, 10); }
+#undef RES_LAUNCH
+    MGCR_HIP(hipGetLastError());
+    g_resident_solves++;
+    if (timing) {   // development aid: where the steps of this solve spent their time (workgroup 0)
+        unsigned long long h[8];
+        MGCR_HIP(hipStreamSynchronize(ctx().stream));
+        MGCR_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        const char *names[8] = {"xr + publish |r|^2", "collect |r|^2", "bookkeeping + gather + apply", "dots + publish", "collect beta numerators",
+                                "beta, table, build + publish", "collect <r,Ap>, <Ap,Ap>", "between steps"};
+        fprintf(stderr, "resident solve, n = %lld, max_it %d:", (long long)n, a.max_it);
+        for (int q = 0; q < 8; q++) fprintf(stderr, " [%s] %.1f us", names[q], (double)h[q] * 0.01);
+        fprintf(stderr, " (totals over all steps)\n");
+    }
+    return MGCR_OK;
+}
+
+}  // namespace mgcr

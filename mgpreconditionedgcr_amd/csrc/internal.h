@@ -167,6 +167,10 @@ bool csr_stencil_active(const CsrDev &A);  // the apply kernels read A through i
 bool set_lean_enabled(bool on);
 bool set_fuse_enabled(bool on);
 bool set_graph_enabled(bool on);
+bool set_resident_enabled(bool on);   // gcr_resident.hip: whole small solves in one launch
+int resident_check();                  // did such a solve give up (launch not co-resident)?  Called at host synchronisation points
+void resident_shutdown();
+int64_t resident_solve_count();
 // y = A x   or (shift) y = w - k*(A x) with w = x unless given (w = b, k = 1: the residual b - A x in one pass);
 // dist != nullptr: row block with halo exchange
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr, const cplx *w = nullptr);
@@ -220,6 +224,7 @@ bool comm_collectives(Comm *c);
 int comm_allreduce_dev(Comm *c, double *dbuf, int count);
 int comm_fold_allreduce(Comm *c, const double *pa, int na, const double *pb, int nb, double *out, int nblk);
 int comm_check(Comm *c);
+int comm_live_count();  // communicators alive in this process
 int comm_check_all();   // every live communicator; called where results are handed back to the host
 constexpr int PW_MAX_RANKS = 16;  // peer-write all-reduce (comm.hip): one lane per rank
 
