@@ -488,27 +488,13 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT];
     if (st->stop_at < st->base + it) return;
-    // the first trip's operands are requested BEFORE the betas are folded from the partials (as in xr_update_kernel):
-    // partials -> beta -> first loads becomes one memory round trip instead of two; small systems have one trip only
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    cplx aj0[NDT], av0 = make_double2(0., 0.), rv0 = av0;
-#pragma unroll
-    for (int j = 0; j < NDT; j++) aj0[j] = av0;
-    if (i0 < n) {
-#pragma unroll
-        for (int j = 0; j < NDT; j++) aj0[j] = ld_stream<NTS>(d.aps[j] + i0);
-        av0 = ar[i0];
-        rv0 = r[i0];
-    }
     double s[2 * NDT];
     fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
-#ifndef MGCR_EXP_NOBOOK
     if (blockIdx.x == 0) {
         double rr[1];
         fold_partials<1>(partsR, nblkR, strideR, rr, lds);
         if (threadIdx.x == 0) close_step(st, it, rr[0], hist, hist_cap, closing != 0);
     }
-#endif
     if (threadIdx.x < NDT) {
         cplx num = make_double2(0., 0.);
 #pragma unroll
@@ -519,11 +505,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     __syncthreads();
     // closing (restart > 8: the cycle-closing step is close_x_kernel + this kernel with NDT = restart, writing
     // Ap_0' over slot 0 in place): no table row — the next cycle starts a new table
-#ifndef MGCR_EXP_NOBOOK
     if constexpr (NDT < LND)   // NDT == LND only ever runs as the closing step of a restart-16 cycle
-#else
-    if constexpr (false)
-#endif
     if (!closing && blockIdx.x == 0 && (int)threadIdx.x <= NDT) {
         // one thread per column of the new table row (thread 0: t_k, thread k: the unit diagonal), so that the
         // loads of a column are independent and the whole row costs one memory round trip, not k^2 / 2 of them —
@@ -546,11 +528,10 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
     double v[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
-        const bool first = i == i0;
         cplx aj[NDT];
 #pragma unroll
-        for (int j = 0; j < NDT; j++) aj[j] = first ? aj0[j] : ld_stream<NTS>(d.aps[j] + i);
-        const cplx av = first ? av0 : ar[i], rv = first ? rv0 : r[i];
+        for (int j = 0; j < NDT; j++) aj[j] = ld_stream<NTS>(d.aps[j] + i);
+        const cplx av = ar[i], rv = r[i];
         cplx ac = make_double2(0., 0.);
 #pragma unroll
         for (int j = 0; j < NDT; j++) ac = csub(ac, cmul(beta[j], aj[j]));

@@ -210,9 +210,7 @@ __global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m,
         *den_slot = den;
         st->npend = slot + 1;
     }
-#ifndef MGCR_EXP_NOBOOK
     if (blockIdx.x == 0 && (int)threadIdx.x < LND) lean_pending_update(lc, slot, alpha, (int)threadIdx.x);
-#endif
     if (lb >= nlogical) return;
     const int32_t W = WT ? WT : m.W;
     int64_t i, end, stride;

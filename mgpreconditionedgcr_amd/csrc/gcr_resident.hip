@@ -26,8 +26,10 @@
 // takes gcr.hip's path.  A workgroup that waits longer than ~4 s for another one (the launch was not co-resident:
 // foreign work on the device) raises the abort flag, every workgroup leaves, x is poisoned with NaN and the next
 // host synchronisation reports the failure — no wave spins forever.
+#include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "internal.h"
 #include "reduce.h"
@@ -60,6 +62,7 @@ struct ResidentArgs {
     double tol2;
     int max_it, storage;
     int from_zero, alpha_only_last;
+    int nbr;             // a row gathers from at most this many workgroups to either side of its own
     double *hist;
     int hist_cap;
     cplx *ring;          // (R + 1) slots of n rows: 0 = the residual a closing step starts the next cycle from, m = D_m, R = P0 after the first cycle
@@ -84,13 +87,21 @@ __device__ __forceinline__ void st_coh(__amdgpu_buffer_rsrc_t r, int idx, int so
     __builtin_amdgcn_raw_buffer_store_b128(w, r, idx * 16, soff, RES_SC1);
 }
 
-__device__ __forceinline__ void res_tick(const unsigned long long *dbg_on, unsigned long long *acc, unsigned long long &t_prev, int phase) {
-    if (dbg_on) {
-        const unsigned long long t = wall_clock64();
-        acc[phase] += t - t_prev;
-        t_prev = t;
-    }
-}
+// development aid (build with EXTRA=-DMGCR_RES_TIMING, run with MGCR_RES_TIMING=1): ticks of the 100 MHz clock per phase of
+// a step, summed over the solve by workgroup 0 and printed by gcr_resident_run.  Off by default: the 8 accumulators are
+// 18 registers the ten-image kernel does not have.
+#ifdef MGCR_RES_TIMING
+#define RES_TICK(a, S, phase)                                \
+    do {                                                     \
+        if ((a).dbg) {                                       \
+            const unsigned long long t_ = wall_clock64();    \
+            (S).tacc[(phase) + 8 * (K >= 5 ? 1 : 0)] += t_ - (S).tprev; \
+            (S).tprev = t_;                                  \
+        }                                                    \
+    } while (0)
+#else
+#define RES_TICK(a, S, phase) do { } while (0)
+#endif
 
 struct ResSync {
     __amdgpu_buffer_rsrc_t slots;
@@ -133,21 +144,27 @@ __device__ __forceinline__ void res_publish(ResSync &s, int kind) {
 // tree of reduce.h fold_partials and stores the group sum, RES_COPIES times (4.5 KB apart: other channels).  Hop 2:
 // thread (k, g) of every workgroup polls its copy of group sum (k, g) into LDS.  false: somebody did not show up in
 // time (abort).
-template <int NVT>
+// EXTRA: scalar NVT of this exchange is scalar 0 of the kind-0 exchange published one generation earlier and not collected
+// then (the |r|^2 partials, whose publication only served as the neighbours' signal: res_neighbour_wait).
+template <int NVT, bool EXTRA = false>
 __device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
-    static_assert(NVT <= RES_NV, "scalars per exchange");
+    constexpr int NS = NVT + (EXTRA ? 1 : 0);
+    static_assert(NS <= RES_NV, "scalars per exchange");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = (s.nblk + 63) >> 6;   // groups that hold workgroups
-    for (int task = wave * s.nblk + s.lb; task < ng * NVT; task += (RED_THREADS / 64) * s.nblk) {   // wave-uniform
-        const int g = task / NVT, k = task - g * NVT;
+    for (int task = wave * s.nblk + s.lb; task < ng * NS; task += (RED_THREADS / 64) * s.nblk) {   // wave-uniform
+        const int g = task / NS, k = task - g * NS;
         const int blk = g * 64 + lane;
+        const bool extra = EXTRA && k == NVT;
+        const int src = extra ? blk : (kind * RES_NV + k) * RES_BLK + blk;
+        const unsigned want = extra ? s.gen - 1u : s.gen;
         double v = 0.;
         if (blk < s.nblk) {
             int spins = 0;
             for (;;) {
-                const v4i w = __builtin_amdgcn_raw_buffer_load_b128(s.slots, ((kind * RES_NV + k) * RES_BLK + blk) * 16, 0, RES_SC1);
+                const v4i w = __builtin_amdgcn_raw_buffer_load_b128(s.slots, src * 16, 0, RES_SC1);
                 v = __hiloint2double(w.y, w.x);
-                if ((unsigned)w.z == s.gen) break;
+                if ((unsigned)w.z == want) break;
                 spins++;
                 if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     *s.gave_up = 1;
@@ -164,7 +181,7 @@ __device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
             __builtin_amdgcn_raw_buffer_store_b128(w4, s.slots, RES_L2_BASE + ((lane * 3 + kind) * RES_NV + k) * 4 * 16 + g * 16, 0, RES_SC1);
         }
     }
-    if ((int)threadIdx.x < 4 * NVT) {
+    if ((int)threadIdx.x < 4 * NS) {
         const int k = threadIdx.x >> 2, g = threadIdx.x & 3;
         double v = 0.;
         if (g < ng) {
@@ -189,6 +206,32 @@ __device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
     s.gen++;
     return *s.gave_up == 0;
 }
+// The residual hand-over needs no device-wide rendezvous: a workgroup gathers rows of the workgroups lb - nbr .. lb + nbr
+// only, and each of those publishes its |r|^2 slot (kind 0, scalar 0) after its residual rows have reached memory.  Wave 0
+// polls those slots (one hop), the totals are folded later (res_collect<.., true>).  A slot may already carry a later
+// generation only in theory (see the file header); >= keeps the wait finite even then.
+__device__ __forceinline__ bool res_neighbour_wait(ResSync &s, int nbr) {
+    if (threadIdx.x < 64) {
+        for (int b = s.lb - nbr + (int)threadIdx.x; b <= s.lb + nbr; b += 64) {
+            if (b < 0 || b >= s.nblk || b == s.lb) continue;
+            int spins = 0;
+            for (;;) {
+                const v4i w = __builtin_amdgcn_raw_buffer_load_b128(s.slots, b * 16, 0, RES_SC1);
+                if ((int)((unsigned)w.z - s.gen) >= 0) break;
+                spins++;
+                if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    *s.gave_up = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+    __syncthreads();
+    s.gen++;
+    return *s.gave_up == 0;
+}
+
 // sum over all workgroups of scalar k of the exchange collected last (reduce.h block_sum_bcast: waves in index order from 0.;
 // the waves past the fourth hold no workgroup and would add + 0.0)
 __device__ __forceinline__ double res_total(const ResSync &s, int k) {
@@ -208,7 +251,9 @@ struct ResState {
     bool x_live;         // x holds something to add to (else: x0 = 0 that was never written)
     bool p0_rhs;         // first cycle: P0 is the right-hand side itself
     bool aborted;
-    unsigned long long tacc[8], tprev;
+#ifdef MGCR_RES_TIMING
+    unsigned long long tacc[16], tprev;
+#endif
 };
 
 template <int R>
@@ -225,7 +270,7 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
     constexpr int nxt = closing ? 0 : K + 1;
     S.it++;
     const int it = S.it;
-    res_tick(a.dbg, S.tacc, S.tprev, 7);   // (whatever ran since the last tick: loop overhead)
+    RES_TICK(a, S, 7);   // (whatever ran since the last tick: loop overhead)
     const bool last = it == a.max_it;
     // alpha and its bookkeeping (gcr.hip xr_update_kernel<true, true> / alpha_only_kernel)
     const cplx alpha = to_sgpr(cdiv(S.num, S.den));
@@ -251,17 +296,18 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
         __builtin_amdgcn_s_waitcnt(0);
         res_contrib<1>(sy, 0, v);
         res_publish<1>(sy, 0);
-        res_tick(a.dbg, S.tacc, S.tprev, 0);
-        if (!res_collect<1>(sy, 0)) { S.aborted = true; return false; }
-        res_tick(a.dbg, S.tacc, S.tprev, 1);
-    }
-    {   // the step's bookkeeping (gcr.hip close_step)
-        const double rr = to_sgpr(res_total(sy, 0));
-        S.iter = it;
-        S.rr = rr;
-        if (owner0 && it < a.hist_cap) a.hist[it] = sqrt(rr) / sqrt(S.bnorm2);
-        if (!((rr / S.bnorm2) > a.tol2)) { S.stop_at = it; return false; }
-        if (last) return false;
+        RES_TICK(a, S, 0);
+        if (last) {   // nothing after this step: fold |r|^2 now (gcr.hip finish_step_kernel)
+            if (!res_collect<1>(sy, 0)) { S.aborted = true; return false; }
+            const double rr = to_sgpr(res_total(sy, 0));
+            S.iter = it;
+            S.rr = rr;
+            if (owner0 && it < a.hist_cap) a.hist[it] = sqrt(rr) / sqrt(S.bnorm2);
+            if (!((rr / S.bnorm2) > a.tol2)) S.stop_at = it;
+            return false;
+        }
+        if (!res_neighbour_wait(sy, a.nbr)) { S.aborted = true; return false; }
+        RES_TICK(a, S, 1);
     }
     // Ar = A r (or r - k A r) from the neighbours' rows, <Ar, Ap_j> for the stored directions
     cplx ar = make_double2(0., 0.);
@@ -270,7 +316,7 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
         const cplx sum = fused_row_product<MODE, NS>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); });
         ar = a.m.shift ? csub(rn, cmul(a.m.k, sum)) : sum;
     }
-    res_tick(a.dbg, S.tacc, S.tprev, 2);
+    RES_TICK(a, S, 2);
     {
         constexpr int NVB = 2 * lim;
 #pragma unroll
@@ -297,9 +343,15 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
             res_contrib<tail>(sy, c0, v);
         }
         res_publish<NVB>(sy, 1);
-        res_tick(a.dbg, S.tacc, S.tprev, 3);
-        if (!res_collect<NVB>(sy, 1)) { S.aborted = true; return false; }
-        res_tick(a.dbg, S.tacc, S.tprev, 4);
+        RES_TICK(a, S, 3);
+        if (!res_collect<NVB, true>(sy, 1)) { S.aborted = true; return false; }
+        RES_TICK(a, S, 4);
+        // the step's bookkeeping (gcr.hip close_step, inside the build kernels: after the apply, like here)
+        const double rr = to_sgpr(res_total(sy, NVB));
+        S.iter = it;
+        S.rr = rr;
+        if (owner0 && it < a.hist_cap) a.hist[it] = sqrt(rr) / sqrt(S.bnorm2);
+        if (!((rr / S.bnorm2) > a.tol2)) { S.stop_at = it; return false; }
     }
     // beta_j, the coefficient table, the new image (gcr.hip build_lean_kernel / close_x_kernel / build_close_kernel)
     if ((int)threadIdx.x < lim) tb.beta[threadIdx.x] = cdiv(make_double2(res_total(sy, 2 * threadIdx.x), res_total(sy, 2 * threadIdx.x + 1)), tb.den[threadIdx.x]);
@@ -377,9 +429,9 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
         }
         res_contrib<4>(sy, 0, v);
         res_publish<4>(sy, 2);
-        res_tick(a.dbg, S.tacc, S.tprev, 5);
+        RES_TICK(a, S, 5);
         if (!res_collect<4>(sy, 2)) { S.aborted = true; return false; }
-        res_tick(a.dbg, S.tacc, S.tprev, 6);
+        RES_TICK(a, S, 6);
         S.num = to_sgpr(make_double2(res_total(sy, 0), res_total(sy, 1)));
         S.den = to_sgpr(make_double2(res_total(sy, 2), res_total(sy, 3)));
     }
@@ -435,8 +487,10 @@ __global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentAr
     S.p0_rhs = true;
     S.it = 0; S.npend = 0; S.stop_at = INT_MAX; S.iter = 0; S.rr = 0.; S.bnorm2 = 0.;
     S.aborted = false;
-    for (int q = 0; q < 8; q++) S.tacc[q] = 0;
+#ifdef MGCR_RES_TIMING
+    for (int q = 0; q < 16; q++) S.tacc[q] = 0;
     S.tprev = a.dbg ? wall_clock64() : 0ull;
+#endif
     // step 0: Ap_0 = A r_0 and <r_0,Ap_0>, <Ap_0,Ap_0>, |r_0|^2 = |b|^2 (gcr_fused.hip init_apply_kernel, gcr.hip init_kernel)
     {
         double v[5] = {0., 0., 0., 0., 0.};
@@ -492,8 +546,10 @@ __global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentAr
         }
         if (act) a.x[i] = xv;
     }
+#ifdef MGCR_RES_TIMING
     if (owner0 && a.dbg)
-        for (int q = 0; q < 8; q++) a.dbg[q] = S.tacc[q];
+        for (int q = 0; q < 16; q++) a.dbg[q] = S.tacc[q];
+#endif
     if (owner0) {
         a.st->stop_at = S.stop_at; a.st->base = 0; a.st->iter = S.iter; a.st->npend = 0; a.st->bnorm2 = S.bnorm2; a.st->rr = S.rr; a.st->tol2 = a.tol2;
     }
@@ -601,12 +657,17 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     a.storage = storage;
     a.from_zero = from_zero ? 1 : 0;
     a.alpha_only_last = alpha_only_last ? 1 : 0;
+    {
+        int64_t reach = 0;
+        for (int c = 0; c < M.sten_ns; c++) reach = std::max<int64_t>(reach, std::llabs((long long)M.sten_off[c]));
+        a.nbr = (int)((reach + RED_THREADS - 1) / RED_THREADS);
+    }
     a.hist = hist; a.hist_cap = hist_cap;
     a.ring = ring;
     a.slots = sh.slots; a.abort_dev = sh.abort_dev; a.abort_host = sh.abort_host;
     static const bool timing = getenv("MGCR_RES_TIMING") && atoi(getenv("MGCR_RES_TIMING")) != 0;
     static unsigned long long *dbg = nullptr;
-    if (timing && !dbg) { MGCR_HIP(hipMalloc((void **)&dbg, 8 * sizeof(unsigned long long))); }
+    if (timing && !dbg) { MGCR_HIP(hipMalloc((void **)&dbg, 16 * sizeof(unsigned long long))); }
     a.dbg = timing ? dbg : nullptr;
     const unsigned need = 3u * (unsigned)a.max_it + 4u;
     if (sh.gen > 0xffffffffu - need - 1u) {   // generations never repeat: start over on cleared slots
@@ -625,14 +686,14 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     MGCR_HIP(hipGetLastError());
     g_resident_solves++;
     if (timing) {   // development aid: where the steps of this solve spent their time (workgroup 0)
-        unsigned long long h[8];
+        unsigned long long h[16];
         MGCR_HIP(hipStreamSynchronize(ctx().stream));
         MGCR_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
         const char *names[8] = {"xr + publish |r|^2", "collect |r|^2", "bookkeeping + gather + apply", "dots + publish", "collect beta numerators",
                                 "beta, table, build + publish", "collect <r,Ap>, <Ap,Ap>", "between steps"};
         fprintf(stderr, "resident solve, n = %lld, max_it %d:", (long long)n, a.max_it);
-        for (int q = 0; q < 8; q++) fprintf(stderr, " [%s] %.1f us", names[q], (double)h[q] * 0.01);
-        fprintf(stderr, " (totals over all steps)\n");
+        for (int q = 0; q < 8; q++) fprintf(stderr, " [%s] %.1f + %.1f us", names[q], (double)h[q] * 0.01, (double)h[q + 8] * 0.01);
+        fprintf(stderr, " (totals over the steps at cycle positions 0-4 + 5-9)\n");
     }
     return MGCR_OK;
 }
