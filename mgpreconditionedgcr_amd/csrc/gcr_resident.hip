@@ -42,6 +42,7 @@ constexpr int RES_NV = 24;          // scalars per exchange kind (<= 2 * 10 beta
 constexpr int RES_BLK = 256;        // workgroups at most (one per CU)
 constexpr int RES_CHUNK = 8;        // scalars folded at a time (register footprint of the shuffle tree)
 constexpr int RES_SPIN_LIMIT = 1 << 22;
+constexpr int RES_RPT_DEFAULT = 2;  // rows per thread (MGCR_RESIDENT_RPT = 1, 2, 4 for experiments)
 constexpr int RES_COPIES = 16;      // copies of every group sum (workgroup b reads copy b % 16)
 constexpr int RES_L1_BYTES = 3 * RES_NV * RES_BLK * 16;            // {value, generation} per (kind, scalar, workgroup)
 constexpr int RES_L2_BASE = RES_L1_BYTES;                          // then [copy][kind][scalar][group of 64 workgroups]
@@ -118,14 +119,16 @@ struct ResSync {
 // slot), collect (every wave polls a share of the slots — 64 workgroups x a few scalars — and sums them with the
 // shuffle tree of reduce.h fold_partials; one barrier), total (any thread: the <= 4 group sums in order).  Same
 // operands, same order, same bits as the per-workgroup partial slabs of gcr.hip's kernels; 2 barriers per exchange.
+// vw: which 64 rows of the workgroup's 1024 these lanes hold (a thread owns RPT rows, 1024 / RPT apart: wave w holds the
+// row sets w, w + nwaves, ...) — the slot a 1024-thread workgroup's wave vw would write
 template <int NV>
-__device__ __forceinline__ void res_contrib(ResSync &s, int k0, double (&v)[NV]) {
+__device__ __forceinline__ void res_contrib(ResSync &s, int k0, double (&v)[NV], int vw) {
     static_assert(NV <= RES_CHUNK, "chunk");
     constexpr int NVP = WaveMulti<NV>::NVP;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     double t;
     const int k = wave_multi_sum<NV>(v, t);
-    if ((lane & (64 / NVP - 1)) == 0 && k < NV) s.pw[(k0 + k) * 17 + wave] = t;
+    if ((lane & (64 / NVP - 1)) == 0 && k < NV) s.pw[(k0 + k) * 17 + vw] = t;
 }
 template <int NVT>
 __device__ __forceinline__ void res_publish(ResSync &s, int kind) {
@@ -133,7 +136,7 @@ __device__ __forceinline__ void res_publish(ResSync &s, int kind) {
     if ((int)threadIdx.x < NVT) {
         double t = 0.;
 #pragma unroll
-        for (int w = 0; w < RED_THREADS / 64; w++) t += s.pw[threadIdx.x * 17 + w];
+        for (int w = 0; w < RED_THREADS / 64; w++) t += s.pw[threadIdx.x * 17 + w];   // 16 sets of 64 rows, whatever the thread count
         const v4i w4 = {__double2loint(t), __double2hiint(t), (int)s.gen, 0};
         __builtin_amdgcn_raw_buffer_store_b128(w4, s.slots, ((kind * RES_NV + (int)threadIdx.x) * RES_BLK + s.lb) * 16, 0, RES_SC1);
     }
@@ -152,7 +155,7 @@ __device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
     static_assert(NS <= RES_NV, "scalars per exchange");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = (s.nblk + 63) >> 6;   // groups that hold workgroups
-    for (int task = wave * s.nblk + s.lb; task < ng * NS; task += (RED_THREADS / 64) * s.nblk) {   // wave-uniform
+    for (int task = wave * s.nblk + s.lb; task < ng * NS; task += ((int)blockDim.x >> 6) * s.nblk) {   // wave-uniform
         const int g = task / NS, k = task - g * NS;
         const int blk = g * 64 + lane;
         const bool extra = EXTRA && k == NVT;
@@ -241,10 +244,51 @@ __device__ __forceinline__ double res_total(const ResSync &s, int k) {
     return t;
 }
 
-template <int R>
+
+// spmv_dev.h sten_row_product_t<NS, false, -1> for the RPT rows of a thread at once: the gathers of ALL rows are in flight before
+// the first one is looked at (row by row they would cost RPT memory round trips); per row the same loads, the same terms in
+// the same order, the same bits.
+template <int NS, int RPT, class XF>
+__device__ __forceinline__ void res_sten_rows(const RowMat &m, const int (&row)[RPT], const bool (&act)[RPT], XF xf, cplx (&sum)[RPT]) {
+    uint64_t pl[RPT][NS];
+    cplx xv[RPT][NS];
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        // (an inactive row set — past the last row — reads the zero presence row behind the last wave and row 0's neighbours: unused)
+        const int r = act[h] ? row[h] : 0;
+        const int32_t wave = __builtin_amdgcn_readfirstlane(act[h] ? (int32_t)(row[h] >> 6) : m.sten_nwaves);
+        const sten_planes_ptr pp = sten_wave_planes(m, wave);
+#pragma unroll
+        for (int c = 0; c < NS; c++) pl[h][c] = pp[c];
+#pragma unroll
+        for (int c = 0; c < NS; c++) {
+            int32_t j = (int32_t)r + m.sten_off[c];
+            j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
+            xv[h][c] = xf(j);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        cplx s = make_double2(0., 0.);
+#pragma unroll
+        for (int c = 0; c < NS; c++) {
+            const bool on = (pl[h][c] >> lane & 1ull) != 0ull;
+            const cplx ns = cadd(s, sten_term<-1>(m, c, xv[h][c]));
+            s.x = on ? ns.x : s.x;
+            s.y = on ? ns.y : s.y;
+        }
+        sum[h] = s;
+    }
+}
+
+template <int R, int RPT>
 struct ResState {
-    cplx Ap[R];          // images of the cycle's directions, this thread's row
-    cplx rv;
+    cplx Ap[RPT][R];     // images of the cycle's directions, this thread's rows
+    cplx rv[RPT];
+    int row[RPT];        // the rows (1024 / RPT apart inside the workgroup's 1024)
+    bool act[RPT];
     cplx num, den;       // <r,Ap_cur>, <Ap_cur,Ap_cur>
     double bnorm2, rr;
     int it, npend, stop_at, iter;
@@ -263,11 +307,12 @@ struct ResTables {       // LDS: gcr_dev.h LeanCoef with rows of R, plus the per
 
 // One step at cycle position K (direction K is the current one, lim = K + 1 directions are stored).  Returns false when the
 // solve is over (converged, last iteration, abort).
-template <int MODE, int NS, int R, int K>
-__device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, ResTables<R> &tb, ResSync &sy, __amdgpu_buffer_rsrc_t ring, int i, bool act, bool owner0) {
+template <int MODE, int NS, int R, int RPT, int K>
+__device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R, RPT> &S, ResTables<R> &tb, ResSync &sy, __amdgpu_buffer_rsrc_t ring, bool owner0) {
     constexpr int lim = K + 1;
     constexpr bool closing = K + 1 == R;
     constexpr int nxt = closing ? 0 : K + 1;
+    const int nwave = (int)blockDim.x >> 6, wave = (int)threadIdx.x >> 6;
     S.it++;
     const int it = S.it;
     RES_TICK(a, S, 7);   // (whatever ran since the last tick: loop overhead)
@@ -286,15 +331,22 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
         S.iter = it;
         return false;
     }
-    const cplx rn = csub(S.rv, cmul(alpha, S.Ap[K]));
-    S.rv = rn;
     const int vbytes = (int)a.n * 16;   // one ring slot
-    if (act && !last) st_coh(ring, i, nxt * vbytes, rn);
-    {   // |r|^2; the residual has reached memory when the workgroup's slot says so (every wave waits for its store first)
-        double v[1] = {0.};
-        if (act) v[0] += rn.x * rn.x + rn.y * rn.y;
+    cplx rn[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        rn[h] = csub(S.rv[h], cmul(alpha, S.Ap[h][K]));
+        S.rv[h] = rn[h];
+        if (S.act[h] && !last) st_coh(ring, S.row[h], nxt * vbytes, rn[h]);
+    }
+    {   // |r|^2; the residual has reached memory when the workgroup's slot says so (every wave waits for its stores first)
         __builtin_amdgcn_s_waitcnt(0);
-        res_contrib<1>(sy, 0, v);
+#pragma unroll
+        for (int h = 0; h < RPT; h++) {
+            double v[1] = {0.};
+            if (S.act[h]) v[0] += rn[h].x * rn[h].x + rn[h].y * rn[h].y;
+            res_contrib<1>(sy, 0, v, h * nwave + wave);
+        }
         res_publish<1>(sy, 0);
         RES_TICK(a, S, 0);
         if (last) {   // nothing after this step: fold |r|^2 now (gcr.hip finish_step_kernel)
@@ -310,37 +362,45 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
         RES_TICK(a, S, 1);
     }
     // Ar = A r (or r - k A r) from the neighbours' rows, <Ar, Ap_j> for the stored directions
-    cplx ar = make_double2(0., 0.);
-    if (act) {
-        const PatLds pl{nullptr, nullptr, nullptr};
-        const cplx sum = fused_row_product<MODE, NS>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); });
-        ar = a.m.shift ? csub(rn, cmul(a.m.k, sum)) : sum;
+    cplx ar[RPT];
+    {
+        static_assert(MODE == 3, "stencil view");
+        cplx sum[RPT];
+        res_sten_rows<NS, RPT>(a.m, S.row, S.act, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); }, sum);
+#pragma unroll
+        for (int h = 0; h < RPT; h++) {
+            ar[h] = make_double2(0., 0.);
+            if (S.act[h]) ar[h] = a.m.shift ? csub(rn[h], cmul(a.m.k, sum[h])) : sum[h];
+        }
     }
     RES_TICK(a, S, 2);
     {
         constexpr int NVB = 2 * lim;
 #pragma unroll
-        for (int c0 = 0; c0 + RES_CHUNK <= NVB; c0 += RES_CHUNK) {
-            double v[RES_CHUNK];
+        for (int h = 0; h < RPT; h++) {
 #pragma unroll
-            for (int q = 0; q < RES_CHUNK / 2; q++) {
-                const cplx t = act ? cconj_mul(ar, S.Ap[c0 / 2 + q]) : make_double2(0., 0.);
-                v[2 * q] = 0. + t.x;
-                v[2 * q + 1] = 0. + t.y;
-            }
-            res_contrib<RES_CHUNK>(sy, c0, v);
-        }
-        constexpr int tail = NVB % RES_CHUNK;
-        if constexpr (tail > 0) {
-            constexpr int c0 = NVB - tail;
-            double v[tail];
+            for (int c0 = 0; c0 + RES_CHUNK <= NVB; c0 += RES_CHUNK) {
+                double v[RES_CHUNK];
 #pragma unroll
-            for (int q = 0; q < tail / 2; q++) {
-                const cplx t = act ? cconj_mul(ar, S.Ap[c0 / 2 + q]) : make_double2(0., 0.);
-                v[2 * q] = 0. + t.x;
-                v[2 * q + 1] = 0. + t.y;
+                for (int q = 0; q < RES_CHUNK / 2; q++) {
+                    const cplx t = S.act[h] ? cconj_mul(ar[h], S.Ap[h][c0 / 2 + q]) : make_double2(0., 0.);
+                    v[2 * q] = 0. + t.x;
+                    v[2 * q + 1] = 0. + t.y;
+                }
+                res_contrib<RES_CHUNK>(sy, c0, v, h * nwave + wave);
             }
-            res_contrib<tail>(sy, c0, v);
+            constexpr int tail = NVB % RES_CHUNK;
+            if constexpr (tail > 0) {
+                constexpr int c0 = NVB - tail;
+                double v[tail];
+#pragma unroll
+                for (int q = 0; q < tail / 2; q++) {
+                    const cplx t = S.act[h] ? cconj_mul(ar[h], S.Ap[h][c0 / 2 + q]) : make_double2(0., 0.);
+                    v[2 * q] = 0. + t.x;
+                    v[2 * q + 1] = 0. + t.y;
+                }
+                res_contrib<tail>(sy, c0, v, h * nwave + wave);
+            }
         }
         res_publish<NVB>(sy, 1);
         RES_TICK(a, S, 3);
@@ -356,22 +416,7 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
     // beta_j, the coefficient table, the new image (gcr.hip build_lean_kernel / close_x_kernel / build_close_kernel)
     if ((int)threadIdx.x < lim) tb.beta[threadIdx.x] = cdiv(make_double2(res_total(sy, 2 * threadIdx.x), res_total(sy, 2 * threadIdx.x + 1)), tb.den[threadIdx.x]);
     __syncthreads();
-    if constexpr (!closing) {
-        if ((int)threadIdx.x <= lim) {   // table row k = lim
-            constexpr int k = lim;
-            const int m = threadIdx.x;
-            cplx c = make_double2(0., 0.);
-            if (m == 0) {
-                for (int j = 0; j < k; j++) c = csub(c, cmul(tb.beta[j], j == 0 ? make_double2(1., 0.) : tb.t[j]));
-                tb.t[k] = c;
-            } else if (m < k) {
-                for (int j = m; j < k; j++) c = csub(c, cmul(tb.beta[j], j == m ? make_double2(1., 0.) : tb.T[j * R + m]));
-                tb.T[k * R + m] = c;
-            } else {
-                tb.T[k * R + k] = make_double2(1., 0.);
-            }
-        }
-    } else {
+    if constexpr (closing) {
         if ((int)threadIdx.x < lim) {
             const int m = threadIdx.x;
             cplx c = make_double2(0., 0.);
@@ -384,52 +429,86 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
         }
         __syncthreads();
     }
-    cplx ac = make_double2(0., 0.);
+    cplx beta[lim];
 #pragma unroll
-    for (int j = 0; j < lim; j++) ac = csub(ac, cmul(to_sgpr(tb.beta[j]), S.Ap[j]));
-    const cplx an = cadd(ar, ac);
+    for (int j = 0; j < lim; j++) beta[j] = to_sgpr(tb.beta[j]);
+    cplx an[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        cplx ac = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < lim; j++) ac = csub(ac, cmul(beta[j], S.Ap[h][j]));
+        an[h] = cadd(ar[h], ac);
+    }
     if constexpr (closing) {
         // x += cx_0 P0 + sum_m cx_m D_m;  P0' = D_R - cp_0 P0 - sum_m cp_m D_m  (D_R = this step's residual); own rows only,
-        // five vectors at a time (all ten in flight do not fit the registers next to the ten images)
-        cplx xv = (act && S.x_live) ? a.x[i] : make_double2(0., 0.);
-        cplx pc = make_double2(0., 0.);
+        // five vectors at a time
 #pragma unroll
-        for (int j0 = 0; j0 < R; j0 += 5) {
-            cplx pj[5];
+        for (int h = 0; h < RPT; h++) {
+            const int i = S.row[h];
+            const bool act = S.act[h];
+            cplx xv = (act && S.x_live) ? a.x[i] : make_double2(0., 0.);
+            cplx pc = make_double2(0., 0.);
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
-                const int j = j0 + q;
-                pj[q] = make_double2(0., 0.);
-                if (act && j < R) pj[q] = j == 0 ? (S.p0_rhs ? a.rhs[i] : ld_coh(ring, i, R * vbytes)) : ld_coh(ring, i, j * vbytes);
+            for (int j0 = 0; j0 < R; j0 += 5) {
+                cplx pj[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const int j = j0 + q;
+                    pj[q] = make_double2(0., 0.);
+                    if (act && j < R) pj[q] = j == 0 ? (S.p0_rhs ? a.rhs[i] : ld_coh(ring, i, R * vbytes)) : ld_coh(ring, i, j * vbytes);
+                }
+#pragma unroll
+                for (int q = 0; q < 5; q++)
+                    if (j0 + q < R) xv = cadd(xv, cmul(to_sgpr(tb.cx[j0 + q]), pj[q]));
+#pragma unroll
+                for (int q = 0; q < 5; q++)
+                    if (j0 + q < R) pc = csub(pc, cmul(to_sgpr(tb.cp[j0 + q]), pj[q]));
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int q = 0; q < 5; q++)
-                if (j0 + q < R) xv = cadd(xv, cmul(to_sgpr(tb.cx[j0 + q]), pj[q]));
-#pragma unroll
-            for (int q = 0; q < 5; q++)
-                if (j0 + q < R) pc = csub(pc, cmul(to_sgpr(tb.cp[j0 + q]), pj[q]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (act) {
-            a.x[i] = xv;
-            st_coh(ring, i, R * vbytes, cadd(rn, pc));
+            if (act) {
+                a.x[i] = xv;
+                st_coh(ring, i, R * vbytes, cadd(rn[h], pc));
+            }
         }
         S.x_live = true;
         S.p0_rhs = false;
         S.npend = 0;
     }
-    S.Ap[nxt] = an;
+#pragma unroll
+    for (int h = 0; h < RPT; h++) S.Ap[h][nxt] = an[h];
     {
-        double v[4] = {0., 0., 0., 0.};
-        if (act) {
-            const cplx t = cconj_mul(rn, an);
-            v[0] += t.x; v[1] += t.y;
-            const cplx u = cconj_mul(an, an);
-            v[2] += u.x; v[3] += u.y;
+#pragma unroll
+        for (int h = 0; h < RPT; h++) {
+            double v[4] = {0., 0., 0., 0.};
+            if (S.act[h]) {
+                const cplx t = cconj_mul(rn[h], an[h]);
+                v[0] += t.x; v[1] += t.y;
+                const cplx u = cconj_mul(an[h], an[h]);
+                v[2] += u.x; v[3] += u.y;
+            }
+            res_contrib<4>(sy, 0, v, h * nwave + wave);
         }
-        res_contrib<4>(sy, 0, v);
         res_publish<4>(sy, 2);
         RES_TICK(a, S, 5);
+        // the coefficient table's row k = lim, by the LAST wave while the exchange is under way (the first waves carry the
+        // exchange's tasks); its readers (the next step's pending-x update, the closing step) are behind later barriers
+        if constexpr (!closing) {
+            const int m = (int)threadIdx.x - ((int)blockDim.x - 64);
+            if (m >= 0 && m <= lim) {
+                constexpr int k = lim;
+                cplx c = make_double2(0., 0.);
+                if (m == 0) {
+                    for (int j = 0; j < k; j++) c = csub(c, cmul(tb.beta[j], j == 0 ? make_double2(1., 0.) : tb.t[j]));
+                    tb.t[k] = c;
+                } else if (m < k) {
+                    for (int j = m; j < k; j++) c = csub(c, cmul(tb.beta[j], j == m ? make_double2(1., 0.) : tb.T[j * R + m]));
+                    tb.T[k * R + m] = c;
+                } else {
+                    tb.T[k * R + k] = make_double2(1., 0.);
+                }
+            }
+        }
         if (!res_collect<4>(sy, 2)) { S.aborted = true; return false; }
         RES_TICK(a, S, 6);
         S.num = to_sgpr(make_double2(res_total(sy, 0), res_total(sy, 1)));
@@ -438,22 +517,26 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R> &S, 
     return true;
 }
 
-template <int MODE, int NS, int R, int K>
-__device__ __forceinline__ bool res_cycle(const ResidentArgs &a, ResState<R> &S, ResTables<R> &tb, ResSync &sy, __amdgpu_buffer_rsrc_t ring, int i, bool act, bool owner0) {
+template <int MODE, int NS, int R, int RPT, int K>
+__device__ __forceinline__ bool res_cycle(const ResidentArgs &a, ResState<R, RPT> &S, ResTables<R> &tb, ResSync &sy, __amdgpu_buffer_rsrc_t ring, bool owner0) {
     if constexpr (K < R) {
         if (K >= a.storage) return false;   // (never reached: a solve whose cycle cannot close ends by max_it before)
-        if (!res_step<MODE, NS, R, K>(a, S, tb, sy, ring, i, act, owner0)) return false;
-        return res_cycle<MODE, NS, R, K + 1>(a, S, tb, sy, ring, i, act, owner0);
+        if (!res_step<MODE, NS, R, RPT, K>(a, S, tb, sy, ring, owner0)) return false;
+        return res_cycle<MODE, NS, R, RPT, K + 1>(a, S, tb, sy, ring, owner0);
     } else {
         return true;
     }
 }
 
-template <int MODE, int NS, int R>
-__global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentArgs a) {
+// RPT rows per thread: 1024 / RPT threads per workgroup.  The reductions are those of 1024 threads (16 sums of 64 rows per
+// workgroup and scalar); what shrinks with the thread count is everything a wave does whatever its rows (alpha, beta, the
+// exchanges' polling, addressing): more than half of a step's instructions with one row per thread.
+template <int MODE, int NS, int R, int RPT>
+__global__ void __launch_bounds__(RED_THREADS / RPT, RED_THREADS / RPT / 256) gcr_resident_kernel(ResidentArgs a) {
     __shared__ double lds_pw[RES_NV * 17], lds_ws[RES_NV * 4];
     __shared__ int gave_up;
     __shared__ ResTables<R> tb;
+    constexpr int T = RED_THREADS / RPT;
     const int lb = logical_workgroup(a.rm, (int)blockIdx.x, (int)gridDim.x);
     const bool owner0 = lb == 0 && threadIdx.x == 0;
     // an outer solve that is over silences this one (gcr.hip reset_kernel)
@@ -464,10 +547,9 @@ __global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentAr
         return;
     }
     if (lb >= a.nlogical) return;
-    const int i = lb * RED_THREADS + (int)threadIdx.x;
-    const bool act = i < a.n;
     const int vbytes = (int)a.n * 16;
     const __amdgpu_buffer_rsrc_t ring = res_rsrc(a.ring, (unsigned)(R + 1) * (unsigned)vbytes);
+    const int nwave = T / 64, wave = (int)threadIdx.x >> 6;
     ResSync sy;
     sy.slots = res_rsrc(a.slots, (unsigned)RES_SLOT_BYTES);
     sy.gen = a.gen0;
@@ -479,10 +561,15 @@ __global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentAr
     sy.gave_up = &gave_up;
     if (threadIdx.x == 0) gave_up = 0;
     __syncthreads();
-    ResState<R> S;
+    ResState<R, RPT> S;
 #pragma unroll
-    for (int j = 0; j < R; j++) S.Ap[j] = make_double2(0., 0.);
-    S.rv = act ? a.rhs[i] : make_double2(0., 0.);
+    for (int h = 0; h < RPT; h++) {
+        S.row[h] = lb * RED_THREADS + h * T + (int)threadIdx.x;
+        S.act[h] = S.row[h] < a.n;
+#pragma unroll
+        for (int j = 0; j < R; j++) S.Ap[h][j] = make_double2(0., 0.);
+        S.rv[h] = S.act[h] ? a.rhs[S.row[h]] : make_double2(0., 0.);
+    }
     S.x_live = !a.from_zero;
     S.p0_rhs = true;
     S.it = 0; S.npend = 0; S.stop_at = INT_MAX; S.iter = 0; S.rr = 0.; S.bnorm2 = 0.;
@@ -493,19 +580,23 @@ __global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentAr
 #endif
     // step 0: Ap_0 = A r_0 and <r_0,Ap_0>, <Ap_0,Ap_0>, |r_0|^2 = |b|^2 (gcr_fused.hip init_apply_kernel, gcr.hip init_kernel)
     {
-        double v[5] = {0., 0., 0., 0., 0.};
-        if (act) {
-            const PatLds pl{nullptr, nullptr, nullptr};
-            const cplx sum = fused_row_product<MODE, NS>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return a.rhs[j]; });
-            const cplx yi = a.m.shift ? csub(S.rv, cmul(a.m.k, sum)) : sum;
-            S.Ap[0] = yi;
-            v[4] += S.rv.x * S.rv.x + S.rv.y * S.rv.y;
-            const cplx t = cconj_mul(S.rv, yi);
-            v[0] += t.x; v[1] += t.y;
-            const cplx u = cconj_mul(yi, yi);
-            v[2] += u.x; v[3] += u.y;
+#pragma unroll
+        for (int h = 0; h < RPT; h++) {
+            double v[5] = {0., 0., 0., 0., 0.};
+            if (S.act[h]) {
+                const PatLds pl{nullptr, nullptr, nullptr};
+                const cplx sum = fused_row_product<MODE, NS>(a.m, S.row[h], 0, pl, [&](int32_t j) -> cplx { return a.rhs[j]; });
+                const cplx rv = S.rv[h];
+                const cplx yi = a.m.shift ? csub(rv, cmul(a.m.k, sum)) : sum;
+                S.Ap[h][0] = yi;
+                v[4] += rv.x * rv.x + rv.y * rv.y;
+                const cplx t = cconj_mul(rv, yi);
+                v[0] += t.x; v[1] += t.y;
+                const cplx u = cconj_mul(yi, yi);
+                v[2] += u.x; v[3] += u.y;
+            }
+            res_contrib<5>(sy, 0, v, h * nwave + wave);
         }
-        res_contrib<5>(sy, 0, v);
         res_publish<5>(sy, 2);
         if (!res_collect<5>(sy, 2)) S.aborted = true;
         S.num = to_sgpr(make_double2(res_total(sy, 0), res_total(sy, 1)));
@@ -515,19 +606,24 @@ __global__ void __launch_bounds__(RED_THREADS, 4) gcr_resident_kernel(ResidentAr
         if (owner0 && !S.aborted) a.hist[0] = sqrt(S.rr) / sqrt(S.bnorm2);
     }
     if (!S.aborted)
-        while (res_cycle<MODE, NS, R, 0>(a, S, tb, sy, ring, i, act, owner0)) {}
+        while (res_cycle<MODE, NS, R, RPT, 0>(a, S, tb, sy, ring, owner0)) {}
     __syncthreads();
     if (S.aborted) {
         if (threadIdx.x == 0) {
             __hip_atomic_store(a.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.abort_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (act) a.x[i] = make_double2(__builtin_nan(""), __builtin_nan(""));
+#pragma unroll
+        for (int h = 0; h < RPT; h++)
+            if (S.act[h]) a.x[S.row[h]] = make_double2(__builtin_nan(""), __builtin_nan(""));
         if (owner0) { a.st->stop_at = S.it; a.st->base = 0; a.st->iter = S.it; a.st->npend = 0; a.st->bnorm2 = S.bnorm2; a.st->rr = __builtin_nan(""); a.st->tol2 = a.tol2; }
         return;
     }
     // the x updates still pending (gcr.hip flush_x_kernel): x += cx_0 P0 + sum_{1 <= m < npend} cx_m D_m
-    {
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        const int i = S.row[h];
+        const bool act = S.act[h];
         cplx xv = (act && S.x_live) ? a.x[i] : make_double2(0., 0.);
         const int np = S.npend;
 #pragma unroll
@@ -679,9 +775,18 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
     const int R = storage <= 5 && (restart == 5 || a.max_it < restart) ? 5 : 10;
     const int ns = sten_slots(M);
-#define RES_LAUNCH(NS, RR) hipLaunchKernelGGL((gcr_resident_kernel<3, NS, RR>), dim3(grid), dim3(RED_THREADS), 0, ctx().stream, a)
-    if (ns == 7) { if (R == 5) RES_LAUNCH(7, 5); else RES_LAUNCH(7, 10); }
-    else { if (R == 5) RES_LAUNCH(9, 5); else RES_LAUNCH(9, 10); }
+    static const int rpt_env = getenv("MGCR_RESIDENT_RPT") ? atoi(getenv("MGCR_RESIDENT_RPT")) : 0;
+    const int rpt = rpt_env == 1 || rpt_env == 2 || rpt_env == 4 ? rpt_env : RES_RPT_DEFAULT;
+#define RES_LAUNCH(NS, RR, RPT) hipLaunchKernelGGL((gcr_resident_kernel<3, NS, RR, RPT>), dim3(grid), dim3(RED_THREADS / RPT), 0, ctx().stream, a)
+#define RES_LAUNCH_R(NS, RR)                             \
+    do {                                                 \
+        if (rpt == 1) RES_LAUNCH(NS, RR, 1);             \
+        else if (rpt == 2) RES_LAUNCH(NS, RR, 2);        \
+        else RES_LAUNCH(NS, RR, 4);                      \
+    } while (0)
+    if (ns == 7) { if (R == 5) RES_LAUNCH_R(7, 5); else RES_LAUNCH_R(7, 10); }
+    else { if (R == 5) RES_LAUNCH_R(9, 5); else RES_LAUNCH_R(9, 10); }
+#undef RES_LAUNCH_R
 #undef RES_LAUNCH
     MGCR_HIP(hipGetLastError());
     g_resident_solves++;

@@ -53,55 +53,91 @@ __device__ __forceinline__ double to_sgpr(double v) {
 }
 __device__ __forceinline__ cplx to_sgpr(cplx v) { return make_double2(to_sgpr(v.x), to_sgpr(v.y)); }
 
+// Lane exchange l <-> l ^ OFF inside a wave64 WITHOUT the LDS permute unit (ds_bpermute_b32, what __shfl_xor compiles to:
+// ~100 cycles of latency per level of a reduction tree, and all 16 waves of a workgroup share the unit): DPP moves for
+// OFF = 1, 2, 4, 8 and gfx950's v_permlane16_swap / v_permlane32_swap for 16 and 32 (tools/xor_lane_lab.hip checks them).
+template <int OFF>
+__device__ __forceinline__ int xor_lane_b32(int v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8, "DPP reaches inside a row of 16 lanes");
+    if constexpr (OFF == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (OFF == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 4) {
+        const int t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);                    // row_half_mirror: l -> l ^ 7
+        return __builtin_amdgcn_mov_dpp(t, 0x1B, 0xf, 0xf, false);                            // quad_perm [3,2,1,0]: l -> l ^ 3
+    } else return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);                        // row_ror:8
+}
+// One level of a reduction tree over the lane pairs (l, l ^ OFF): every lane hands in the value `lo` it has for the scalar
+// the LOWER lane of its pair keeps and `hi` for the scalar the UPPER lane keeps; it gets back, for the scalar it keeps,
+// (lower lane's value) + (upper lane's value) — operands and order of wave_sum's tree.  lo == hi: a plain butterfly level.
+// OFF = 32 / 16: v_permlane{32,16}_swap exchanges the upper half (odd rows) of its first operand with the lower half (even
+// rows) of its second one, which IS "the lower lane keeps lo and receives the upper lane's lo, the upper lane keeps hi and
+// receives the lower lane's hi": two swaps and one add, no select.
+template <int OFF>
+__device__ __forceinline__ double tree_level(double lo, double hi) {
+    if constexpr (OFF == 32 || OFF == 16) {
+        const unsigned ll = (unsigned)__double2loint(lo), lh = (unsigned)__double2hiint(lo);
+        const unsigned hl = (unsigned)__double2loint(hi), hh = (unsigned)__double2hiint(hi);
+        if constexpr (OFF == 32) {
+            const auto a = __builtin_amdgcn_permlane32_swap(ll, hl, false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(lh, hh, false, false);
+            return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+        } else {
+            const auto a = __builtin_amdgcn_permlane16_swap(ll, hl, false, false);
+            const auto b = __builtin_amdgcn_permlane16_swap(lh, hh, false, false);
+            return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+        }
+    } else {
+        const bool upper = ((int)threadIdx.x & OFF) != 0;
+        const double keep = upper ? hi : lo, send = upper ? lo : hi;
+        const double recv = __hiloint2double(xor_lane_b32<OFF>(__double2hiint(send)), xor_lane_b32<OFF>(__double2loint(send)));
+        return upper ? (recv + keep) : (keep + recv);   // always (lower lane's value) + (upper lane's value)
+    }
+}
+
+// pairs (l, l + 32), then (l, l + 16) of those sums, ... : valid in lane 0 (every lane whose bits below the level are clear)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    v = tree_level<32>(v, v);
+    v = tree_level<16>(v, v);
+    v = tree_level<8>(v, v);
+    v = tree_level<4>(v, v);
+    v = tree_level<2>(v, v);
+    v = tree_level<1>(v, v);
     return v;  // valid in lane 0
 }
 
 // NV wave sums at once.  Each scalar is summed over the 64 lanes by the very tree wave_sum builds (pairs (l, l + 32),
-// then (l, l + 16) of those sums, ...: same operands, same order, same bits), but the NV trees share their shuffles:
+// then (l, l + 16) of those sums, ...: same operands, same order, same bits), but the NV trees share their exchanges:
 // at offset 32 the lower half-wave keeps the first half of the scalars and hands the second half to the upper
 // half-wave (which keeps those and hands over the first half), at offset 16 the halves split again, ... until every
-// lane carries one scalar; the remaining offsets are a plain butterfly.  NV = 16: 17 shuffles of a double instead
-// of 96 (they go through the LDS permute unit, which all 16 waves of a workgroup share: the folds and block
-// reductions of 10-20 scalars were a visible part of every solver kernel in the latency regime).
+// lane carries one scalar; the remaining offsets are a plain butterfly.  NV = 16: 17 exchanges of a double instead
+// of 96.
 // On return lane `l` holds in v[0] the total of scalar wave_multi_owner<NV>(l) (several lanes hold each scalar).
 template <int NV>
 struct WaveMulti {
     static constexpr int NVP = NV <= 1 ? 1 : NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
     static_assert(NV <= 64, "at most 64 scalars per multi-sum");
 };
+template <int C, int OFF, int NVP>
+__device__ __forceinline__ void wave_multi_level(double (&w)[NVP], int &base) {
+    // C scalars are still carried by every lane (C is a power of two)
+    if constexpr (C > 1) {
+        constexpr int h = C / 2;
+#pragma unroll
+        for (int j = 0; j < h; j++) w[j] = tree_level<OFF>(w[j], w[j + h]);
+        if (((int)threadIdx.x & OFF) != 0) base += h;
+    } else {
+        w[0] = tree_level<OFF>(w[0], w[0]);
+    }
+    if constexpr (OFF > 1) wave_multi_level<(C > 1 ? C / 2 : 1), OFF / 2, NVP>(w, base);
+}
 template <int NV>
 __device__ __forceinline__ int wave_multi_sum(double (&v)[NV], double &out) {
     constexpr int NVP = WaveMulti<NV>::NVP;
-    const int lane = threadIdx.x & 63;
     double w[NVP];
 #pragma unroll
     for (int j = 0; j < NVP; j++) w[j] = j < NV ? v[j] : 0.;
     int base = 0;
-    int c = NVP;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const bool upper = (lane & off) != 0;
-        if (c > 1) {
-            const int h = c / 2;
-#pragma unroll
-            for (int j = 0; j < NVP / 2; j++) {
-                if (j < h) {
-                    const double lo = w[j], hi = w[j + h];
-                    const double keep = upper ? hi : lo;
-                    const double recv = __shfl_xor(upper ? lo : hi, off, 64);
-                    w[j] = upper ? (recv + keep) : (keep + recv);   // always (lower lane's value) + (upper lane's value)
-                }
-            }
-            if (upper) base += h;
-            c = h;
-        } else {
-            const double recv = __shfl_xor(w[0], off, 64);
-            w[0] = upper ? (recv + w[0]) : (w[0] + recv);
-        }
-    }
+    wave_multi_level<NVP, 32, NVP>(w, base);
     out = w[0];
     return base;
 }
