@@ -42,7 +42,7 @@ constexpr int RES_NV = 24;          // scalars per exchange kind (<= 2 * 10 beta
 constexpr int RES_BLK = 256;        // workgroups at most (one per CU)
 constexpr int RES_CHUNK = 8;        // scalars folded at a time (register footprint of the shuffle tree)
 constexpr int RES_SPIN_LIMIT = 1 << 22;
-constexpr int RES_RPT_DEFAULT = 2;  // rows per thread (MGCR_RESIDENT_RPT = 1, 2, 4 for experiments)
+constexpr int RES_RPT_DEFAULT = 2;  // rows per thread: 64^3 GCR(10) 18.7 / 16.0 / 19.8 us per iteration with 1 / 2 / 4 (MGCR_RESIDENT_RPT in -DMGCR_RES_ALL_RPT builds)
 constexpr int RES_COPIES = 16;      // copies of every group sum (workgroup b reads copy b % 16)
 constexpr int RES_L1_BYTES = 3 * RES_NV * RES_BLK * 16;            // {value, generation} per (kind, scalar, workgroup)
 constexpr int RES_L2_BASE = RES_L1_BYTES;                          // then [copy][kind][scalar][group of 64 workgroups]
@@ -64,6 +64,8 @@ struct ResidentArgs {
     int max_it, storage;
     int from_zero, alpha_only_last;
     int nbr;             // a row gathers from at most this many workgroups to either side of its own
+    int spin_limit;      // polls before a workgroup gives up on the others (RES_SPIN_LIMIT; tests shorten it)
+    int test_stall;      // tests: logical workgroup test_stall - 1 leaves right after step 0 without a word (0: nobody)
     double *hist;
     int hist_cap;
     cplx *ring;          // (R + 1) slots of n rows: 0 = the residual a closing step starts the next cycle from, m = D_m, R = P0 after the first cycle
@@ -109,6 +111,7 @@ struct ResSync {
     unsigned gen;        // generation of the NEXT exchange
     int nblk, lb;
     unsigned *abort_dev;
+    int spin_limit;
     double *pw;          // [RES_NV][17] this workgroup's wave sums of the exchange being posted
     double *ws;          // [RES_NV][4]  sums over 64 workgroups each of the exchange being collected
     int *gave_up;        // LDS flag
@@ -169,7 +172,7 @@ __device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
                 v = __hiloint2double(w.y, w.x);
                 if ((unsigned)w.z == want) break;
                 spins++;
-                if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (spins > s.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     *s.gave_up = 1;
                     v = 0.;
                     break;
@@ -195,7 +198,7 @@ __device__ __forceinline__ bool res_collect(ResSync &s, int kind) {
                 v = __hiloint2double(w.y, w.x);
                 if ((unsigned)w.z == s.gen) break;
                 spins++;
-                if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (spins > s.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     *s.gave_up = 1;
                     v = 0.;
                     break;
@@ -222,7 +225,7 @@ __device__ __forceinline__ bool res_neighbour_wait(ResSync &s, int nbr) {
                 const v4i w = __builtin_amdgcn_raw_buffer_load_b128(s.slots, b * 16, 0, RES_SC1);
                 if ((int)((unsigned)w.z - s.gen) >= 0) break;
                 spins++;
-                if (spins > RES_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (spins > s.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(s.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     *s.gave_up = 1;
                     break;
                 }
@@ -556,6 +559,7 @@ __global__ void __launch_bounds__(RED_THREADS / RPT, RED_THREADS / RPT / 256) gc
     sy.nblk = a.nlogical;
     sy.lb = lb;
     sy.abort_dev = a.abort_dev;
+    sy.spin_limit = a.spin_limit;
     sy.pw = lds_pw;
     sy.ws = lds_ws;
     sy.gave_up = &gave_up;
@@ -605,6 +609,7 @@ __global__ void __launch_bounds__(RED_THREADS / RPT, RED_THREADS / RPT / 256) gc
         S.bnorm2 = S.rr;
         if (owner0 && !S.aborted) a.hist[0] = sqrt(S.rr) / sqrt(S.bnorm2);
     }
+    if (a.test_stall && lb == a.test_stall - 1) return;   // (tests) the others must notice, give up and say so
     if (!S.aborted)
         while (res_cycle<MODE, NS, R, RPT, 0>(a, S, tb, sy, ring, owner0)) {}
     __syncthreads();
@@ -753,6 +758,8 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     a.storage = storage;
     a.from_zero = from_zero ? 1 : 0;
     a.alpha_only_last = alpha_only_last ? 1 : 0;
+    a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
+    a.test_stall = getenv("MGCR_TEST_RESIDENT_STALL") ? atoi(getenv("MGCR_TEST_RESIDENT_STALL")) : 0;
     {
         int64_t reach = 0;
         for (int c = 0; c < M.sten_ns; c++) reach = std::max<int64_t>(reach, std::llabs((long long)M.sten_off[c]));
@@ -778,12 +785,16 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     static const int rpt_env = getenv("MGCR_RESIDENT_RPT") ? atoi(getenv("MGCR_RESIDENT_RPT")) : 0;
     const int rpt = rpt_env == 1 || rpt_env == 2 || rpt_env == 4 ? rpt_env : RES_RPT_DEFAULT;
 #define RES_LAUNCH(NS, RR, RPT) hipLaunchKernelGGL((gcr_resident_kernel<3, NS, RR, RPT>), dim3(grid), dim3(RED_THREADS / RPT), 0, ctx().stream, a)
+#ifdef MGCR_RES_ALL_RPT   /* experiments: one and four rows per thread as well (build with EXTRA=-DMGCR_RES_ALL_RPT) */
 #define RES_LAUNCH_R(NS, RR)                             \
     do {                                                 \
         if (rpt == 1) RES_LAUNCH(NS, RR, 1);             \
         else if (rpt == 2) RES_LAUNCH(NS, RR, 2);        \
         else RES_LAUNCH(NS, RR, 4);                      \
     } while (0)
+#else
+#define RES_LAUNCH_R(NS, RR) do { (void)rpt; RES_LAUNCH(NS, RR, 2); } while (0)
+#endif
     if (ns == 7) { if (R == 5) RES_LAUNCH_R(7, 5); else RES_LAUNCH_R(7, 10); }
     else { if (R == 5) RES_LAUNCH_R(9, 5); else RES_LAUNCH_R(9, 10); }
 #undef RES_LAUNCH_R

@@ -113,3 +113,41 @@ def test_resident_is_faster_per_iteration():
             mg.set_option("resident_solver", prev)
     print("64^3 GCR(10): resident %.1f us, multi-kernel %.1f us per iteration" % (t[1] * 1e6, t[0] * 1e6))
     assert t[1] * 1.2 < t[0]
+
+
+def test_resident_gives_up_instead_of_hanging(tmp_path):
+    """A workgroup that never shows up (here: told to leave after step 0) must not leave the others spinning: they give up
+    after a bounded number of polls, x comes back as NaN and the next host synchronisation reports the failure.  Runs in a
+    child process: the switches are read from the environment once."""
+    import subprocess
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import mgpreconditionedgcr_amd as mg
+from mgpreconditionedgcr_amd import problems
+n = 32
+N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+A = mg.Sparse(N, ncol, rowptr, col, val)
+g = mg.GCR(A, mg.GCR_Param(0, 10, 30, 1e-30, False))
+b = mg.Field((n, n, n)).fill_rhs(0)
+x = mg.Field((n, n, n))
+try:
+    g.solve(b, x)
+    print("NO-ERROR")
+except mg.MgcrError as e:
+    print("ERROR:", e)
+try:
+    xs = x.to_numpy()
+except mg.MgcrError as e:   # the failure is reported once; the data is still readable afterwards
+    xs = x.to_numpy()
+# every workgroup that was there poisoned its rows (the absent one, 1024 rows of 32768, could not)
+print("NAN" if np.isnan(xs).sum() >= xs.size - 1024 else "FINITE %d" % np.isnan(xs).sum())
+'''
+    import os
+    env = dict(os.environ, MGCR_TEST_RESIDENT_STALL="3", MGCR_TEST_RESIDENT_SPIN_LIMIT="20000")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120,
+                         cwd=os.path.join(os.path.dirname(__file__), ".."))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ERROR:" in out.stdout and "co-resident" in out.stdout, out.stdout
+    assert "NAN" in out.stdout, out.stdout
