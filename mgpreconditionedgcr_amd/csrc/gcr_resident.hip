@@ -291,6 +291,8 @@ struct ResState {
     cplx Ap[RPT][R];     // images of the cycle's directions, this thread's rows
     cplx rv[RPT];
     int row[RPT];        // the rows (1024 / RPT apart inside the workgroup's 1024)
+    int32_t t0[RPT];     // MODE 1, 2: the row's pattern (id * W), fixed for the solve
+    PatLds pl;           // MODE 1: the pattern table in LDS
     bool act[RPT];
     cplx num, den;       // <r,Ap_cur>, <Ap_cur,Ap_cur>
     double bnorm2, rr;
@@ -367,9 +369,16 @@ __device__ __forceinline__ bool res_step(const ResidentArgs &a, ResState<R, RPT>
     // Ar = A r (or r - k A r) from the neighbours' rows, <Ar, Ap_j> for the stored directions
     cplx ar[RPT];
     {
-        static_assert(MODE == 3, "stencil view");
         cplx sum[RPT];
-        res_sten_rows<NS, RPT>(a.m, S.row, S.act, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); }, sum);
+        if constexpr (MODE == 3) {
+            res_sten_rows<NS, RPT>(a.m, S.row, S.act, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); }, sum);
+        } else {   // ELL slab / row-pattern dictionaries (spmv_dev.h row_product): NS is the compile-time row width (0: m.W)
+#pragma unroll
+            for (int h = 0; h < RPT; h++) {
+                sum[h] = make_double2(0., 0.);
+                if (S.act[h]) sum[h] = fused_row_product<MODE, NS>(a.m, S.row[h], S.t0[h], S.pl, [&](int32_t j) -> cplx { return ld_coh(ring, j, nxt * vbytes); });
+            }
+        }
 #pragma unroll
         for (int h = 0; h < RPT; h++) {
             ar[h] = make_double2(0., 0.);
@@ -539,6 +548,7 @@ __global__ void __launch_bounds__(RED_THREADS / RPT, RED_THREADS / RPT / 256) gc
     __shared__ double lds_pw[RES_NV * 17], lds_ws[RES_NV * 4];
     __shared__ int gave_up;
     __shared__ ResTables<R> tb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     constexpr int T = RED_THREADS / RPT;
     const int lb = logical_workgroup(a.rm, (int)blockIdx.x, (int)gridDim.x);
     const bool owner0 = lb == 0 && threadIdx.x == 0;
@@ -573,7 +583,11 @@ __global__ void __launch_bounds__(RED_THREADS / RPT, RED_THREADS / RPT / 256) gc
 #pragma unroll
         for (int j = 0; j < R; j++) S.Ap[h][j] = make_double2(0., 0.);
         S.rv[h] = S.act[h] ? a.rhs[S.row[h]] : make_double2(0., 0.);
+        S.t0[h] = 0;
+        if ((MODE == 1 || MODE == 2) && S.act[h]) S.t0[h] = (int32_t)a.m.pid[S.row[h]] * (NS ? NS : a.m.W);
     }
+    S.pl = PatLds{nullptr, nullptr, nullptr};
+    if (MODE == 1) S.pl = stage_patterns(a.m, step_smem);
     S.x_live = !a.from_zero;
     S.p0_rhs = true;
     S.it = 0; S.npend = 0; S.stop_at = INT_MAX; S.iter = 0; S.rr = 0.; S.bnorm2 = 0.;
@@ -588,8 +602,7 @@ __global__ void __launch_bounds__(RED_THREADS / RPT, RED_THREADS / RPT / 256) gc
         for (int h = 0; h < RPT; h++) {
             double v[5] = {0., 0., 0., 0., 0.};
             if (S.act[h]) {
-                const PatLds pl{nullptr, nullptr, nullptr};
-                const cplx sum = fused_row_product<MODE, NS>(a.m, S.row[h], 0, pl, [&](int32_t j) -> cplx { return a.rhs[j]; });
+                const cplx sum = fused_row_product<MODE, NS>(a.m, S.row[h], S.t0[h], S.pl, [&](int32_t j) -> cplx { return a.rhs[j]; });
                 const cplx rv = S.rv[h];
                 const cplx yi = a.m.shift ? csub(rv, cmul(a.m.k, sum)) : sum;
                 S.Ap[h][0] = yi;
@@ -726,8 +739,11 @@ bool gcr_resident_eligible(const Op *A, const mgcr_gcr_param &p, int storage, in
     const Op *b0 = A->kind == OP_DIRAC ? A->base : A;
     if (!b0 || b0->kind != OP_CSR || b0->dist || A->comm) return false;
     const CsrDev &M = b0->csr;
-    if (!csr_fusable(M, nullptr) || M.nrow != n || !csr_stencil_active(M) || M.sten_rare) return false;
-    if (sten_slots(M) != 7 && sten_slots(M) != 9) return false;
+    // one thread walks a whole row, gather after gather: short rows only.  (Long rows with few of them — the reference's 3072 x 39
+    // sample, stored with 8 lanes per row — were tried through a one-thread replay of spmv.hip's lane sums: 32 us per iteration
+    // against 20 for the multi-kernel path, whose SpMV spreads a row over 8 lanes.)
+    if (!csr_fusable(M, nullptr) || M.nrow != n || M.W > 16) return false;
+    if (csr_stencil_active(M) && (M.sten_rare || (sten_slots(M) != 7 && sten_slots(M) != 9))) return false;
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;
     const bool never_closes = max_it < restart;
     if (storage > 10) return false;
@@ -760,10 +776,11 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     a.alpha_only_last = alpha_only_last ? 1 : 0;
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     a.test_stall = getenv("MGCR_TEST_RESIDENT_STALL") ? atoi(getenv("MGCR_TEST_RESIDENT_STALL")) : 0;
-    {
+    {   // how far a row's gathers go: exactly for the stencil view, CsrDev::reach otherwise (0 = unknown: every workgroup)
         int64_t reach = 0;
-        for (int c = 0; c < M.sten_ns; c++) reach = std::max<int64_t>(reach, std::llabs((long long)M.sten_off[c]));
-        a.nbr = (int)((reach + RED_THREADS - 1) / RED_THREADS);
+        if (csr_stencil_active(M)) for (int c = 0; c < M.sten_ns; c++) reach = std::max<int64_t>(reach, std::llabs((long long)M.sten_off[c]));
+        else reach = M.reach > 0 ? M.reach : n;
+        a.nbr = (int)std::min<int64_t>((reach + RED_THREADS - 1) / RED_THREADS, RES_BLK);
     }
     a.hist = hist; a.hist_cap = hist_cap;
     a.ring = ring;
@@ -781,22 +798,27 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     sh.gen += need;
     const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
     const int R = storage <= 5 && (restart == 5 || a.max_it < restart) ? 5 : 10;
-    const int ns = sten_slots(M);
     static const int rpt_env = getenv("MGCR_RESIDENT_RPT") ? atoi(getenv("MGCR_RESIDENT_RPT")) : 0;
     const int rpt = rpt_env == 1 || rpt_env == 2 || rpt_env == 4 ? rpt_env : RES_RPT_DEFAULT;
-#define RES_LAUNCH(NS, RR, RPT) hipLaunchKernelGGL((gcr_resident_kernel<3, NS, RR, RPT>), dim3(grid), dim3(RED_THREADS / RPT), 0, ctx().stream, a)
+    const size_t lds_bytes = csr_stencil_active(M) ? 0 : row_mat_lds_bytes(M);
+#define RES_LAUNCH(MODE, NS, RR, RPT) \
+    hipLaunchKernelGGL((gcr_resident_kernel<MODE, NS, RR, RPT>), dim3(grid), dim3(RED_THREADS / RPT), lds_bytes, ctx().stream, a)
 #ifdef MGCR_RES_ALL_RPT   /* experiments: one and four rows per thread as well (build with EXTRA=-DMGCR_RES_ALL_RPT) */
-#define RES_LAUNCH_R(NS, RR)                             \
-    do {                                                 \
-        if (rpt == 1) RES_LAUNCH(NS, RR, 1);             \
-        else if (rpt == 2) RES_LAUNCH(NS, RR, 2);        \
-        else RES_LAUNCH(NS, RR, 4);                      \
+#define RES_LAUNCH_R(MODE, NS, RR)                             \
+    do {                                                       \
+        if (rpt == 1) RES_LAUNCH(MODE, NS, RR, 1);             \
+        else if (rpt == 2) RES_LAUNCH(MODE, NS, RR, 2);        \
+        else RES_LAUNCH(MODE, NS, RR, 4);                      \
     } while (0)
 #else
-#define RES_LAUNCH_R(NS, RR) do { (void)rpt; RES_LAUNCH(NS, RR, 2); } while (0)
+#define RES_LAUNCH_R(MODE, NS, RR) do { (void)rpt; RES_LAUNCH(MODE, NS, RR, 2); } while (0)
 #endif
-    if (ns == 7) { if (R == 5) RES_LAUNCH_R(7, 5); else RES_LAUNCH_R(7, 10); }
-    else { if (R == 5) RES_LAUNCH_R(9, 5); else RES_LAUNCH_R(9, 10); }
+#define RES_LAUNCH_M(MODE, NS) do { if (R == 5) RES_LAUNCH_R(MODE, NS, 5); else RES_LAUNCH_R(MODE, NS, 10); } while (0)
+    if (csr_stencil_active(M)) { if (sten_slots(M) == 7) RES_LAUNCH_M(3, 7); else RES_LAUNCH_M(3, 9); }
+    else if (M.pat_mode == 1) RES_LAUNCH_M(1, 0);
+    else if (M.pat_mode == 2) RES_LAUNCH_M(2, 0);
+    else RES_LAUNCH_M(0, 0);
+#undef RES_LAUNCH_M
 #undef RES_LAUNCH_R
 #undef RES_LAUNCH
     MGCR_HIP(hipGetLastError());

@@ -18,14 +18,10 @@
 // Scope: Sparse / DiracOp operators (ELL slab + CSR tail), restart or truncation mode with at most
 // SMALL_MAX_DIRS stored directions, no preconditioner, single GPU.
 //
-// Tried and dropped: the same one-launch solve spread over up to 256 workgroups (one row per thread,
-// hipLaunchCooperativeKernel, grid barriers between the phases) for systems of 1k .. 256k rows.  Correct
-// (it passed the whole parity suite), but slower than the multi-kernel loop it was meant to beat: 64 us per
-// iteration on the 3072-row sample (multi-kernel + hipGraph: 28 us) and 200 us on a 262144-row coarsest
-// level (45 us) — with one workgroup per CU every thread walks its row's gather chain and the stored
-// directions with 16 waves per CU to hide the latency, where the multi-kernel path runs kernels shaped for
-// throughput.  The stock cooperative_groups grid.sync() was not the problem (a device-memory barrier made no
-// difference).
+// Larger systems (up to one row per thread of the CHIP) have their own one-launch solver, gcr_resident.hip.  Round 1's
+// attempt at it (hipLaunchCooperativeKernel, grid barriers between the phases, vectors in memory: 200 us per iteration
+// on a 262 144-row coarsest level against 45 us for the multi-kernel loop) failed on two counts that file's header
+// explains: fenced barriers, and Krylov vectors that were re-read from memory every phase instead of living in registers.
 #include <climits>
 
 #include "internal.h"

@@ -151,3 +151,68 @@ print("NAN" if np.isnan(xs).sum() >= xs.size - 1024 else "FINITE %d" % np.isnan(
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ERROR:" in out.stdout and "co-resident" in out.stdout, out.stdout
     assert "NAN" in out.stdout, out.stdout
+
+
+def _diag_dominant(N, rowptr, col, val, factor=2.0):
+    """add to every diagonal entry enough to dominate its row (GCR then converges whatever the off-diagonal values)"""
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    rowsum = np.bincount(rows, weights=np.abs(val), minlength=N)
+    val = val.copy()
+    d = col == rows
+    val[d] = factor * rowsum[rows[d]] + 1.0
+    return val
+
+
+@pytest.mark.parametrize("case", ["ell-small", "ell-random-columns", "dictionary-with-values", "dictionary-columns-only"])
+@pytest.mark.parametrize("restart,max_it", [(10, 37), (5, 12), (10, 4)])
+def test_resident_general_storage_bit_for_bit(case, restart, max_it):
+    """every storage format of a Sparse the fused kernels read — plain ELL slab (matrices below 2^15 rows, or without
+    repeating rows), row-pattern dictionary with values, dictionary for the columns + value slab — through the resident
+    solver: the bits of the multi-kernel path"""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import problems
+    rng = np.random.default_rng(5)
+    opts = {}
+    if case == "ell-small":
+        n = 20   # 8000 rows: below the dictionary's 2^15
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        val = val + 0.0j
+        val[col == np.repeat(np.arange(N), np.diff(rowptr))] += 0.3 - 0.1j
+        dims, want = (n, n, n), 0
+    elif case == "ell-random-columns":
+        N = 40000
+        col = np.sort(rng.integers(0, N, size=(N, 6)), axis=1)
+        col[:, 0] = np.arange(N)   # a diagonal entry per row (first in storage order is fine: CSR order is what it is)
+        col = np.sort(col, axis=1).ravel()
+        rowptr = np.arange(N + 1, dtype=np.int64) * 6
+        val = rng.standard_normal(col.size) + 1j * rng.standard_normal(col.size)
+        # duplicates of the diagonal column may occur: make every one of them big
+        val = _diag_dominant(N, rowptr, col, val)
+        ncol, dims, want = N, (N,), 0
+    else:
+        n = 34   # 39304 rows
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+        dims = (n, n, n)
+        if case == "dictionary-with-values":
+            val = val * (0.75 - 0.5j)
+            val[col == np.repeat(np.arange(N), np.diff(rowptr))] += 0.2
+            opts, want = {"stencil_storage": 0}, 1
+        else:
+            val = rng.standard_normal(val.size) + 1j * rng.standard_normal(val.size)
+            val = _diag_dominant(N, rowptr, col, val)
+            want = 2
+    prev = {k: mg.set_option(k, v) for k, v in opts.items()}
+    try:
+        A = mg.Sparse(N, ncol, rowptr, col, val)
+    finally:
+        for k, v in prev.items():
+            mg.set_option(k, v)
+    assert A.storage_format()[0] == want
+    rhs = _rhs(N, 17)
+    p = mg.GCR_Param(0, restart, max_it, 1e-11, False)
+    xr, hr, itr, cr = _solve(A, dims, p, rhs, True)
+    xc, hc, itc, cc = _solve(A, dims, p, rhs, False)
+    assert itr == itc and cr == cc and itr >= min(max_it, 3)
+    assert np.array_equal(hr, hc)
+    assert np.array_equal(xr, xc)
+    assert hr[-1] < hr[0]
