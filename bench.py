@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "bcsr", "sample"]
+EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "bcsr", "sample", "latency64"]
 MG_PARITY_NOTE = ("unpinned: the reference's MG::operator() returns uninitialised memory (src/MG.h:124-129,405-430), so no reference "
                   "output exists; the cycle is checked against the oracle's corrected cycle (tests/test_gpu_mg.py)")
 # transports a multi-GPU run falls back through (environment of the worker processes)
@@ -832,6 +832,39 @@ def wl_sample(args):
             "note": "latency regime: 3 dependent kernels per iteration on 3072 rows"}
 
 
+def wl_latency64(args):
+    """The latency regime: Poisson 64^3 (262 144 rows = the coarsest level of configs[2]'s hierarchy), GCR restart 10, 400 iterations
+    — the one-launch resident solver (csrc/gcr_resident.hip) beside the multi-kernel path on the same operator; both must give the
+    same residual to the last bit."""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, Sparse, problems
+    mg.init(0)
+    n, restart, its = 64, 10, 400
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    dims = (n, n, n)
+    rhs = Field(dims).fill_rhs(0)
+    out = {}
+    for resident in (1, 0):
+        prev = mg.set_option("resident_solver", resident)
+        try:
+            g = GCR(A, GCR_Param(0, restart, its, 1e-300, False))
+            x = Field(dims)
+            before = mg.stat("resident_solves")
+            timed_solve(mg, g, rhs, x)
+            took = mg.stat("resident_solves") - before
+
+            sv = stats(repeat_timed(lambda: timed_solve(mg, g, rhs, x), min_total=0.1, min_reps=5))
+            out["resident" if resident else "multi_kernel"] = {
+                "us_per_iteration": sv["median"] * 1e6 / g.last_iterations, "it_per_s": g.last_iterations / sv["median"], "timing_seconds": sv,
+                "iterations": g.last_iterations, "final_rel_residual": float(g.last_history[-1]), "one_launch_path_taken": bool(took)}
+        finally:
+            mg.set_option("resident_solver", prev)
+    return {"workload": "latency regime: 3D 7-point Poisson 64^3, GCR restart 10, 400 iterations, fp64", **out,
+            "same_residual_bits": out["resident"]["final_rel_residual"] == out["multi_kernel"]["final_rel_residual"],
+            "speedup": out["multi_kernel"]["us_per_iteration"] / out["resident"]["us_per_iteration"]}
+
+
 def wl_poisson128_tol(args):
     """configs[1] run to tolerance (not in the default line: it takes a second or so): GCR restart 5 to 1e-13 on Poisson
     128^3, and the same solve with configs[2]'s 3-level MG as flexible right preconditioner."""
@@ -1013,7 +1046,7 @@ DIST_WORKLOADS = {"dist_mg": wl_dist_mg, "dist_bcsr": wl_dist_bcsr}
 DIST_EXTRA_TIMEOUT_S = 240
 
 WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
-             "sample": wl_sample}
+             "sample": wl_sample, "latency64": wl_latency64}
 
 
 def run_extras(argv_base, budget_s=240.0):
