@@ -257,13 +257,37 @@ __global__ void __launch_bounds__(RED_THREADS) xr_update_kernel(DevState *__rest
     if (threadIdx.x == 0) partsR[blockIdx.x] = tot;
 }
 
-// applies the x updates still pending when the solve ends (never skipped)
+// applies the x updates still pending when the solve ends (never skipped).  The usual counts (a smoother's 2-3 sweeps, up to a
+// restart-5 cycle) get their loads issued together; same sums, same order.
+template <int NP>
+__device__ __forceinline__ void flush_x_rows(const cplx *__restrict__ alphas, const DirPtrs &d0, cplx *__restrict__ x, int64_t n, int assign) {
+    cplx al[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) al[j] = to_sgpr(alphas[j]);
+    GRID_STRIDE(i, n) {
+        cplx pv[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) pv[j] = d0.ps[j][i];
+        cplx xv = assign ? make_double2(0., 0.) : x[i];   // assign: x0 = 0 was never materialised (gcr_run: assign_x)
+#pragma unroll
+        for (int j = 0; j < NP; j++) xv = cadd(xv, cmul(al[j], pv[j]));
+        x[i] = xv;
+    }
+}
 __global__ void __launch_bounds__(RED_THREADS) flush_x_kernel(DevState *__restrict__ st, const cplx *__restrict__ alphas, DirPtrs d0,
                                                               cplx *__restrict__ x, int64_t n, int assign) {
     const int np = st->npend;
     if (np <= 0) return;   // (also when an outer solver's stop predicate turned this whole solve into a no-op)
+    switch (np) {
+        case 1: flush_x_rows<1>(alphas, d0, x, n, assign); return;
+        case 2: flush_x_rows<2>(alphas, d0, x, n, assign); return;
+        case 3: flush_x_rows<3>(alphas, d0, x, n, assign); return;
+        case 4: flush_x_rows<4>(alphas, d0, x, n, assign); return;
+        case 5: flush_x_rows<5>(alphas, d0, x, n, assign); return;
+        default: break;
+    }
     GRID_STRIDE(i, n) {
-        cplx xv = assign ? make_double2(0., 0.) : x[i];   // assign: x0 = 0 was never materialised (gcr_run: assign_x)
+        cplx xv = assign ? make_double2(0., 0.) : x[i];
         for (int j = 0; j < np && j < LND; j++) xv = cadd(xv, cmul(alphas[j], d0.ps[j][i]));
         x[i] = xv;
     }

@@ -112,7 +112,18 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
     if (pend.st) {
         const int np = pend.st->npend;
         cplx xv = make_double2(0., 0.);
-        for (int j = 0; j < np && j < LND; j++) xv = cadd(xv, cmul(pend.coef[j], pend.v[j][i]));
+        if (np == 2) {          // a smoother's 2 sweeps (3 vectors at most): loads issued together; same sum, same order
+            const cplx v0 = pend.v[0][i], v1 = pend.v[1][i];
+            xv = cadd(xv, cmul(pend.coef[0], v0));
+            xv = cadd(xv, cmul(pend.coef[1], v1));
+        } else if (np == 3) {
+            const cplx v0 = pend.v[0][i], v1 = pend.v[1][i], v2 = pend.v[2][i];
+            xv = cadd(xv, cmul(pend.coef[0], v0));
+            xv = cadd(xv, cmul(pend.coef[1], v1));
+            xv = cadd(xv, cmul(pend.coef[2], v2));
+        } else {
+            for (int j = 0; j < np && j < LND; j++) xv = cadd(xv, cmul(pend.coef[j], pend.v[j][i]));
+        }
         x[i] = cadd(xv, cmul(damp, s));
         return;
     }
