@@ -349,20 +349,32 @@ static int pat_try(CsrDev &A, bool *ok) {
 // (tools/spmv_lab.hip, Poisson): 13.1 against 16.8 us at 128^3 back to back, 134 against 168 us at 256^3.
 // Entries whose stored value is exactly 0 (the slab's padding) are treated as absent: they only ever add +-0.
 // ------------------------------------------------------------------------------------------------
+// (each wave walks several waves' worth of rows and keeps the per-slot row counts in lane 0's registers: one atomic per slot and
+// WAVE OF THE GRID at the end.  One atomic per slot and 64 rows — 2.3 M of them on 16 addresses at 256^3 — took 25 ms.)
 __global__ void __launch_bounds__(256) sten_planes_kernel(int64_t nrow, int64_t nwaves, int32_t ns, int32_t stride,
                                                           const uint16_t *__restrict__ pid, const uint16_t *__restrict__ pmask,
                                                           uint64_t *__restrict__ planes, unsigned long long *__restrict__ counts) {
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (wave >= nwaves) return;
-    const int64_t row = wave * 64 + lane;
-    const uint32_t m = row < nrow ? pmask[pid[row]] : 0u;
-    for (int32_t c = 0; c < stride; c++) {
-        const unsigned long long b = __ballot(c < ns && (m >> c & 1u));
-        if (lane == 0) {
-            planes[wave * stride + c] = b;
-            if (b) atomicAdd(counts + c, (unsigned long long)__popcll(b));
+    const int64_t gw = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, tw = (int64_t)gridDim.x * 4;
+    unsigned long long cnt[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) cnt[c] = 0ull;
+    for (int64_t wave = gw; wave < nwaves; wave += tw) {
+        const int64_t row = wave * 64 + lane;
+        const uint32_t m = row < nrow ? pmask[pid[row]] : 0u;
+#pragma unroll
+        for (int32_t c = 0; c < 16; c++) {
+            if (c < stride) {
+                const unsigned long long b = __ballot(c < ns && (m >> c & 1u));
+                if (lane == 0) planes[wave * stride + c] = b;
+                cnt[c] += (unsigned long long)__popcll(b);
+            }
         }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+            if (cnt[c]) atomicAdd(counts + c, cnt[c]);
     }
 }
 
@@ -428,7 +440,8 @@ static int sten_try(CsrDev &A) {
                  hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * 16, c.stream) == hipSuccess &&
                  hipMemsetAsync(planes + (size_t)nwaves * stride, 0, sizeof(uint64_t) * stride, c.stream) == hipSuccess;
         if (g && nwaves) {
-            hipLaunchKernelGGL(sten_planes_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, c.stream, A.nrow, nwaves, nslots,
+            const int64_t pg = (nwaves + 3) / 4;   // 4 waves per workgroup; at most 2048 workgroups, each wave then walks several
+            hipLaunchKernelGGL(sten_planes_kernel, dim3((unsigned)(pg < 2048 ? pg : 2048)), dim3(256), 0, c.stream, A.nrow, nwaves, nslots,
                                stride, (const uint16_t *)A.pat_id, (const uint16_t *)d_pmask, planes, d_counts);
             g = hipGetLastError() == hipSuccess;
         }
