@@ -1,10 +1,11 @@
-// Resident GCR: a whole lean restarted solve (src/GCR.h:158-302) in ONE launch, for systems of at most one row per
-// thread of the chip (<= 256 workgroups x 1024 threads = 262 144 rows on MI355X) — the latency regime, where every
-// kernel of gcr.hip's path costs its launch (~4.5 us in a dependent chain) plus a pass over 4 MB vectors that live in
-// the Infinity Cache: 49 iterations of the coarsest solve of a 256^3 V-cycle took 49 x (13.6 + 12.2) us.
+// Resident GCR: a whole lean restarted solve (src/GCR.h:158-302) in ONE launch, for systems of at most 1024 rows per
+// compute unit (<= 256 workgroups = 262 144 rows on MI355X) — the latency regime, where every kernel of gcr.hip's path
+// costs its launch (~4.5 us in a dependent chain) plus a pass over 4 MB vectors that live in the Infinity Cache: the 49
+// iterations of the coarsest solve of a 256^3 V-cycle took 49 x (13.6 + 12.2) us; here 49 x 14.7.
 //
-// What makes one launch possible (tools/barrier_lab.hip, tools/coherent_lab.hip, profiles/r02_barrier_lab.txt):
-//   * a device-wide rendezvous costs 1.7 us when every workgroup only STORES a flag of its own and POLLS the others
+// What makes one launch possible (tools/barrier_lab.hip, tools/coherent_lab.hip, profiles/r02_barrier_lab.txt,
+// r02_coherent_lab.txt):
+//   * a device-wide rendezvous costs 1.7 us when every workgroup only STORES a flag of its own and POLLS the others'
 //     with relaxed atomics — the 21-57 us of a counter barrier with release / acquire fences are the fences (256
 //     workgroups each writing back and invalidating their XCD's L2) and the contended counter;
 //   * without fences the data that crosses workgroups has to be coherent by itself: it is written with
@@ -12,20 +13,28 @@
 //     non-coherent caches), the agent-scope cache policy of a relaxed atomic, which the compiler schedules like any
 //     other load (no inline assembly, no hand-placed waits).  tools/coherent_lab.hip checks exactly this on the part.
 //
-// Data layout: thread t of logical workgroup b owns row i = 1024 b + t for the whole solve.  Its entries of the
-// stored images Ap_0..Ap_{R-1}, of r, of P0 and of x are REGISTERS (4 VGPRs each); the only vector that crosses
-// threads is the residual a step hands to the operator apply (the residual ring D_1..D_{R-1} of gcr.hip's lean
-// cycle, in memory anyway: the step that closes a cycle reads its own rows back).  Reductions: every workgroup
-// stores its partial sums as 16-byte {value, generation} slots and folds ALL workgroups' slots itself, in the order
-// and with the tree of reduce.h's fold_partials — the scalars, hence every iterate, have the bits of gcr.hip's
-// kernels (tests/test_gpu_resident.py compares the two paths bit for bit).  Three such exchanges per iteration
-// (|r|^2 + the residual hand-over; the beta numerators; <r,Ap>, <Ap,Ap>), each one store and one polled load deep.
+// Data layout: a workgroup of 512 threads owns 1024 consecutive rows, thread t rows t and t + 512 (RPT = 2: with one
+// row per thread every wave repeats the scalar work and ten images do not fit 128 registers; with four, one wave per
+// SIMD hides nothing).  Its entries of the stored images Ap_0..Ap_{R-1} and of r are REGISTERS (4 VGPRs each and row);
+// x and P0 are touched once per restart cycle and stay in memory (own rows).  The only vector that crosses threads is
+// the residual a step hands to the operator apply (the residual ring D_1..D_{R-1} of gcr.hip's lean cycle, needed in
+// memory anyway: the step that closes a cycle reads its own rows back); 7-point stencils take the near neighbours of it
+// from an LDS window written from registers.
+// Reductions: every workgroup stores its partial sums as 16-byte {value, generation} slots.  They are folded in two
+// hops — (64 workgroups x scalar) tasks dealt over waves of the first workgroups, whose group sums every workgroup then
+// polls from one of 16 replicas — because 256 workgroups polling the same 4 KB made one memory channel serve it all
+// (5-6 us per exchange).  Order and tree are those of reduce.h's fold_partials: the scalars, hence every iterate, have
+// the bits of gcr.hip's kernels (tests/test_gpu_resident.py compares the two paths bit for bit).  Per iteration: two
+// such exchanges (the beta numerators with |r|^2; <r,Ap>, <Ap,Ap>) and one hand-over of the residual that only waits
+// for the neighbouring workgroups' slots.
 //
-// Scope: single GPU, a Sparse / DiracOp in the stencil view (spmv_dev.h MODE 3), lean restart cycles of 5 or 10
-// (or solves that end before their first cycle closes), no preconditioner hooks, x0 = 0 or ignored.  Everything else
-// takes gcr.hip's path.  A workgroup that waits longer than ~4 s for another one (the launch was not co-resident:
-// foreign work on the device) raises the abort flag, every workgroup leaves, x is poisoned with NaN and the next
-// host synchronisation reports the failure — no wave spins forever.
+// Scope: single GPU (no live communicator: several processes could share the device), a Sparse / DiracOp stored one
+// thread per row with rows of at most 16 entries (stencil view, row-pattern dictionaries, ELL slab), lean restart
+// cycles of 5 or 10 (or solves that end before their first cycle closes), no preconditioner hooks, x0 = 0 or
+// ignored, no piecewise hand-over of x or r to a V-cycle.  Everything else takes gcr.hip's path.  A workgroup that
+// polls more than RES_SPIN_LIMIT times for another one (the launch was not co-resident: foreign work on the device)
+// raises the abort flag, every workgroup leaves, x is poisoned with NaN and the next host synchronisation reports
+// the failure — no wave spins forever (test_resident_gives_up_instead_of_hanging).
 #include <algorithm>
 #include <climits>
 #include <cmath>
