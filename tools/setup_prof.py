@@ -1,3 +1,5 @@
+"""Where the set-up of configs[2] goes (Sparse creation, MG hierarchy): wall times; under `rocprofv3 --kernel-trace --hip-trace`
+the kernels and HIP calls behind them (found sten_planes_kernel's 2.3 M serialised atomics: 25 ms per 256^3 operator)."""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 import mgpreconditionedgcr_amd as mg
