@@ -33,6 +33,18 @@ __global__ void __launch_bounds__(256) k_copy(int64_t n, const cplx *__restrict_
     if (i < n) y[i] = x[i];
 }
 
+// RPT elements per thread, a workgroup's elements contiguous, all loads issued before the first store
+template <int RPT>
+__global__ void __launch_bounds__(256) k_copy_n(int64_t n, const cplx *__restrict__ x, cplx *__restrict__ y) {
+    const int64_t base = (int64_t)blockIdx.x * 256 * RPT + threadIdx.x;
+    cplx v[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; h++) v[h] = base + h * 256 < n ? x[base + h * 256] : make_double2(0., 0.);
+#pragma unroll
+    for (int h = 0; h < RPT; h++)
+        if (base + h * 256 < n) y[base + h * 256] = v[h];
+}
+
 // ---- C: the product's pat_spmv_lds (table staged per workgroup, id -> LDS -> gathers) -----------
 __global__ void __launch_bounds__(256) k_pat_lds(int64_t n, int64_t ntiles, int32_t npat, const uint16_t *__restrict__ pid,
                                                   const int32_t *__restrict__ poff, const double *__restrict__ pre,
@@ -425,6 +437,119 @@ __global__ void __launch_bounds__(BLK) k_planes_tile(int64_t n, int64_t ntiles, 
     if (live) y[row] = sum;
 }
 
+// Lb with a non-temporal store of y (does y's write-back traffic push x's planes out of the 4 MB L2?)
+template <int NS, int BLK, unsigned NEAR>
+__global__ void __launch_bounds__(BLK) k_planes_tile_nt(int64_t n, int64_t ntiles, Sup sup, SlotVal sv, int32_t H, const uint64_t *__restrict__ planes,
+                                                     const cplx *__restrict__ x, cplx *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    cplx *sx = reinterpret_cast<cplx *>(smem);
+    const int64_t base = tile * BLK;
+    const int64_t rloc = base + threadIdx.x;
+    const bool live = rloc < n;
+    const int32_t row = (int32_t)(live ? rloc : n - 1);
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
+    const uint64_t *pp = planes + wave * 8;
+    uint64_t pl[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) pl[c] = pp[c];
+    cplx xv[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++)
+        if (!(NEAR >> c & 1u)) {
+            int32_t j = row + sup.off[c];
+            j = j < 0 ? 0 : j >= (int32_t)n ? (int32_t)n - 1 : j;
+            xv[c] = x[j];
+        }
+    cplx own = x[row];
+    cplx halo = make_double2(0., 0.);
+    int hidx = -1;
+    if ((int)threadIdx.x < 2 * H) {
+        const int t = threadIdx.x;
+        int64_t j = t < H ? base - H + t : base + BLK + (t - H);
+        j = j < 0 ? 0 : j >= n ? n - 1 : j;
+        halo = x[j];
+        hidx = t < H ? t : BLK + t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    sx[H + threadIdx.x] = own;
+    if (hidx >= 0) sx[hidx] = halo;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    cplx sum = make_double2(0., 0.);
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + sup.off[c]] : xv[c];
+        const bool on = (pl[c] >> lane & 1ull) != 0;
+        const double nx = sum.x + sv.v[c] * v.x, ny = sum.y + sv.v[c] * v.y;
+        sum.x = on ? nx : sum.x; sum.y = on ? ny : sum.y;
+    }
+    if (live) { __builtin_nontemporal_store(sum.x, &y[row].x); __builtin_nontemporal_store(sum.y, &y[row].y); }
+}
+
+
+// Lb with RPT rows per thread: a workgroup of BLK threads owns RPT * BLK consecutive rows (thread t: rows t, t + BLK, ...), one
+// window of RPT * BLK + 2 H entries, all loads of all rows in flight before the barrier
+template <int NS, int BLK, unsigned NEAR, int RPT>
+__global__ void __launch_bounds__(BLK) k_planes_tile_n(int64_t n, int64_t ntiles, Sup sup, SlotVal sv, int32_t H, const uint64_t *__restrict__ planes,
+                                                       const cplx *__restrict__ x, cplx *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    cplx *sx = reinterpret_cast<cplx *>(smem);
+    const int64_t base = tile * BLK * RPT;
+    uint64_t pl[RPT][NS];
+    cplx xv[RPT][NS], own[RPT];
+    int32_t row[RPT];
+    bool live[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        const int64_t rloc = base + h * BLK + threadIdx.x;
+        live[h] = rloc < n;
+        row[h] = (int32_t)(live[h] ? rloc : n - 1);
+        const int64_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
+        const uint64_t *pp = planes + (wave < (n + 63) / 64 ? wave : 0) * 8;
+#pragma unroll
+        for (int c = 0; c < NS; c++) pl[h][c] = pp[c];
+#pragma unroll
+        for (int c = 0; c < NS; c++)
+            if (!(NEAR >> c & 1u)) {
+                int32_t j = row[h] + sup.off[c];
+                j = j < 0 ? 0 : j >= (int32_t)n ? (int32_t)n - 1 : j;
+                xv[h][c] = x[j];
+            }
+        own[h] = x[row[h]];
+    }
+    cplx halo = make_double2(0., 0.);
+    int hidx = -1;
+    if ((int)threadIdx.x < 2 * H) {
+        const int t = threadIdx.x;
+        int64_t j = t < H ? base - H + t : base + BLK * RPT + (t - H);
+        j = j < 0 ? 0 : j >= n ? n - 1 : j;
+        halo = x[j];
+        hidx = t < H ? t : BLK * RPT + t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < RPT; h++) sx[H + h * BLK + threadIdx.x] = own[h];
+    if (hidx >= 0) sx[hidx] = halo;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int h = 0; h < RPT; h++) {
+        cplx sum = make_double2(0., 0.);
+#pragma unroll
+        for (int c = 0; c < NS; c++) {
+            cplx v = (NEAR >> c & 1u) ? sx[H + h * BLK + (int)threadIdx.x + sup.off[c]] : xv[h][c];
+            const bool on = (pl[h][c] >> lane & 1ull) != 0;
+            const double nx = sum.x + sv.v[c] * v.x, ny = sum.y + sv.v[c] * v.y;
+            sum.x = on ? nx : sum.x; sum.y = on ? ny : sum.y;
+        }
+        if (live[h]) y[row[h]] = sum;
+    }
+}
+
 __global__ void k_flush(int64_t n, const double4 *__restrict__ a, double4 *__restrict__ b) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
@@ -507,6 +632,9 @@ int main(int argc, char **argv) {
     std::vector<Var> vars;
     vars.push_back({"C  pat_spmv_lds (product)", [&] { hipLaunchKernelGGL(k_pat_lds, dim3(g256), dim3(256), lds_c, st, N, nt256, npat, pid, poff, pre, x, y); }});
     vars.push_back({"A  copy y=x", [&] { hipLaunchKernelGGL(k_copy, dim3((unsigned)nt256), dim3(256), 0, st, N, x, y); }});
+    vars.push_back({"A2 copy, 2 per thread", [&] { hipLaunchKernelGGL((k_copy_n<2>), dim3((unsigned)((N + 511) / 512)), dim3(256), 0, st, N, x, y); }});
+    vars.push_back({"A4 copy, 4 per thread", [&] { hipLaunchKernelGGL((k_copy_n<4>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, N, x, y); }});
+    vars.push_back({"A8 copy, 8 per thread", [&] { hipLaunchKernelGGL((k_copy_n<8>), dim3((unsigned)((N + 2047) / 2048)), dim3(256), 0, st, N, x, y); }});
     vars.push_back({"F  fixed stencil (no id/table)", [&] { hipLaunchKernelGGL(k_fixed, dim3(g256), dim3(256), 0, st, N, nt256, sup, x, y); }});
     vars.push_back({"S1 superset, 256 thr, table per wg", [&] { hipLaunchKernelGGL((k_sup<7>), dim3(g256), dim3(256), lds_s, st, N, nt256, npat, sup, pid, sval, smask, x, y); }});
     vars.push_back({"S3 superset, no LDS", [&] { hipLaunchKernelGGL((k_sup_nolds<7>), dim3(g256), dim3(256), 0, st, N, nt256, npat, sup, pid, sval, smask, x, y); }});
@@ -579,6 +707,15 @@ int main(int argc, char **argv) {
                 if (2 * H <= 512) {
                     vars.push_back({"Lb planes + tile 1024 halo n", [&, H, nt1k, g1k] { hipLaunchKernelGGL((k_planes_tile<7, 1024, 0x3eu>), dim3(g1k), dim3(1024), (size_t)(1024 + 2 * H) * 16, st, N, nt1k, sup, sv, H, planes, x, y); }});
                     vars.push_back({"Lb planes + tile 512 halo n", [&, H, nt512, g512] { hipLaunchKernelGGL((k_planes_tile<7, 512, 0x3eu>), dim3(g512), dim3(512), (size_t)(512 + 2 * H) * 16, st, N, nt512, sup, sv, H, planes, x, y); }});
+                    {
+                        const int64_t nt2 = (N + 1023) / 1024, nt4 = (N + 2047) / 2048;
+                        const unsigned g2 = (unsigned)((nt2 + 7) / 8 * 8), g4 = (unsigned)((nt4 + 7) / 8 * 8);
+                        vars.push_back({"Lb planes + tile, 512 thr x 2 rows", [&, H, nt2, g2] { hipLaunchKernelGGL((k_planes_tile_n<7, 512, 0x3eu, 2>), dim3(g2), dim3(512), (size_t)(1024 + 2 * H) * 16, st, N, nt2, sup, sv, H, planes, x, y); }});
+                        vars.push_back({"Lb planes + tile, 256 thr x 2 rows", [&, H, nt512, g512] { hipLaunchKernelGGL((k_planes_tile_n<7, 256, 0x3eu, 2>), dim3(g512), dim3(256), (size_t)(512 + 2 * H) * 16, st, N, nt512, sup, sv, H, planes, x, y); }});
+                        vars.push_back({"Lb planes + tile, 512 thr x 4 rows", [&, H, nt4, g4] { hipLaunchKernelGGL((k_planes_tile_n<7, 512, 0x3eu, 4>), dim3(g4), dim3(512), (size_t)(2048 + 2 * H) * 16, st, N, nt4, sup, sv, H, planes, x, y); }});
+                        vars.push_back({"Lb planes + tile, 256 thr x 4 rows", [&, H, nt2, g2] { hipLaunchKernelGGL((k_planes_tile_n<7, 256, 0x3eu, 4>), dim3(g2), dim3(256), (size_t)(1024 + 2 * H) * 16, st, N, nt2, sup, sv, H, planes, x, y); }});
+                    }
+                    vars.push_back({"Lb planes + tile 512, nontemporal y", [&, H, nt512, g512] { hipLaunchKernelGGL((k_planes_tile_nt<7, 512, 0x3eu>), dim3(g512), dim3(512), (size_t)(512 + 2 * H) * 16, st, N, nt512, sup, sv, H, planes, x, y); }});
                     vars.push_back({"Lb planes + tile 1024 halo n (+-n only)", [&, H, nt1k, g1k] { hipLaunchKernelGGL((k_planes_tile<7, 1024, 0x22u>), dim3(g1k), dim3(1024), (size_t)(1024 + 2 * H) * 16, st, N, nt1k, sup, sv, H, planes, x, y); }});
                 }
             }
