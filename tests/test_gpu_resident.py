@@ -216,3 +216,35 @@ def test_resident_general_storage_bit_for_bit(case, restart, max_it):
     assert np.array_equal(hr, hc)
     assert np.array_equal(xr, xc)
     assert hr[-1] < hr[0]
+
+
+def test_vcycle_with_resident_coarsest_solve_is_bit_identical():
+    """a V-cycle whose coarsest solve takes the one-launch path returns the bits of the same cycle on the multi-kernel path, and
+    the preconditioned outer solve the same history"""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import problems
+    n = 64
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    dims = (n, n, n)
+    out = []
+    for resident in (1, 0):
+        prev = mg.set_option("resident_solver", resident)
+        try:
+            A = mg.Sparse(N, ncol, rowptr, col, val)
+            prm = mg.MG_Param(mg.Mesh(dims), 2, 1, None, mg.GCR(mg.GCR_Param(0, 10, 50, 1e-2, False)),
+                              mg.GCR(mg.GCR_Param(0, 10, 2, 1e-30, False)), 1, None, None, null_vectors=np.ones((1, N), np.complex128))
+            M = mg.MG(A, prm)
+            b = mg.Field(dims).fill_rhs(2)
+            before = mg.stat("resident_solves")
+            y = M(b).to_numpy()
+            took = mg.stat("resident_solves") - before
+            outer = mg.GCR(A, mg.GCR_Param(0, 5, 40, 1e-9, False, None, M, flexible=True))
+            x = mg.Field(dims).set_zero()
+            outer.solve(b, x)
+            out.append((took, y, outer.last_history.copy(), x.to_numpy()))
+        finally:
+            mg.set_option("resident_solver", prev)
+    assert out[0][0] >= 1 and out[1][0] == 0   # the 32^3 coarsest level (32768 rows) went through the resident solver, or not
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    assert out[0][2][-1] < 1e-9
