@@ -235,12 +235,17 @@ def pmc_traffic(key, n, lims=None, restart=0):
     if lims and kern:
         import re
 
+        have_step_build = any(name.startswith("step_build_kernel") for name in kern)
+
         def of(l):
             for name, b in kern.items():
                 if key == "xr" and name.startswith("xr_update_kernel"):
                     return b
+                m = re.match(r"step_build_kernel<\d+, \d+, (\d+)>", name)
+                if key == "apply_dots" and m and int(m.group(1)) == l and l < restart and have_step_build:
+                    return b
                 m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
-                if key == "apply_dots" and m and int(m.group(1)) == l:
+                if key == "apply_dots" and m and int(m.group(1)) == l and not (l < restart and have_step_build):
                     return b
                 m = re.match(r"build_lean_kernel<(\d+)>", name)
                 if key == "build" and l < restart and m and int(m.group(1)) == l:
@@ -354,10 +359,24 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
       apply   matrix + r read + Ar written + lim Aps_j read (+ Ar re-read by the separate multidot kernel when the
               fused kernel is not used)
       build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
+    fused == 2 (csrc/gcr_stepbuild.hip): the in-cycle steps run apply, dots and build as ONE launch in which A r never
+    leaves the chip — matrix + r + 2 lim Aps_j + r again + Ap written = matrix + 16 ncol + (2 lim + 2) V, booked under
+    `apply`; only the step that closes a cycle still has a build launch.
     exact for the iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored directions."""
     lims = [((k - 1) % R) + 1 for k in range(1, max(n_it, 1) + 1)]
-    b_apply = [matrix_bytes + 16 * ncol + 16 * N + l * V + (0 if fused else V) + (V if l > 8 else 0) for l in lims]
-    b_build = [(2 * R + 6) * V if l == R else (3 + l) * V for l in lims]
+    one = fused == 2
+
+    def apply_bytes(l):
+        if one and l < R and l <= 5:
+            return matrix_bytes + 16 * ncol + (2 * l + 2) * V
+        return matrix_bytes + 16 * ncol + 16 * N + l * V + (0 if fused else V) + (V if l > 8 else 0)
+
+    def build_bytes(l):
+        if l == R:
+            return (2 * R + 6) * V
+        return 0 if (one and l <= 5) else (3 + l) * V
+    b_apply = [apply_bytes(l) for l in lims]
+    b_build = [build_bytes(l) for l in lims]
     return [3.0 * V, sum(b_apply) / len(lims), sum(b_build) / len(lims)], sum(lims) / float(len(lims))
 
 
@@ -507,8 +526,12 @@ def run_headline(args, with_cpu=True):
     R = args.restart
     b_phase, mean_lim = gcr_phase_model(n_it.value, R, V, stored["matrix_bytes"], ncol, N, fused.value)
     names = ["xr_update_kernel (alpha, residual ring, |r|^2)",
-             "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value else "SpMV + multidot_kernel",
+             "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value == 1 else "SpMV + multidot_kernel",
              "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
+    if fused.value == 2:
+        names[1] = ("step_build_kernel<1..%d> (SpMV + beta dot products + direction build in ONE launch, A r stays in LDS); the step that "
+                    "closes a cycle: step_apply_kernel<%d>" % (R - 1, R))
+        names[2] = "build_close_kernel<%d> (the step that closes a cycle; the other steps build inside step_build_kernel)" % R
     keys = ["xr", "apply_dots", "build"]
     dom = max(range(3), key=lambda k: ph_us[k])
     achieved = b_phase[dom] / (ph_us[dom] * 1e-6) / 1e9

@@ -118,9 +118,13 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  *   "resident_solver" ($MGCR_RESIDENT): a lean restarted GCR solve on a stencil-view Sparse / DiracOp of at most one row per
  *                      thread of the chip (<= 262 144 rows) runs as ONE launch with its vectors in registers
  *                      (csrc/gcr_resident.hip; same iterates, bit for bit, as the multi-kernel path).
+ *   "step_build"      ($MGCR_STEPBUILD): a lean step with up to 5 stored directions on a 7-point stencil-view operator of 2^19 .. 2^21
+ *                      rows runs its apply, dot products and direction build as one launch, A r staying in LDS
+ *                      (csrc/gcr_stepbuild.hip; same iterates, bit for bit, as the two kernels).
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);
-/* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init. */
+/* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init,
+ * "step_build_launches" = steps that ran as one apply + build launch. */
 int mgcr_stat(const char *name, int64_t *value);
 
 /* ---- GCR: src/GCR.h, src/SolverParam.h ---------------------------------------------------- */

@@ -150,6 +150,7 @@ int mgcr_set_option(const char *name, int value, int *previous) {
     else if (!strcmp(name, "fused_apply")) prev = set_fuse_enabled(value != 0);
     else if (!strcmp(name, "graph_replay")) prev = set_graph_enabled(value != 0);
     else if (!strcmp(name, "resident_solver")) prev = set_resident_enabled(value != 0);
+    else if (!strcmp(name, "step_build")) prev = set_stepbuild_enabled(value != 0);
     else { set_error("mgcr_set_option: unknown option '%s'", name); return MGCR_ERR_INVALID; }
     if (previous) *previous = prev ? 1 : 0;
     return MGCR_OK;
@@ -158,6 +159,7 @@ int mgcr_set_option(const char *name, int value, int *previous) {
 int mgcr_stat(const char *name, int64_t *value) {
     MGCR_CHECK(name && value, MGCR_ERR_INVALID, "mgcr_stat: null argument");
     if (!strcmp(name, "resident_solves")) *value = resident_solve_count();
+    else if (!strcmp(name, "step_build_launches")) *value = stepbuild_launch_count();
     else { set_error("mgcr_stat: unknown counter '%s'", name); return MGCR_ERR_INVALID; }
     return MGCR_OK;
 }

@@ -62,11 +62,11 @@ bool set_lean_enabled(bool on) {
 // 0 = alpha/r update (+ preconditioner), 1 = operator apply + beta dot products, 2 = direction build
 static double g_prof_phase_ms[3] = {0., 0., 0.};
 static int g_prof_iters = 0;
-static bool g_prof_fused = false;
+static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip)
 void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused) {
     for (int k = 0; k < 3; k++) phase_ms_total[k] = g_prof_phase_ms[k];
     *n_iter = g_prof_iters;
-    *fused = g_prof_fused ? 1 : 0;
+    *fused = g_prof_fused;
 }
 
 struct GcrState {
@@ -1243,6 +1243,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;
+    bool prof_step_build = false;
     // one iteration, enqueued on the library stream; `it` = iteration number relative to DevState::base
     auto one_iteration = [&](int it, bool last = false) -> int {
         iter_count++;
@@ -1338,6 +1339,25 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         MGCR_TRY(mark());
         const int nchunk = (lim + ND - 1) / ND;
         int ch0 = 0;
+        // apply + dots + build in ONE launch (gcr_stepbuild.hip) where A r of a thread's rows fits LDS: not the step that closes a cycle
+        bool step_build = false;
+        if (fuse_ok && lean && !flex && !multi && !xr_now && ic_next != 0 && rmap.band == 0) {
+            const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+            step_build = csr_step_build_eligible(b0->csr, b0->dist, lim);
+        }
+        if (step_build) {
+            prof_step_build = true;
+            const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+            const cplx *vecs[FND];
+            for (int j = 0; j < FND; j++) vecs[j] = s->aps[j < lim ? j : 0];
+            MGCR_TRY(csr_step_build(b0->csr, dir, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->st, it, refR.p, refR.nblk, refR.stride, s->hist,
+                                    s->hist_cap, s->den, s->aps[nxt], s->partsA, s->lc, rmap));
+            MGCR_TRY(mark());
+            MGCR_TRY(mark());
+            iter_count = ic_next;
+            cur = nxt;
+            return MGCR_OK;
+        }
         if (fuse_ok) {
             // Ar = A dir and the <Ar, Aps_j> partials of the first FND = 10 stored directions in one pass (gcr_fused.hip);
             // with more than that (restart > 10) multidot_kernel takes directions 8.. in its chunks of ND = 8 (8 and 9 twice:
@@ -1489,7 +1509,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 g_prof_phase_ms[k] += ms;
             }
         g_prof_iters = (int)(prof_events.size() / 4);
-        g_prof_fused = fuse_ok;
+        g_prof_fused = prof_step_build ? 2 : fuse_ok ? 1 : 0;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);

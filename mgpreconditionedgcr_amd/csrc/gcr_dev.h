@@ -149,4 +149,10 @@ bool gcr_resident_eligible(const Op *A, const mgcr_gcr_param &p, int storage, in
 int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, const cplx *rhs, cplx *x, bool from_zero, bool alpha_only_last,
                      DevState *st, double *hist, int hist_cap, cplx *ring /* 11 n entries */, SkipRef outer);
 
+// gcr_stepbuild.hip: apply + dot products + direction build of a lean step in one launch
+bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim);
+int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cplx *const *aps, int nd, DevState *st, int it, const double *partsR,
+                   int nblkR, int strideR, double *hist, int hist_cap, const cplx *den, cplx *ap_out, double *partsA, LeanCoef *lc,
+                   const RowMap &rm);
+
 }  // namespace mgcr

@@ -1,0 +1,242 @@
+// Apply + dot products + direction build of a lean GCR step as ONE launch (src/GCR.h:242-287), for systems whose A r fits
+// the chip's LDS: at most 4096 rows per workgroup of 1024 threads, two workgroups per CU — 2 097 152 rows on MI355X, i.e.
+// up to Poisson 128^3, the metric's configuration.
+//
+// gcr_fused.hip's step_apply_kernel writes Ar (V), its partial sums of <Ar, Ap_j> go to memory, and gcr.hip's
+// build_lean_kernel — behind a kernel boundary, because beta needs the sums over ALL workgroups — reads Ar back (V).
+// Here the two kernel bodies run in one launch with exchange_dev.h's fence-free exchange (~3 us) in between: a thread
+// keeps the Ar of its 4 rows in LDS (64 KB per workgroup, thread-private slots), so Ar is neither written to nor read
+// from memory: 2 V of the iteration's 15.6 V, one kernel boundary and one fold less.  Everything else is the two
+// kernels' code: the same rows per thread (RowMap), the same per-thread accumulation order, the same fold tree — the
+// same bits (tests/test_gpu_stepbuild.py compares with the two-kernel path bit for bit).
+//
+// Needs all workgroups co-resident (they wait for each other): 64 VGPRs and <= 80 KB of LDS each, at most 2 x #CU
+// workgroups, no other process on the device (no live communicator).  Up to 5 stored directions (beyond that the two
+// kernels need 128 registers: one workgroup per CU).  Bounded polls as in gcr_resident.hip: a missing workgroup makes the
+// others leave with NaN results and an error at the next host synchronisation.
+#include <climits>
+#include <cstdlib>
+
+#include "internal.h"
+#include "reduce.h"
+#include "gcr_dev.h"
+#include "spmv_dev.h"
+#include "exchange_dev.h"
+
+namespace mgcr {
+
+constexpr int SB_MAX_TRIPS = 4;     // rows per thread whose Ar stays in LDS (4 x 1024 x 16 B = 64 KB per workgroup)
+constexpr int SB_MAX_ND = 5;
+
+struct StepBuildArgs {
+    RowMat m;
+    const cplx *x;           // the residual the step applies the operator to (= the direction's start D_k)
+    const cplx *aps[SB_MAX_ND];
+    int64_t n;
+    int nlogical;
+    RowMap rm;
+    DevState *st;
+    int it;
+    const double *partsR;    // |r|^2 partials of the residual update that ran before
+    int nblkR, strideR;
+    double *hist;
+    int hist_cap;
+    const cplx *den;
+    cplx *ap_out;
+    double *partsA;
+    LeanCoef *lc;
+    v4i *slots;
+    unsigned gen0;
+    unsigned *abort_dev;
+    int *abort_host;
+    int spin_limit;
+};
+
+// step bookkeeping (gcr.hip close_step; kept in step with it by tests/test_gpu_stepbuild.py)
+__device__ __forceinline__ void sb_close_step(DevState *st, int it, double rr, double *hist, int hist_cap) {
+    const int git = st->base + it;
+    st->iter = git;
+    st->rr = rr;
+    if (git < hist_cap) hist[git] = sqrt(rr) / sqrt(st->bnorm2);
+    if (!((rr / st->bnorm2) > st->tol2)) st->stop_at = git;
+}
+
+template <int MODE, int WT, int NDT>
+__global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArgs a) {
+    __shared__ double lds[(2 * NDT > 4 ? 2 * NDT : 4) * 17];
+    __shared__ double lds_pw[2 * SB_MAX_ND * 17], lds_ws[2 * SB_MAX_ND * RES_GRP];
+    __shared__ int gave_up;
+    __shared__ cplx sbeta[NDT];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];   // Ar of this workgroup's rows: [trip][thread]
+    if (a.st->stop_at < a.st->base + a.it) return;
+    const int lb = logical_workgroup(a.rm, (int)blockIdx.x, (int)gridDim.x);
+    if (lb >= a.nlogical) return;
+    cplx *arL = reinterpret_cast<cplx *>(sb_smem);
+    ResSync sy;
+    sy.slots = res_rsrc(a.slots, (unsigned)RES_SLOT_BYTES);
+    sy.gen = a.gen0;
+    sy.nblk = a.nlogical;
+    sy.lb = lb;
+    sy.abort_dev = a.abort_dev;
+    sy.spin_limit = a.spin_limit;
+    sy.pw = lds_pw;
+    sy.ws = lds_ws;
+    sy.gave_up = &gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    int64_t i0, end, stride;
+    row_range(a.rm, lb, a.nlogical, a.n, &i0, &end, &stride);
+    // ---- apply + dot products (gcr_fused.hip step_apply_kernel) ----
+    {
+        double v[2 * NDT];
+#pragma unroll
+        for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
+        int trip = 0;
+        for (int64_t i = i0; i < end; i += stride, trip++) {
+            const PatLds pl{nullptr, nullptr, nullptr};
+            const cplx sum = fused_row_product<MODE, WT>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return a.x[j]; });
+            const cplx yi = a.m.shift ? csub(a.x[i], cmul(a.m.k, sum)) : sum;
+            arL[trip * RED_THREADS + (int)threadIdx.x] = yi;
+            __builtin_amdgcn_sched_barrier(0);
+            cplx b[NDT];
+#pragma unroll
+            for (int j = 0; j < NDT; j++) b[j] = ld_stream<true>(a.aps[j] + i);
+#pragma unroll
+            for (int j = 0; j < NDT; j++) {
+                cplx t = cconj_mul(yi, b[j]);
+                v[2 * j] += t.x;
+                v[2 * j + 1] += t.y;
+            }
+        }
+        // ---- the sums over all workgroups (exchange_dev.h), in place of the partial slab + fold_partials ----
+        const double mine = block_sum_owner<2 * NDT>(v, lds);
+        if ((int)threadIdx.x < 2 * NDT) {
+            const v4i w4 = {__double2loint(mine), __double2hiint(mine), (int)sy.gen, 0};
+            __builtin_amdgcn_raw_buffer_store_b128(w4, sy.slots, ((1 * RES_NV + (int)threadIdx.x) * RES_BLK + lb) * 16, 0, RES_SC1);
+        }
+    }
+    const bool ok = res_collect<2 * NDT>(sy, 1);
+    if (!ok) {   // somebody is missing: leave, with results nobody can mistake for numbers
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.abort_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        for (int64_t i = i0; i < end; i += stride) a.ap_out[i] = make_double2(__builtin_nan(""), __builtin_nan(""));
+        if ((int)threadIdx.x < 4) a.partsA[threadIdx.x * RED_MAX_BLOCKS + lb] = __builtin_nan("");
+        return;
+    }
+    // ---- direction build (gcr.hip build_lean_kernel, not closing) ----
+    if (lb == 0) {
+        double rr[1];
+        fold_partials<1>(a.partsR, a.nblkR, a.strideR, rr, lds);
+        if (threadIdx.x == 0) sb_close_step(a.st, a.it, rr[0], a.hist, a.hist_cap);
+    }
+    if ((int)threadIdx.x < NDT) sbeta[threadIdx.x] = cdiv(make_double2(res_total(sy, 2 * threadIdx.x), res_total(sy, 2 * threadIdx.x + 1)), a.den[threadIdx.x]);
+    __syncthreads();
+    if (lb == 0 && (int)threadIdx.x <= NDT) {   // row k = NDT of the coefficient table
+        constexpr int k = NDT;
+        const int m = threadIdx.x;
+        LeanCoef *lc = a.lc;
+        cplx c = make_double2(0., 0.);
+        if (m == 0) {
+            for (int j = 0; j < k; j++) c = csub(c, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
+            lc->t[k] = c;
+        } else if (m < k) {
+            for (int j = m; j < k; j++) c = csub(c, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * LND + m]));
+            lc->T[k * LND + m] = c;
+        } else {
+            lc->T[k * LND + k] = make_double2(1., 0.);
+        }
+    }
+    cplx beta[NDT];
+#pragma unroll
+    for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
+    double v[4] = {0., 0., 0., 0.};
+    int trip = 0;
+    for (int64_t i = i0; i < end; i += stride, trip++) {
+        cplx aj[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) aj[j] = ld_stream<NTS>(a.aps[j] + i);
+        const cplx av = arL[trip * RED_THREADS + (int)threadIdx.x], rv = a.x[i];
+        cplx ac = make_double2(0., 0.);
+#pragma unroll
+        for (int j = 0; j < NDT; j++) ac = csub(ac, cmul(beta[j], aj[j]));
+        const cplx an = cadd(av, ac);
+        a.ap_out[i] = an;
+        cplx t = cconj_mul(rv, an);
+        v[0] += t.x; v[1] += t.y;
+        cplx u = cconj_mul(an, an);
+        v[2] += u.x; v[3] += u.y;
+    }
+    const double mine = block_sum_owner<4>(v, lds);
+    if (threadIdx.x < 4) a.partsA[threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+}
+
+static int g_stepbuild = -1;
+static bool stepbuild_enabled() {
+    if (g_stepbuild < 0) g_stepbuild = !(getenv("MGCR_STEPBUILD") && atoi(getenv("MGCR_STEPBUILD")) == 0);
+    return g_stepbuild != 0;
+}
+bool set_stepbuild_enabled(bool on) {
+    bool prev = stepbuild_enabled();
+    g_stepbuild = on ? 1 : 0;
+    return prev;
+}
+static int64_t g_stepbuild_launches = 0;
+int64_t stepbuild_launch_count() { return g_stepbuild_launches; }
+
+// can step `lim` of a lean cycle on A run as one launch?  (single GPU, 7-slot stencil view, <= 5 stored directions, A r in LDS)
+bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim) {
+    if (!stepbuild_enabled() || dist || comm_live_count() > 0 || lim < 1 || lim > SB_MAX_ND) return false;
+    if (!csr_fusable(A, nullptr) || !csr_stencil_active(A) || A.sten_rare || sten_slots(A) != 7) return false;
+    const int g = red_grid(A.nrow);
+    if (g < 64 || g % 8 != 0) return false;   // (smaller systems have the resident solver or the xr-fused kernels)
+    if ((int64_t)g * RED_THREADS * SB_MAX_TRIPS < A.nrow) return false;
+    if (A.reach >= ((int64_t)1 << 15)) return false;   // rows that reach this far take the LDS-window kernels (gcr_fused.hip)
+    if (exchange_shared_init() != MGCR_OK) return false;
+    return g <= 2 * exchange_shared().cus && g <= RES_BLK;
+}
+
+int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cplx *const *aps, int nd, DevState *st, int it, const double *partsR,
+                   int nblkR, int strideR, double *hist, int hist_cap, const cplx *den, cplx *ap_out, double *partsA, LeanCoef *lc,
+                   const RowMap &rm) {
+    MGCR_CHECK(nd >= 1 && nd <= SB_MAX_ND, MGCR_ERR_INVALID, "csr_step_build: 1..5 directions");
+    MGCR_TRY(exchange_shared_init());
+    ExchangeShared &sh = exchange_shared();
+    StepBuildArgs a;
+    a.m = row_mat(A, shift, k);
+    a.x = x;
+    for (int j = 0; j < SB_MAX_ND; j++) a.aps[j] = aps[j < nd ? j : 0];
+    a.n = A.nrow;
+    const int g = red_grid(A.nrow);
+    a.nlogical = g;
+    a.rm = rm;
+    a.st = st; a.it = it; a.partsR = partsR; a.nblkR = nblkR; a.strideR = strideR; a.hist = hist; a.hist_cap = hist_cap;
+    a.den = den; a.ap_out = ap_out; a.partsA = partsA; a.lc = lc;
+    a.slots = sh.slots; a.abort_dev = sh.abort_dev; a.abort_host = sh.abort_host;
+    a.gen0 = exchange_take_generations(2);
+    a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
+    const unsigned grid = (unsigned)g;
+    const size_t lds_bytes = sizeof(cplx) * RED_THREADS * (size_t)((A.nrow + (int64_t)g * RED_THREADS - 1) / ((int64_t)g * RED_THREADS));
+#define SB(NDT)                                                                                                                    \
+    do {                                                                                                                           \
+        static bool big_lds = false;   /* 64 KB of dynamic LDS: above the default limit */                                          \
+        if (!big_lds) {                                                                                                            \
+            MGCR_HIP(hipFuncSetAttribute((const void *)step_build_kernel<3, 7, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            big_lds = true;                                                                                                        \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((step_build_kernel<3, 7, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, a);             \
+    } while (0)
+    switch (nd) {
+        case 1: SB(1); break;
+        case 2: SB(2); break;
+        case 3: SB(3); break;
+        case 4: SB(4); break;
+        default: SB(5); break;
+    }
+#undef SB
+    MGCR_HIP(hipGetLastError());
+    g_stepbuild_launches++;
+    return MGCR_OK;
+}
+
+}  // namespace mgcr

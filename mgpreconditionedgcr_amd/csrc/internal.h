@@ -171,6 +171,8 @@ bool set_resident_enabled(bool on);   // gcr_resident.hip: whole small solves in
 int resident_check();                  // did such a solve give up (launch not co-resident)?  Called at host synchronisation points
 void resident_shutdown();
 int64_t resident_solve_count();
+bool set_stepbuild_enabled(bool on);   // gcr_stepbuild.hip: apply + dots + build of a lean step as one launch
+int64_t stepbuild_launch_count();
 // y = A x   or (shift) y = w - k*(A x) with w = x unless given (w = b, k = 1: the residual b - A x in one pass);
 // dist != nullptr: row block with halo exchange
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr, const cplx *w = nullptr);

@@ -1,0 +1,67 @@
+"""Apply + dot products + direction build as one launch (csrc/gcr_stepbuild.hip) against the two kernels it replaces: the same
+solve must give the same iteration count, history and x bit for bit (same rows per thread, same accumulation order, same
+fold tree), and the one-launch path must actually have run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(A, dims, p, b, fused):
+    import mgpreconditionedgcr_amd as mg
+    prev = mg.set_option("step_build", 1 if fused else 0)
+    try:
+        g = mg.GCR(A, p)
+        x = mg.Field(dims).set_zero()
+        before = mg.stat("step_build_launches")
+        g.solve(b, x)
+        return x.to_numpy().copy(), g.last_history.copy(), g.last_iterations, mg.stat("step_build_launches") - before
+    finally:
+        mg.set_option("step_build", prev)
+
+
+@pytest.mark.parametrize("n,restart,max_it,dirac", [(96, 5, 23, False), (128, 5, 20, False), (112, 10, 27, False), (100, 5, 12, True),
+                                                    (128, 10, 14, True), (104, 3, 9, False)])
+def test_step_build_equals_two_kernels_bit_for_bit(n, restart, max_it, dirac):
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import problems
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = mg.Sparse(N, ncol, rowptr, col, val)
+    op = mg.DiracOp(A, 0.05 - 0.02j) if dirac else A
+    dims = (n, n, n)
+    b = mg.Field(dims).fill_rhs(n)
+    p = mg.GCR_Param(0, restart, max_it, 1e-30, False)
+    xf, hf, itf, nf = _solve(op, dims, p, b, True)
+    xc, hc, itc, nc = _solve(op, dims, p, b, False)
+    assert nc == 0 and nf > 0, (nf, nc)
+    # every step with at most 5 stored directions that does not close a cycle
+    expect = sum(1 for it in range(1, max_it) if (it % restart) != 0 and min(it % restart, restart) <= 5)
+    assert nf == expect, (nf, expect)
+    assert itf == itc
+    assert np.array_equal(hf, hc)
+    assert np.array_equal(xf, xc)
+    assert np.all(np.isfinite(xf)) and hf[-1] < hf[0]
+
+
+def test_step_build_stops_like_the_two_kernels():
+    """convergence inside a cycle: the stop predicate is raised by the build half, later launches of the solve return at once"""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import problems
+    n = 96
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    val = val.copy()
+    val[col == np.repeat(np.arange(N), np.diff(rowptr))] += 2.0   # well conditioned: converges in a few steps
+    A = mg.Sparse(N, ncol, rowptr, col, val)
+    dims = (n, n, n)
+    b = mg.Field(dims).fill_rhs(1)
+    p = mg.GCR_Param(0, 5, 200, 1e-9, False)
+    xf, hf, itf, nf = _solve(A, dims, p, b, True)
+    xc, hc, itc, nc = _solve(A, dims, p, b, False)
+    assert nf > 0 and itf == itc and itf < 60
+    assert np.array_equal(hf, hc) and np.array_equal(xf, xc)
+    assert hf[-1] <= 1e-9
