@@ -236,14 +236,15 @@ def pmc_traffic(key, n, lims=None, restart=0):
         import re
 
         have_step_build = any(name.startswith("step_build_kernel") for name in kern)
+        have_step_build_xr = any(re.match(r"step_build_kernel<.*, true>", name) for name in kern)
 
         def of(l):
             for name, b in kern.items():
                 if key == "xr" and name.startswith("xr_update_kernel"):
                     return b
-                m = re.match(r"step_build_kernel<\d+, \d+, (\d+)>", name)
-                if key == "apply_dots" and m and int(m.group(1)) == l and l < restart and have_step_build:
-                    return b
+                m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false)>", name)
+                if key == "apply_dots" and m and int(m.group(1)) == l and l < restart and have_step_build and (m.group(2) == "true") == have_step_build_xr:
+                    return b   # (with the next step's update fused in, the few launches without it — before the solve's last step — are booked like the others)
                 m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
                 if key == "apply_dots" and m and int(m.group(1)) == l and not (l < restart and have_step_build):
                     return b
@@ -359,25 +360,37 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
       apply   matrix + r read + Ar written + lim Aps_j read (+ Ar re-read by the separate multidot kernel when the
               fused kernel is not used)
       build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
-    fused == 2 (csrc/gcr_stepbuild.hip): the in-cycle steps run apply, dots and build as ONE launch in which A r never
+    fused >= 2 (csrc/gcr_stepbuild.hip): the in-cycle steps run apply, dots and build as ONE launch in which A r never
     leaves the chip — matrix + r + 2 lim Aps_j + r again + Ap written = matrix + 16 ncol + (2 lim + 2) V, booked under
-    `apply`; only the step that closes a cycle still has a build launch.
+    `apply`; only the step that closes a cycle still has a build launch.  fused == 3: that launch also ends with the NEXT
+    iteration's residual update (+ 2 V: r read, r' written; the new Ap is on the chip), whose xr launch then does not exist.
     exact for the iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored directions."""
     lims = [((k - 1) % R) + 1 for k in range(1, max(n_it, 1) + 1)]
-    one = fused == 2
+    one = fused >= 2
+    nl = len(lims)
 
-    def apply_bytes(l):
-        if one and l < R and l <= 5:
-            return matrix_bytes + 16 * ncol + (2 * l + 2) * V
+    def one_launch(idx):            # iteration idx (0-based) runs apply + dots + build as one launch
+        return one and lims[idx] < R and lims[idx] <= 5
+
+    def update_prefetched(idx):     # ... and its residual update already ran at the end of the previous iteration's launch (fused == 3)
+        return fused == 3 and idx >= 1 and one_launch(idx - 1) and idx < nl - 1
+
+    def apply_bytes(idx):
+        l = lims[idx]
+        if one_launch(idx):
+            nxt = 2 * V if (idx + 1 < nl and update_prefetched(idx + 1)) else 0    # r read again, r' written; the new Ap is on the chip
+            return matrix_bytes + 16 * ncol + (2 * l + 2) * V + nxt
         return matrix_bytes + 16 * ncol + 16 * N + l * V + (0 if fused else V) + (V if l > 8 else 0)
 
-    def build_bytes(l):
+    def build_bytes(idx):
+        l = lims[idx]
         if l == R:
             return (2 * R + 6) * V
-        return 0 if (one and l <= 5) else (3 + l) * V
-    b_apply = [apply_bytes(l) for l in lims]
-    b_build = [build_bytes(l) for l in lims]
-    return [3.0 * V, sum(b_apply) / len(lims), sum(b_build) / len(lims)], sum(lims) / float(len(lims))
+        return 0 if one_launch(idx) else (3 + l) * V
+    b_xr = [0 if update_prefetched(i) else 3.0 * V for i in range(nl)]
+    b_apply = [apply_bytes(i) for i in range(nl)]
+    b_build = [build_bytes(i) for i in range(nl)]
+    return [sum(b_xr) / nl, sum(b_apply) / nl, sum(b_build) / nl], sum(lims) / float(nl)
 
 
 def cold_apply_ms(mg, A, xin, yout, reps, Field):
@@ -528,9 +541,11 @@ def run_headline(args, with_cpu=True):
     names = ["xr_update_kernel (alpha, residual ring, |r|^2)",
              "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value == 1 else "SpMV + multidot_kernel",
              "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
-    if fused.value == 2:
-        names[1] = ("step_build_kernel<1..%d> (SpMV + beta dot products + direction build in ONE launch, A r stays in LDS); the step that "
-                    "closes a cycle: step_apply_kernel<%d>" % (R - 1, R))
+    if fused.value >= 2:
+        names[0] = "xr_update_kernel (alpha, residual ring, |r|^2)" + (
+            ": only the updates that follow a cycle's closing step, open or end the solve — the others run at the end of step_build_kernel" if fused.value == 3 else "")
+        names[1] = ("step_build_kernel<1..%d> (SpMV + beta dot products + direction build%s in ONE launch, A r stays in LDS); the step that "
+                    "closes a cycle: step_apply_kernel<%d>" % (R - 1, " + the next step's residual update" if fused.value == 3 else "", R))
         names[2] = "build_close_kernel<%d> (the step that closes a cycle; the other steps build inside step_build_kernel)" % R
     keys = ["xr", "apply_dots", "build"]
     dom = max(range(3), key=lambda k: ph_us[k])

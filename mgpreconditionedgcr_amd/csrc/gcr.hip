@@ -62,7 +62,7 @@ bool set_lean_enabled(bool on) {
 // 0 = alpha/r update (+ preconditioner), 1 = operator apply + beta dot products, 2 = direction build
 static double g_prof_phase_ms[3] = {0., 0., 0.};
 static int g_prof_iters = 0;
-static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip)
+static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip); 3: + the next step's residual update
 void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused) {
     for (int k = 0; k < 3; k++) phase_ms_total[k] = g_prof_phase_ms[k];
     *n_iter = g_prof_iters;
@@ -111,6 +111,10 @@ constexpr int64_t GRAPH_MAX_ROWS = 1 << 18;
 
 static bool fuse_init_enabled() {
     static const bool on = !(getenv("MGCR_FUSE_INIT") && atoi(getenv("MGCR_FUSE_INIT")) == 0);
+    return on;
+}
+static bool stepbuild_xr_enabled() {
+    static const bool on = !(getenv("MGCR_STEPBUILD_XR") && atoi(getenv("MGCR_STEPBUILD_XR")) == 0);
     return on;
 }
 static int g_graph = -1;
@@ -1243,7 +1247,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;
-    bool prof_step_build = false;
+    bool prof_step_build = false, prof_step_build_xr = false;
+    bool xr_prefetched = false;   // the next iteration's residual update already ran at the end of this one's launch
     // one iteration, enqueued on the library stream; `it` = iteration number relative to DevState::base
     auto one_iteration = [&](int it, bool last = false) -> int {
         iter_count++;
@@ -1292,7 +1297,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             }
             xr_now = xr_fuse && !(last && skip_tail);   // latency regime: the update runs inside the apply kernel below
             xr_in = rcur;
-            if (!xr_now)
+            if (xr_prefetched) xr_prefetched = false;   // the previous step's launch ended with this update (gcr_stepbuild.hip)
+            else if (!xr_now)
             KLAUNCH((xr_update_kernel<true, true>), g, s->st, it, refA.p, refA.nblk, refA.stride, (const cplx *)nullptr,
                     (const cplx *)s->aps[cur], x, rcur, r_out, n, s->partsR, s->den + cur, s->alphas, cur, s->lc);
             rcur = r_out;
@@ -1350,8 +1356,19 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
             const cplx *vecs[FND];
             for (int j = 0; j < FND; j++) vecs[j] = s->aps[j < lim ? j : 0];
+            // ... and, unless the next step is the solve's last (whose update takes other kernels), that step's residual update too:
+            // r and the new Ap of a thread's rows are on the chip, alpha costs one more exchange instead of a launch
+            cplx *xr_out = nullptr;
+            if (global + 1 < max_it && stepbuild_xr_enabled()) {
+                const int ic2 = ((ic_next + 1) % s->restart == 0) ? 0 : ic_next + 1;
+                const int nxt2 = ic2 % s->storage;
+                MGCR_TRY(ensure_slot(s, nxt2));
+                xr_out = nxt2 >= 1 ? s->ps[nxt2] : s->r;
+            }
             MGCR_TRY(csr_step_build(b0->csr, dir, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->st, it, refR.p, refR.nblk, refR.stride, s->hist,
-                                    s->hist_cap, s->den, s->aps[nxt], s->partsA, s->lc, rmap));
+                                    s->hist_cap, s->den, s->aps[nxt], s->partsA, s->lc, rmap, xr_out, s->den + nxt, nxt, s->partsR));
+            xr_prefetched = xr_out != nullptr;
+            prof_step_build_xr = prof_step_build_xr || xr_prefetched;
             MGCR_TRY(mark());
             MGCR_TRY(mark());
             iter_count = ic_next;
@@ -1509,7 +1526,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 g_prof_phase_ms[k] += ms;
             }
         g_prof_iters = (int)(prof_events.size() / 4);
-        g_prof_fused = prof_step_build ? 2 : fuse_ok ? 1 : 0;
+        g_prof_fused = prof_step_build_xr ? 3 : prof_step_build ? 2 : fuse_ok ? 1 : 0;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);

@@ -45,6 +45,11 @@ struct StepBuildArgs {
     cplx *ap_out;
     double *partsA;
     LeanCoef *lc;
+    // XR: the NEXT step's residual update (gcr.hip xr_update_kernel<true, true>) at the end of this launch
+    cplx *xr_out;            // where it leaves r - alpha Ap' (the next ring slot)
+    cplx *xr_den_slot;
+    int xr_slot;
+    double *partsR_out;
     v4i *slots;
     unsigned gen0;
     unsigned *abort_dev;
@@ -61,7 +66,7 @@ __device__ __forceinline__ void sb_close_step(DevState *st, int it, double rr, d
     if (!((rr / st->bnorm2) > st->tol2)) st->stop_at = git;
 }
 
-template <int MODE, int WT, int NDT>
+template <int MODE, int WT, int NDT, bool XR>
 __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArgs a) {
     __shared__ double lds[(2 * NDT > 4 ? 2 * NDT : 4) * 17];
     __shared__ double lds_pw[2 * SB_MAX_ND * 17], lds_ws[2 * SB_MAX_ND * RES_GRP];
@@ -125,10 +130,12 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
         return;
     }
     // ---- direction build (gcr.hip build_lean_kernel, not closing) ----
-    if (lb == 0) {
+    bool ends_here = false;   // XR: did this step end the solve?  Every workgroup folds |r|^2 itself: same bits, same answer
+    if (XR || lb == 0) {
         double rr[1];
         fold_partials<1>(a.partsR, a.nblkR, a.strideR, rr, lds);
-        if (threadIdx.x == 0) sb_close_step(a.st, a.it, rr[0], a.hist, a.hist_cap);
+        if (lb == 0 && threadIdx.x == 0) sb_close_step(a.st, a.it, rr[0], a.hist, a.hist_cap);
+        ends_here = !((rr[0] / a.st->bnorm2) > a.st->tol2);
     }
     if ((int)threadIdx.x < NDT) sbeta[threadIdx.x] = cdiv(make_double2(res_total(sy, 2 * threadIdx.x), res_total(sy, 2 * threadIdx.x + 1)), a.den[threadIdx.x]);
     __syncthreads();
@@ -162,6 +169,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
         for (int j = 0; j < NDT; j++) ac = csub(ac, cmul(beta[j], aj[j]));
         const cplx an = cadd(av, ac);
         a.ap_out[i] = an;
+        if (XR) arL[trip * RED_THREADS + (int)threadIdx.x] = an;   // (A r is not needed any more; the update below wants Ap')
         cplx t = cconj_mul(rv, an);
         v[0] += t.x; v[1] += t.y;
         cplx u = cconj_mul(an, an);
@@ -169,6 +177,40 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
     }
     const double mine = block_sum_owner<4>(v, lds);
     if (threadIdx.x < 4) a.partsA[threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    if constexpr (XR) {
+        // ---- the next step's residual update (gcr.hip xr_update_kernel<true, true>): alpha needs <r,Ap'>, <Ap',Ap'> over ALL
+        // workgroups — a second exchange instead of a kernel boundary; r and Ap' of the thread's rows are on the chip ----
+        if ((int)threadIdx.x < 4) {
+            const v4i w4 = {__double2loint(mine), __double2hiint(mine), (int)sy.gen, 0};
+            __builtin_amdgcn_raw_buffer_store_b128(w4, sy.slots, ((2 * RES_NV + (int)threadIdx.x) * RES_BLK + lb) * 16, 0, RES_SC1);
+        }
+        if (!res_collect<4>(sy, 2)) {
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(a.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.abort_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            for (int64_t i = i0; i < end; i += stride) a.xr_out[i] = make_double2(__builtin_nan(""), __builtin_nan(""));
+            if (threadIdx.x == 0) a.partsR_out[lb] = __builtin_nan("");
+            return;
+        }
+        if (ends_here) return;   // the step converged: the next one's kernels are no-ops (gcr_dev.h DevState::stop_at)
+        const cplx num = make_double2(res_total(sy, 0), res_total(sy, 1)), den = make_double2(res_total(sy, 2), res_total(sy, 3));
+        const cplx alpha = to_sgpr(cdiv(num, den));
+        if (lb == 0 && threadIdx.x == 0) {
+            *a.xr_den_slot = den;
+            a.st->npend = a.xr_slot + 1;
+        }
+        if (lb == 0 && (int)threadIdx.x < LND) lean_pending_update(a.lc, a.xr_slot, alpha, (int)threadIdx.x);
+        double vr[1] = {0.};
+        trip = 0;
+        for (int64_t i = i0; i < end; i += stride, trip++) {
+            const cplx rn = csub(a.x[i], cmul(alpha, arL[trip * RED_THREADS + (int)threadIdx.x]));
+            a.xr_out[i] = rn;
+            vr[0] += rn.x * rn.x + rn.y * rn.y;
+        }
+        const double tot = block_sum_owner<1>(vr, lds);
+        if (threadIdx.x == 0) a.partsR_out[lb] = tot;
+    }
 }
 
 static int g_stepbuild = -1;
@@ -198,7 +240,7 @@ bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim) {
 
 int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cplx *const *aps, int nd, DevState *st, int it, const double *partsR,
                    int nblkR, int strideR, double *hist, int hist_cap, const cplx *den, cplx *ap_out, double *partsA, LeanCoef *lc,
-                   const RowMap &rm) {
+                   const RowMap &rm, cplx *xr_out, cplx *xr_den_slot, int xr_slot, double *partsR_out) {
     MGCR_CHECK(nd >= 1 && nd <= SB_MAX_ND, MGCR_ERR_INVALID, "csr_step_build: 1..5 directions");
     MGCR_TRY(exchange_shared_init());
     ExchangeShared &sh = exchange_shared();
@@ -213,19 +255,21 @@ int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cpl
     a.st = st; a.it = it; a.partsR = partsR; a.nblkR = nblkR; a.strideR = strideR; a.hist = hist; a.hist_cap = hist_cap;
     a.den = den; a.ap_out = ap_out; a.partsA = partsA; a.lc = lc;
     a.slots = sh.slots; a.abort_dev = sh.abort_dev; a.abort_host = sh.abort_host;
-    a.gen0 = exchange_take_generations(2);
+    a.xr_out = xr_out; a.xr_den_slot = xr_den_slot; a.xr_slot = xr_slot; a.partsR_out = partsR_out;
+    a.gen0 = exchange_take_generations(3);
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     const unsigned grid = (unsigned)g;
     const size_t lds_bytes = sizeof(cplx) * RED_THREADS * (size_t)((A.nrow + (int64_t)g * RED_THREADS - 1) / ((int64_t)g * RED_THREADS));
-#define SB(NDT)                                                                                                                    \
+#define SB1(NDT, XRF)                                                                                                              \
     do {                                                                                                                           \
         static bool big_lds = false;   /* 64 KB of dynamic LDS: above the default limit */                                          \
         if (!big_lds) {                                                                                                            \
-            MGCR_HIP(hipFuncSetAttribute((const void *)step_build_kernel<3, 7, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            MGCR_HIP(hipFuncSetAttribute((const void *)step_build_kernel<3, 7, NDT, XRF>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
             big_lds = true;                                                                                                        \
         }                                                                                                                          \
-        hipLaunchKernelGGL((step_build_kernel<3, 7, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, a);             \
+        hipLaunchKernelGGL((step_build_kernel<3, 7, NDT, XRF>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, a);        \
     } while (0)
+#define SB(NDT) do { if (xr_out) SB1(NDT, true); else SB1(NDT, false); } while (0)
     switch (nd) {
         case 1: SB(1); break;
         case 2: SB(2); break;
@@ -233,6 +277,7 @@ int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cpl
         case 4: SB(4); break;
         default: SB(5); break;
     }
+#undef SB1
 #undef SB
     MGCR_HIP(hipGetLastError());
     g_stepbuild_launches++;

@@ -31,9 +31,11 @@ for r in rows:
     m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
     if m:
         b = B_spmv + int(m.group(1)) * V            # SpMV + lim direction streams, Ar written once
-    m = re.match(r"step_build_kernel<\d+, \d+, (\d+)>", name)
+    m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false)>", name)
     if m:
         b = B_spmv - V + (2 * int(m.group(1)) + 2) * V   # SpMV without the write of Ar; lim streams twice, r re-read, Ap written
+        if m.group(2) == "true":
+            b += 2 * V                                   # + the next step's residual update: r read, r' written
     m = re.match(r"build_lean_kernel<(\d+)>", name)
     if m:
         b = (3 + int(m.group(1))) * V               # r, Ar, lim Aps read; Ap written
