@@ -362,31 +362,39 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
       build   in-cycle (3 + lim) V, lim = 1..R-1;  cycle-closing step (2R + 6) V
     fused >= 2 (csrc/gcr_stepbuild.hip): the in-cycle steps run apply, dots and build as ONE launch in which A r never
     leaves the chip — matrix + r + 2 lim Aps_j + r again + Ap written = matrix + 16 ncol + (2 lim + 2) V, booked under
-    `apply`; only the step that closes a cycle still has a build launch.  fused == 3: that launch also ends with the NEXT
+    `apply`; only the step that closes a cycle still has a build launch.  fused >= 3: that launch also ends with the NEXT
     iteration's residual update (+ 2 V: r read, r' written; the new Ap is on the chip), whose xr launch then does not exist.
+    fused == 4: the step that closes a cycle runs the same way (restart <= 5): matrix + 16 ncol + (3 R + 5) V.  The solve's
+    last iteration (the timed solves run to max_iter) has no apply and no build launch at all (finish_step_kernel): it counts
+    with its residual update only — rounds 1 and 2 booked an apply and a build for it that never ran (4-8 % too many bytes in the
+    whole-iteration figure at --steps 20, 5 % in the dominant phase's).
     exact for the iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored directions."""
     lims = [((k - 1) % R) + 1 for k in range(1, max(n_it, 1) + 1)]
     one = fused >= 2
     nl = len(lims)
 
-    def one_launch(idx):            # iteration idx (0-based) runs apply + dots + build as one launch
-        return one and lims[idx] < R and lims[idx] <= 5
+    def one_launch(idx):            # iteration idx (0-based) runs apply + dots + build as one launch (fused == 4: the closing step too)
+        return one and lims[idx] <= 5 and (lims[idx] < R or fused == 4) and idx < nl - 1
 
-    def update_prefetched(idx):     # ... and its residual update already ran at the end of the previous iteration's launch (fused == 3)
-        return fused == 3 and idx >= 1 and one_launch(idx - 1) and idx < nl - 1
+    def update_prefetched(idx):     # ... and its residual update already ran at the end of the previous iteration's launch (fused >= 3)
+        return fused >= 3 and idx >= 1 and one_launch(idx - 1) and idx < nl - 1
 
     def apply_bytes(idx):
         l = lims[idx]
+        if idx == nl - 1:
+            return 0      # the solve's last iteration updates x and r and records |r|; the direction it would go on to build is never used
         if one_launch(idx):
             nxt = 2 * V if (idx + 1 < nl and update_prefetched(idx + 1)) else 0    # r read again, r' written; the new Ap is on the chip
+            if l == R:   # closing step in one launch: apply (without the write of A r) + build_close (without its read)
+                return matrix_bytes + 16 * ncol + (3 * R + 5) * V + nxt
             return matrix_bytes + 16 * ncol + (2 * l + 2) * V + nxt
         return matrix_bytes + 16 * ncol + 16 * N + l * V + (0 if fused else V) + (V if l > 8 else 0)
 
     def build_bytes(idx):
         l = lims[idx]
-        if l == R:
-            return (2 * R + 6) * V
-        return 0 if one_launch(idx) else (3 + l) * V
+        if one_launch(idx) or idx == nl - 1:
+            return 0
+        return (2 * R + 6) * V if l == R else (3 + l) * V
     b_xr = [0 if update_prefetched(i) else 3.0 * V for i in range(nl)]
     b_apply = [apply_bytes(i) for i in range(nl)]
     b_build = [build_bytes(i) for i in range(nl)]
@@ -543,10 +551,12 @@ def run_headline(args, with_cpu=True):
              "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
     if fused.value >= 2:
         names[0] = "xr_update_kernel (alpha, residual ring, |r|^2)" + (
-            ": only the updates that follow a cycle's closing step, open or end the solve — the others run at the end of step_build_kernel" if fused.value == 3 else "")
-        names[1] = ("step_build_kernel<1..%d> (SpMV + beta dot products + direction build%s in ONE launch, A r stays in LDS); the step that "
-                    "closes a cycle: step_apply_kernel<%d>" % (R - 1, " + the next step's residual update" if fused.value == 3 else "", R))
-        names[2] = "build_close_kernel<%d> (the step that closes a cycle; the other steps build inside step_build_kernel)" % R
+            ": only the updates that open or end the solve%s — the others run at the end of step_build_kernel" % ("" if fused.value == 4 else " or follow a cycle's closing step") if fused.value >= 3 else "")
+        names[1] = ("step_build_kernel<1..%d> (SpMV + beta dot products + direction build%s in ONE launch, A r stays in LDS)%s"
+                    % (R if fused.value == 4 else R - 1, " + the next step's residual update" if fused.value >= 3 else "",
+                       "" if fused.value == 4 else "; the step that closes a cycle: step_apply_kernel<%d>" % R))
+        names[2] = ("(no launch: every step builds inside step_build_kernel; what is timed here are the event records of an empty slot)" if fused.value == 4 else
+                    "build_close_kernel<%d> (the step that closes a cycle; the other steps build inside step_build_kernel)" % R)
     keys = ["xr", "apply_dots", "build"]
     dom = max(range(3), key=lambda k: ph_us[k])
     achieved = b_phase[dom] / (ph_us[dom] * 1e-6) / 1e9

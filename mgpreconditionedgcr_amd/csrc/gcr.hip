@@ -62,7 +62,7 @@ bool set_lean_enabled(bool on) {
 // 0 = alpha/r update (+ preconditioner), 1 = operator apply + beta dot products, 2 = direction build
 static double g_prof_phase_ms[3] = {0., 0., 0.};
 static int g_prof_iters = 0;
-static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip); 3: + the next step's residual update
+static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip); 3: + the next step's residual update; 4: the step that closes a cycle as well
 void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused) {
     for (int k = 0; k < 3; k++) phase_ms_total[k] = g_prof_phase_ms[k];
     *n_iter = g_prof_iters;
@@ -115,6 +115,10 @@ static bool fuse_init_enabled() {
 }
 static bool stepbuild_xr_enabled() {
     static const bool on = !(getenv("MGCR_STEPBUILD_XR") && atoi(getenv("MGCR_STEPBUILD_XR")) == 0);
+    return on;
+}
+static bool stepbuild_close_enabled() {
+    static const bool on = !(getenv("MGCR_STEPBUILD_CLOSE") && atoi(getenv("MGCR_STEPBUILD_CLOSE")) == 0);
     return on;
 }
 static int g_graph = -1;
@@ -1247,7 +1251,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     int iter_count = 0, cur = 0, global = 0;
     bool done = false;
     std::vector<hipEvent_t> prof_events;
-    bool prof_step_build = false, prof_step_build_xr = false;
+    bool prof_step_build = false, prof_step_build_xr = false, prof_step_build_close = false;
     bool xr_prefetched = false;   // the next iteration's residual update already ran at the end of this one's launch
     // one iteration, enqueued on the library stream; `it` = iteration number relative to DevState::base
     auto one_iteration = [&](int it, bool last = false) -> int {
@@ -1347,7 +1351,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         int ch0 = 0;
         // apply + dots + build in ONE launch (gcr_stepbuild.hip) where A r of a thread's rows fits LDS: not the step that closes a cycle
         bool step_build = false;
-        if (fuse_ok && lean && !flex && !multi && !xr_now && ic_next != 0 && rmap.band == 0) {
+        const bool closes = ic_next == 0;   // (lim == restart then; up to 5 directions the closing step has its one-launch form too)
+        if (fuse_ok && lean && !flex && !multi && !xr_now && rmap.band == 0 && (!closes || stepbuild_close_enabled())) {
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
             step_build = csr_step_build_eligible(b0->csr, b0->dist, lim);
         }
@@ -1365,10 +1370,14 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 MGCR_TRY(ensure_slot(s, nxt2));
                 xr_out = nxt2 >= 1 ? s->ps[nxt2] : s->r;
             }
+            const cplx *cps[FND];
+            for (int j = 0; j < FND; j++) cps[j] = s->ps[j < lim ? j : 0];
             MGCR_TRY(csr_step_build(b0->csr, dir, s->A->kind == OP_DIRAC, s->A->k, vecs, lim, s->st, it, refR.p, refR.nblk, refR.stride, s->hist,
-                                    s->hist_cap, s->den, s->aps[nxt], s->partsA, s->lc, rmap, xr_out, s->den + nxt, nxt, s->partsR));
+                                    s->hist_cap, s->den, s->aps[nxt], s->partsA, s->lc, rmap, xr_out, s->den + nxt, nxt, s->partsR,
+                                    closes ? cps : nullptr, closes ? s->ps[0] : nullptr, closes ? x : nullptr));
             xr_prefetched = xr_out != nullptr;
             prof_step_build_xr = prof_step_build_xr || xr_prefetched;
+            prof_step_build_close = prof_step_build_close || closes;
             MGCR_TRY(mark());
             MGCR_TRY(mark());
             iter_count = ic_next;
@@ -1526,7 +1535,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
                 g_prof_phase_ms[k] += ms;
             }
         g_prof_iters = (int)(prof_events.size() / 4);
-        g_prof_fused = prof_step_build_xr ? 3 : prof_step_build ? 2 : fuse_ok ? 1 : 0;
+        g_prof_fused = prof_step_build_close ? 4 : prof_step_build_xr ? 3 : prof_step_build ? 2 : fuse_ok ? 1 : 0;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);

@@ -153,6 +153,7 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
 bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim);
 int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cplx *const *aps, int nd, DevState *st, int it, const double *partsR,
                    int nblkR, int strideR, double *hist, int hist_cap, const cplx *den, cplx *ap_out, double *partsA, LeanCoef *lc,
-                   const RowMap &rm, cplx *xr_out = nullptr, cplx *xr_den_slot = nullptr, int xr_slot = 0, double *partsR_out = nullptr);
+                   const RowMap &rm, cplx *xr_out = nullptr, cplx *xr_den_slot = nullptr, int xr_slot = 0, double *partsR_out = nullptr,
+                   const cplx *const *close_ps = nullptr, cplx *close_p_out = nullptr, cplx *close_x = nullptr);
 
 }  // namespace mgcr

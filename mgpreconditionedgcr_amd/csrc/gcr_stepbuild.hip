@@ -45,6 +45,10 @@ struct StepBuildArgs {
     cplx *ap_out;
     double *partsA;
     LeanCoef *lc;
+    // CLOSE: the step that closes a restart cycle (gcr.hip build_close_kernel): the cycle's directions, its first one rewritten, x updated
+    const cplx *ps[SB_MAX_ND];
+    cplx *p_out;
+    cplx *xvec;
     // XR: the NEXT step's residual update (gcr.hip xr_update_kernel<true, true>) at the end of this launch
     cplx *xr_out;            // where it leaves r - alpha Ap' (the next ring slot)
     cplx *xr_den_slot;
@@ -58,20 +62,21 @@ struct StepBuildArgs {
 };
 
 // step bookkeeping (gcr.hip close_step; kept in step with it by tests/test_gpu_stepbuild.py)
-__device__ __forceinline__ void sb_close_step(DevState *st, int it, double rr, double *hist, int hist_cap) {
+__device__ __forceinline__ void sb_close_step(DevState *st, int it, double rr, double *hist, int hist_cap, bool clear_pending) {
     const int git = st->base + it;
     st->iter = git;
     st->rr = rr;
     if (git < hist_cap) hist[git] = sqrt(rr) / sqrt(st->bnorm2);
     if (!((rr / st->bnorm2) > st->tol2)) st->stop_at = git;
+    if (clear_pending) st->npend = 0;
 }
 
-template <int MODE, int WT, int NDT, bool XR>
+template <int MODE, int WT, int NDT, bool XR, bool CLOSE>
 __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArgs a) {
     __shared__ double lds[(2 * NDT > 4 ? 2 * NDT : 4) * 17];
     __shared__ double lds_pw[2 * SB_MAX_ND * 17], lds_ws[2 * SB_MAX_ND * RES_GRP];
     __shared__ int gave_up;
-    __shared__ cplx sbeta[NDT];
+    __shared__ cplx sbeta[NDT], scp[NDT];
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];   // Ar of this workgroup's rows: [trip][thread]
     if (a.st->stop_at < a.st->base + a.it) return;
     const int lb = logical_workgroup(a.rm, (int)blockIdx.x, (int)gridDim.x);
@@ -134,12 +139,26 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
     if (XR || lb == 0) {
         double rr[1];
         fold_partials<1>(a.partsR, a.nblkR, a.strideR, rr, lds);
-        if (lb == 0 && threadIdx.x == 0) sb_close_step(a.st, a.it, rr[0], a.hist, a.hist_cap);
+        if (lb == 0 && threadIdx.x == 0) sb_close_step(a.st, a.it, rr[0], a.hist, a.hist_cap, CLOSE);
         ends_here = !((rr[0] / a.st->bnorm2) > a.st->tol2);
     }
     if ((int)threadIdx.x < NDT) sbeta[threadIdx.x] = cdiv(make_double2(res_total(sy, 2 * threadIdx.x), res_total(sy, 2 * threadIdx.x + 1)), a.den[threadIdx.x]);
     __syncthreads();
-    if (lb == 0 && (int)threadIdx.x <= NDT) {   // row k = NDT of the coefficient table
+    if constexpr (CLOSE) {   // gcr.hip build_close_kernel: cp_m = sum_{j >= m} beta_j T_jm (cp_0 = sum_j beta_j t_j), in every workgroup
+        if ((int)threadIdx.x < NDT) {
+            const int m = threadIdx.x;
+            const LeanCoef *lc = a.lc;
+            cplx c = make_double2(0., 0.);
+            if (m == 0) {
+                for (int j = 0; j < NDT; j++) c = cadd(c, cmul(sbeta[j], j == 0 ? make_double2(1., 0.) : lc->t[j]));
+            } else {
+                for (int j = m; j < NDT; j++) c = cadd(c, cmul(sbeta[j], j == m ? make_double2(1., 0.) : lc->T[j * LND + m]));
+            }
+            scp[m] = c;
+        }
+        __syncthreads();
+    }
+    if (!CLOSE && lb == 0 && (int)threadIdx.x <= NDT) {   // row k = NDT of the coefficient table
         constexpr int k = NDT;
         const int m = threadIdx.x;
         LeanCoef *lc = a.lc;
@@ -159,6 +178,31 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
     for (int j = 0; j < NDT; j++) beta[j] = to_sgpr(sbeta[j]);
     double v[4] = {0., 0., 0., 0.};
     int trip = 0;
+    if constexpr (CLOSE) {
+        // x += sum_j cx_j p_j;  P0' = dir - sum_j cp_j p_j  (p_0 = P0, p_m = D_m): a pass of its own over the p streams, so that they
+        // and the Ap streams below are never in registers together (64 VGPRs: two workgroups per CU)
+        cplx cp[NDT], cx[NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; j++) {
+            cp[j] = to_sgpr(scp[j]);
+            cx[j] = to_sgpr(a.lc->cx[j]);
+        }
+        for (int64_t i = i0; i < end; i += stride) {
+            cplx pj[NDT];
+#pragma unroll
+            for (int j = 0; j < NDT; j++) pj[j] = ld_stream<NTS>(a.ps[j] + i);
+            const cplx dv = a.x[i];
+            cplx xv = a.xvec[i];
+#pragma unroll
+            for (int j = 0; j < NDT; j++) xv = cadd(xv, cmul(cx[j], pj[j]));
+            a.xvec[i] = xv;
+            cplx pc = make_double2(0., 0.);
+#pragma unroll
+            for (int j = 0; j < NDT; j++) pc = csub(pc, cmul(cp[j], pj[j]));
+            st_stream<NTS>(a.p_out + i, cadd(dv, pc));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int64_t i = i0; i < end; i += stride, trip++) {
         cplx aj[NDT];
 #pragma unroll
@@ -240,7 +284,8 @@ bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim) {
 
 int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cplx *const *aps, int nd, DevState *st, int it, const double *partsR,
                    int nblkR, int strideR, double *hist, int hist_cap, const cplx *den, cplx *ap_out, double *partsA, LeanCoef *lc,
-                   const RowMap &rm, cplx *xr_out, cplx *xr_den_slot, int xr_slot, double *partsR_out) {
+                   const RowMap &rm, cplx *xr_out, cplx *xr_den_slot, int xr_slot, double *partsR_out, const cplx *const *close_ps, cplx *close_p_out,
+                   cplx *close_x) {
     MGCR_CHECK(nd >= 1 && nd <= SB_MAX_ND, MGCR_ERR_INVALID, "csr_step_build: 1..5 directions");
     MGCR_TRY(exchange_shared_init());
     ExchangeShared &sh = exchange_shared();
@@ -255,21 +300,27 @@ int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cpl
     a.st = st; a.it = it; a.partsR = partsR; a.nblkR = nblkR; a.strideR = strideR; a.hist = hist; a.hist_cap = hist_cap;
     a.den = den; a.ap_out = ap_out; a.partsA = partsA; a.lc = lc;
     a.slots = sh.slots; a.abort_dev = sh.abort_dev; a.abort_host = sh.abort_host;
+    for (int j = 0; j < SB_MAX_ND; j++) a.ps[j] = close_ps ? close_ps[j < nd ? j : 0] : nullptr;
+    a.p_out = close_p_out; a.xvec = close_x;
     a.xr_out = xr_out; a.xr_den_slot = xr_den_slot; a.xr_slot = xr_slot; a.partsR_out = partsR_out;
     a.gen0 = exchange_take_generations(3);
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     const unsigned grid = (unsigned)g;
     const size_t lds_bytes = sizeof(cplx) * RED_THREADS * (size_t)((A.nrow + (int64_t)g * RED_THREADS - 1) / ((int64_t)g * RED_THREADS));
-#define SB1(NDT, XRF)                                                                                                              \
+#define SB1(NDT, XRF, CL)                                                                                                          \
     do {                                                                                                                           \
         static bool big_lds = false;   /* 64 KB of dynamic LDS: above the default limit */                                          \
         if (!big_lds) {                                                                                                            \
-            MGCR_HIP(hipFuncSetAttribute((const void *)step_build_kernel<3, 7, NDT, XRF>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            MGCR_HIP(hipFuncSetAttribute((const void *)step_build_kernel<3, 7, NDT, XRF, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
             big_lds = true;                                                                                                        \
         }                                                                                                                          \
-        hipLaunchKernelGGL((step_build_kernel<3, 7, NDT, XRF>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, a);        \
+        hipLaunchKernelGGL((step_build_kernel<3, 7, NDT, XRF, CL>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, a);    \
     } while (0)
-#define SB(NDT) do { if (xr_out) SB1(NDT, true); else SB1(NDT, false); } while (0)
+#define SB(NDT)                                                                    \
+    do {                                                                           \
+        if (close_ps) { if (xr_out) SB1(NDT, true, true); else SB1(NDT, false, true); }   \
+        else { if (xr_out) SB1(NDT, true, false); else SB1(NDT, false, false); }          \
+    } while (0)
     switch (nd) {
         case 1: SB(1); break;
         case 2: SB(2); break;

@@ -39,8 +39,8 @@ def test_step_build_equals_two_kernels_bit_for_bit(n, restart, max_it, dirac):
     xf, hf, itf, nf = _solve(op, dims, p, b, True)
     xc, hc, itc, nc = _solve(op, dims, p, b, False)
     assert nc == 0 and nf > 0, (nf, nc)
-    # every step with at most 5 stored directions that does not close a cycle
-    expect = sum(1 for it in range(1, max_it) if (it % restart) != 0 and min(it % restart, restart) <= 5)
+    # every step but the solve's last that orthogonalises against at most 5 stored directions (the steps that close a cycle included)
+    expect = sum(1 for it in range(1, max_it) if ((it - 1) % restart) + 1 <= 5)
     assert nf == expect, (nf, expect)
     assert itf == itc
     assert np.array_equal(hf, hc)
