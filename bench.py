@@ -236,17 +236,19 @@ def pmc_traffic(key, n, lims=None, restart=0):
         import re
 
         have_step_build = any(name.startswith("step_build_kernel") for name in kern)
-        have_step_build_xr = any(re.match(r"step_build_kernel<.*, true>", name) for name in kern)
+        have_step_build_xr = any(re.match(r"step_build_kernel<\d+, \d+, \d+, true, ", name) for name in kern)
+        have_step_build_close = any(re.match(r"step_build_kernel<.*, true>", name) for name in kern)
 
         def of(l):
             for name, b in kern.items():
                 if key == "xr" and name.startswith("xr_update_kernel"):
                     return b
-                m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false)>", name)
-                if key == "apply_dots" and m and int(m.group(1)) == l and l < restart and have_step_build and (m.group(2) == "true") == have_step_build_xr:
+                m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false), (true|false)>", name)
+                if (key == "apply_dots" and m and int(m.group(1)) == l and (l < restart or m.group(3) == "true") and have_step_build and
+                        (m.group(2) == "true") == have_step_build_xr):
                     return b   # (with the next step's update fused in, the few launches without it — before the solve's last step — are booked like the others)
                 m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
-                if key == "apply_dots" and m and int(m.group(1)) == l and not (l < restart and have_step_build):
+                if key == "apply_dots" and m and int(m.group(1)) == l and not ((l < restart or have_step_build_close) and have_step_build):
                     return b
                 m = re.match(r"build_lean_kernel<(\d+)>", name)
                 if key == "build" and l < restart and m and int(m.group(1)) == l:
@@ -256,6 +258,8 @@ def pmc_traffic(key, n, lims=None, restart=0):
                     return b
             return None
         per = [of(l) for l in lims]
+        if key != "xr" and per:
+            per[-1] = 0.0   # the solve's last iteration launches neither an apply nor a build (gcr_phase_model)
         if all(v is not None for v in per):
             return sum(per) / len(per), note + ", per kernel, weighted by the kernels the timed iterations launched"
     return d["phase_hbm_bytes_per_launch"].get(key), note + ", average over the launches of the profiled run"

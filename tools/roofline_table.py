@@ -31,9 +31,12 @@ for r in rows:
     m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
     if m:
         b = B_spmv + int(m.group(1)) * V            # SpMV + lim direction streams, Ar written once
-    m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false)>", name)
+    m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false), (true|false)>", name)
     if m:
-        b = B_spmv - V + (2 * int(m.group(1)) + 2) * V   # SpMV without the write of Ar; lim streams twice, r re-read, Ap written
+        lim = int(m.group(1))
+        b = B_spmv - V + (2 * lim + 2) * V               # SpMV without the write of Ar; lim streams twice, r re-read, Ap written
+        if m.group(3) == "true":
+            b = B_spmv - V + (3 * lim + 5) * V           # the step that closes a cycle: + lim p streams, x read and written, P0 written
         if m.group(2) == "true":
             b += 2 * V                                   # + the next step's residual update: r read, r' written
     m = re.match(r"build_lean_kernel<(\d+)>", name)
