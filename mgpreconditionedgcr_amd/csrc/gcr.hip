@@ -1352,7 +1352,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
         // apply + dots + build in ONE launch (gcr_stepbuild.hip) where A r of a thread's rows fits LDS: not the step that closes a cycle
         bool step_build = false;
         const bool closes = ic_next == 0;   // (lim == restart then; up to 5 directions the closing step has its one-launch form too)
-        if (fuse_ok && lean && !flex && !multi && !xr_now && rmap.band == 0 && (!closes || stepbuild_close_enabled())) {
+        if (fuse_ok && lean && !flex && !multi && !xr_now && rmap.band == 0 && (!closes || stepbuild_close_enabled()) &&
+            !graphs_enabled()) {   // (a captured cycle would replay the exchange's generation numbers)
             const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
             step_build = csr_step_build_eligible(b0->csr, b0->dist, lim);
         }

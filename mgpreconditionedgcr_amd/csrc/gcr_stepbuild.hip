@@ -59,6 +59,7 @@ struct StepBuildArgs {
     unsigned *abort_dev;
     int *abort_host;
     int spin_limit;
+    int test_stall;          // tests: logical workgroup test_stall - 1 leaves before publishing anything (0: nobody)
 };
 
 // step bookkeeping (gcr.hip close_step; kept in step with it by tests/test_gpu_stepbuild.py)
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
     sy.ws = lds_ws;
     sy.gave_up = &gave_up;
     if (threadIdx.x == 0) gave_up = 0;
+    if (a.test_stall && lb == a.test_stall - 1) return;   // (tests) the others must notice, give up and say so
     int64_t i0, end, stride;
     row_range(a.rm, lb, a.nlogical, a.n, &i0, &end, &stride);
     // ---- apply + dot products (gcr_fused.hip step_apply_kernel) ----
@@ -304,6 +306,7 @@ int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cpl
     a.p_out = close_p_out; a.xvec = close_x;
     a.xr_out = xr_out; a.xr_den_slot = xr_den_slot; a.xr_slot = xr_slot; a.partsR_out = partsR_out;
     a.gen0 = exchange_take_generations(3);
+    a.test_stall = getenv("MGCR_TEST_STEPBUILD_STALL") ? atoi(getenv("MGCR_TEST_STEPBUILD_STALL")) : 0;
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     const unsigned grid = (unsigned)g;
     const size_t lds_bytes = sizeof(cplx) * RED_THREADS * (size_t)((A.nrow + (int64_t)g * RED_THREADS - 1) / ((int64_t)g * RED_THREADS));

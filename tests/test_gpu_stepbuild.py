@@ -65,3 +65,34 @@ def test_step_build_stops_like_the_two_kernels():
     assert nf > 0 and itf == itc and itf < 60
     assert np.array_equal(hf, hc) and np.array_equal(xf, xc)
     assert hf[-1] <= 1e-9
+
+
+def test_step_build_gives_up_instead_of_hanging():
+    """a workgroup that never publishes (told to leave at once) must not leave the other 511 spinning: bounded polls, NaN
+    results, an error at the next host synchronisation.  Child process: the switches are read from the environment once."""
+    import subprocess
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import mgpreconditionedgcr_amd as mg
+from mgpreconditionedgcr_amd import problems
+n = 96
+N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+A = mg.Sparse(N, ncol, rowptr, col, val)
+g = mg.GCR(A, mg.GCR_Param(0, 5, 12, 1e-30, False))
+b = mg.Field((n, n, n)).fill_rhs(0)
+x = mg.Field((n, n, n)).set_zero()
+try:
+    g.solve(b, x)
+    mg.lib().mgcr_synchronize()
+    print("NO-ERROR" if mg.lib().mgcr_synchronize() == 0 and np.isfinite(g.last_history).all() else "ERROR: history not finite")
+except mg.MgcrError as e:
+    print("ERROR:", e)
+print("HISTORY-NAN" if not np.isfinite(g.last_history).all() else "HISTORY-FINITE")
+'''
+    env = dict(os.environ, MGCR_TEST_STEPBUILD_STALL="7", MGCR_TEST_RESIDENT_SPIN_LIMIT="20000")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180,
+                         cwd=os.path.join(os.path.dirname(__file__), ".."))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ERROR:" in out.stdout, out.stdout
