@@ -3,7 +3,8 @@
 //
 //   * x, r and the stored directions live in HBM for the whole solve; p and Ap are not separate
 //     vectors but the ring slot that was written last (the reference copies them, :286-287);
-//   * per iteration three kernels instead of ~90 vector passes:
+//   * per iteration three kernels instead of ~90 vector passes — one launch per iteration where A r fits
+//     the chip's LDS (gcr_stepbuild.hip), one launch per solve for small systems (gcr_resident.hip):
 //        xr_update   x += a p, r -= a Ap, |r|^2 partials                         6 V  (3 V when the
 //                    x update is deferred to the end of the restart cycle, see xr_update_kernel)
 //        apply+dots  Ar = A r and the <Ar, Aps[i]> partials for all stored i      B_matrix + (2+lim) V
