@@ -126,6 +126,17 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
             __builtin_amdgcn_raw_buffer_store_b128(w4, sy.slots, ((1 * RES_NV + (int)threadIdx.x) * RES_BLK + lb) * 16, 0, RES_SC1);
         }
     }
+    // the first trip's streams of the build are requested BEFORE the exchange is waited for (they do not depend on beta): one
+    // memory round trip of the launch hides behind the polls
+    // (up to 3 stored directions: with more the kernel does not keep them next to everything else in 64 registers)
+    constexpr bool PRE = NDT <= 3;
+    cplx pre[NDT];
+#pragma unroll
+    for (int j = 0; j < NDT; j++) pre[j] = make_double2(0., 0.);
+    if (PRE && i0 < end) {
+#pragma unroll
+        for (int j = 0; j < NDT; j++) pre[j] = ld_stream<NTS>((CLOSE ? a.ps[j] : a.aps[j]) + i0);
+    }
     const bool ok = res_collect<2 * NDT>(sy, 1);
     if (!ok) {   // somebody is missing: leave, with results nobody can mistake for numbers
         if (threadIdx.x == 0) {
@@ -192,7 +203,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
         for (int64_t i = i0; i < end; i += stride) {
             cplx pj[NDT];
 #pragma unroll
-            for (int j = 0; j < NDT; j++) pj[j] = ld_stream<NTS>(a.ps[j] + i);
+            for (int j = 0; j < NDT; j++) pj[j] = (PRE && i == i0) ? pre[j] : ld_stream<NTS>(a.ps[j] + i);
             const cplx dv = a.x[i];
             cplx xv = a.xvec[i];
 #pragma unroll
@@ -208,7 +219,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
     for (int64_t i = i0; i < end; i += stride, trip++) {
         cplx aj[NDT];
 #pragma unroll
-        for (int j = 0; j < NDT; j++) aj[j] = ld_stream<NTS>(a.aps[j] + i);
+        for (int j = 0; j < NDT; j++) aj[j] = (PRE && !CLOSE && i == i0) ? pre[j] : ld_stream<NTS>(a.aps[j] + i);
         const cplx av = arL[trip * RED_THREADS + (int)threadIdx.x], rv = a.x[i];
         cplx ac = make_double2(0., 0.);
 #pragma unroll
@@ -230,6 +241,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
             const v4i w4 = {__double2loint(mine), __double2hiint(mine), (int)sy.gen, 0};
             __builtin_amdgcn_raw_buffer_store_b128(w4, sy.slots, ((2 * RES_NV + (int)threadIdx.x) * RES_BLK + lb) * 16, 0, RES_SC1);
         }
+        const cplx xr0 = i0 < end ? a.x[i0] : make_double2(0., 0.);   // (requested before the polls, like `pre` above)
         if (!res_collect<4>(sy, 2)) {
             if (threadIdx.x == 0) {
                 __hip_atomic_store(a.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -250,7 +262,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
         double vr[1] = {0.};
         trip = 0;
         for (int64_t i = i0; i < end; i += stride, trip++) {
-            const cplx rn = csub(a.x[i], cmul(alpha, arL[trip * RED_THREADS + (int)threadIdx.x]));
+            const cplx rn = csub(i == i0 ? xr0 : a.x[i], cmul(alpha, arL[trip * RED_THREADS + (int)threadIdx.x]));
             a.xr_out[i] = rn;
             vr[0] += rn.x * rn.x + rn.y * rn.y;
         }
