@@ -381,7 +381,7 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
         return one and lims[idx] <= 5 and (lims[idx] < R or fused == 4) and idx < nl - 1
 
     def update_prefetched(idx):     # ... and its residual update already ran at the end of the previous iteration's launch (fused >= 3)
-        return fused >= 3 and idx >= 1 and one_launch(idx - 1) and idx < nl - 1
+        return fused >= 3 and idx >= 1 and one_launch(idx - 1)
 
     def apply_bytes(idx):
         l = lims[idx]

@@ -1366,7 +1366,8 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             // ... and, unless the next step is the solve's last (whose update takes other kernels), that step's residual update too:
             // r and the new Ap of a thread's rows are on the chip, alpha costs one more exchange instead of a launch
             cplx *xr_out = nullptr;
-            if (global + 1 < max_it && stepbuild_xr_enabled()) {
+            const bool next_is_special_last = global + 1 == max_it && nested && (s->defer_residual || s->discard_residual);
+            if (global + 1 <= max_it && !next_is_special_last && stepbuild_xr_enabled()) {
                 const int ic2 = ((ic_next + 1) % s->restart == 0) ? 0 : ic_next + 1;
                 const int nxt2 = ic2 % s->storage;
                 MGCR_TRY(ensure_slot(s, nxt2));
@@ -1542,6 +1543,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);
     if (multi) MGCR_TRY(comm_check(comm));   // a peer-write wait that timed out poisoned the scalars with NaN
+    MGCR_TRY(resident_check());              // a one-launch step (gcr_stepbuild.hip) that was not co-resident gave up
     return frc;
 }
 

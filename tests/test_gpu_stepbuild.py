@@ -84,15 +84,15 @@ g = mg.GCR(A, mg.GCR_Param(0, 5, 12, 1e-30, False))
 b = mg.Field((n, n, n)).fill_rhs(0)
 x = mg.Field((n, n, n)).set_zero()
 try:
-    g.solve(b, x)
-    mg.lib().mgcr_synchronize()
-    print("NO-ERROR" if mg.lib().mgcr_synchronize() == 0 and np.isfinite(g.last_history).all() else "ERROR: history not finite")
+    g.solve(b, x)          # the solve itself reports it (gcr_run ends with the check)
+    print("NO-ERROR")
 except mg.MgcrError as e:
     print("ERROR:", e)
-print("HISTORY-NAN" if not np.isfinite(g.last_history).all() else "HISTORY-FINITE")
+print("LIBRARY-USABLE" if mg.lib().mgcr_synchronize() == 0 else "STILL-FAILING")
 '''
     env = dict(os.environ, MGCR_TEST_STEPBUILD_STALL="7", MGCR_TEST_RESIDENT_SPIN_LIMIT="20000")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180,
                          cwd=os.path.join(os.path.dirname(__file__), ".."))
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "ERROR:" in out.stdout, out.stdout
+    assert "ERROR:" in out.stdout and "co-resident" in out.stdout, out.stdout
+    assert "LIBRARY-USABLE" in out.stdout, out.stdout
