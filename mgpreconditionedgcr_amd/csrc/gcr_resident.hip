@@ -630,7 +630,11 @@ int resident_check() {
     if (s.abort_host && *(volatile int *)s.abort_host != 0) {
         *(volatile int *)s.abort_host = 0;
         hipMemsetAsync(s.abort_dev, 0, sizeof(unsigned), ctx().stream);
-        set_error("one-launch solver kernel: a workgroup waited too long for the others (the launch was not co-resident); its results were poisoned with NaN");
+        // whatever kept the launch from being co-resident may still be there: this process stays with the multi-kernel paths
+        set_resident_enabled(false);
+        set_stepbuild_enabled(false);
+        set_error("one-launch solver kernel: a workgroup waited too long for the others (the launch was not co-resident); its results were "
+                  "poisoned with NaN.  The one-launch paths are now off in this process: solve again");
         return MGCR_ERR_HIP;
     }
     return MGCR_OK;
