@@ -1,19 +1,26 @@
-// Apply + dot products + direction build of a lean GCR step as ONE launch (src/GCR.h:242-287), for systems whose A r fits
-// the chip's LDS: at most 4096 rows per workgroup of 1024 threads, two workgroups per CU — 2 097 152 rows on MI355X, i.e.
-// up to Poisson 128^3, the metric's configuration.
+// A lean GCR step as ONE launch (src/GCR.h:230-287), for systems whose A r fits the chip's LDS: at most 4096 rows per
+// workgroup of 1024 threads, two workgroups per CU — 2 097 152 rows on MI355X, i.e. up to Poisson 128^3, the metric's
+// configuration.
 //
 // gcr_fused.hip's step_apply_kernel writes Ar (V), its partial sums of <Ar, Ap_j> go to memory, and gcr.hip's
-// build_lean_kernel — behind a kernel boundary, because beta needs the sums over ALL workgroups — reads Ar back (V).
-// Here the two kernel bodies run in one launch with exchange_dev.h's fence-free exchange (~3 us) in between: a thread
-// keeps the Ar of its 4 rows in LDS (64 KB per workgroup, thread-private slots), so Ar is neither written to nor read
-// from memory: 2 V of the iteration's 15.6 V, one kernel boundary and one fold less.  Everything else is the two
-// kernels' code: the same rows per thread (RowMap), the same per-thread accumulation order, the same fold tree — the
-// same bits (tests/test_gpu_stepbuild.py compares with the two-kernel path bit for bit).
+// build_lean_kernel — behind a kernel boundary, because beta needs the sums over ALL workgroups — reads Ar back (V);
+// xr_update_kernel, behind another boundary because alpha needs <r,Ap'> and <Ap',Ap'>, reads r and the new Ap' back.
+// Here the kernel bodies run in one launch with exchange_dev.h's fence-free exchange (~3 us) where the boundaries were:
+//   apply + dots | exchange | direction build (CLOSE: the cycle-closing form, gcr.hip build_close_kernel: x update and the
+//   next cycle's first direction in a pass of their own) | exchange | XR: the NEXT step's residual update.
+// A thread keeps the Ar of its 4 rows in LDS (64 KB per workgroup, thread-private slots) and overwrites it with the new
+// Ap' for the update: Ar is neither written to nor read from memory, Ap' is not read back — per in-cycle step
+// B_matrix + 16 ncol + (2 lim + 4) V instead of B_matrix + 16 ncol + (2 lim + 7) V, two kernel boundaries and two folds
+// less.  The first trip's streams of the build and the update's first r are requested before an exchange is polled.
+// Everything else is the kernels' code: the same rows per thread (RowMap), the same per-thread accumulation order, the
+// same fold tree — the same bits (tests/test_gpu_stepbuild.py compares with the three-kernel path bit for bit).
 //
 // Needs all workgroups co-resident (they wait for each other): 64 VGPRs and <= 80 KB of LDS each, at most 2 x #CU
-// workgroups, no other process on the device (no live communicator).  Up to 5 stored directions (beyond that the two
+// workgroups, no other process on the device (no live communicator).  Up to 5 stored directions (beyond that the
 // kernels need 128 registers: one workgroup per CU).  Bounded polls as in gcr_resident.hip: a missing workgroup makes the
-// others leave with NaN results and an error at the next host synchronisation.
+// others leave with NaN results, the solve returns an error and the one-launch paths switch themselves off.
+// The host (gcr.hip gcr_run) knows which launch already performed the next update (xr_prefetched); a solve that stops
+// on the device turns the whole launch, or its update part, into a no-op like any other kernel of the solve.
 #include <climits>
 #include <cstdlib>
 
