@@ -100,3 +100,37 @@ print("RETRY-OK" if np.isfinite(x.to_numpy()).all() and g.last_iterations == 12 
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ERROR:" in out.stdout and "co-resident" in out.stdout, out.stdout
     assert "LIBRARY-USABLE" in out.stdout and "RETRY-OK" in out.stdout, out.stdout
+
+
+def test_vcycle_with_one_launch_smoother_steps_is_bit_identical():
+    """inside a V-cycle at 128^3 the level-0 smoothers (2 sweeps: the first one an in-cycle step, the second the solve's last,
+    with the V-cycle's deferred-residual / pending-x hand-overs) and the flexible outer solve: same cycle output and same outer
+    history with the one-launch steps on and off"""
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import problems
+    n = 128
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    dims = (n, n, n)
+    out = []
+    for on in (1, 0):
+        prev = mg.set_option("step_build", on)
+        try:
+            A = mg.Sparse(N, ncol, rowptr, col, val)
+            prm = mg.MG_Param(mg.Mesh(dims), 2, 1, None, mg.GCR(mg.GCR_Param(0, 10, 50, 1e-2, False)),
+                              mg.GCR(mg.GCR_Param(0, 10, 2, 1e-30, False)), 2, None, None, null_vectors=np.ones((1, N), np.complex128))
+            M = mg.MG(A, prm)
+            b = mg.Field(dims).fill_rhs(4)
+            before = mg.stat("step_build_launches")
+            y = M(b).to_numpy()
+            took = mg.stat("step_build_launches") - before
+            outer = mg.GCR(A, mg.GCR_Param(0, 5, 30, 1e-8, False, None, M, flexible=True))
+            x = mg.Field(dims).set_zero()
+            outer.solve(b, x)
+            out.append((took, y, outer.last_history.copy(), x.to_numpy()))
+            del M, A
+        finally:
+            mg.set_option("step_build", prev)
+    assert out[0][0] >= 2 and out[1][0] == 0
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    assert out[0][2][-1] <= 1e-8
