@@ -659,13 +659,25 @@ int csr_build_device(int64_t nrow, int64_t ncol, const int64_t *h_rowptr, const 
 // ------------------------------------------------------------------------------------------------
 // SpMV
 // ------------------------------------------------------------------------------------------------
+// has the solve this apply belongs to stopped on the device?  (skip = {stop_at, base}, gcr.hip DevState; null: stand-alone apply.)
+// Read through the constant address space: scalar loads wherever the call stands.
+__device__ __forceinline__ bool stop_flag(const int *skip, int skip_it) {
+    typedef const int __attribute__((address_space(4))) *stop_ptr;
+    const stop_ptr sk = (stop_ptr)(uintptr_t)skip;
+    return skip && sk[0] < sk[1] + skip_it;
+}
+
 template <int WT, bool SHIFT, bool XCD, bool REALV, bool NT>
 __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int64_t row_count, int64_t npad, int32_t Wrt,
                                                           int64_t ntiles, const void *__restrict__ val,
                                                           const int32_t *__restrict__ col, const cplx *__restrict__ x,
                                                           const cplx *__restrict__ xh, int32_t n_own,
                                                           cplx *__restrict__ y, cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
-    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
+    // One scalar batch for every argument (pinned by the empty asm) instead of one dependent fetch per early exit: a wave
+    // lives a few microseconds and each dependent scalar round trip in front of its first load costs ~0.2 us of that.  The
+    // solver's stop flag (skip = {stop_at, base}: see gcr.hip DevState) is looked at while the loads fly and only gates the store.
+    asm volatile("" ::"s"(row_begin), "s"(row_count), "s"(npad), "s"(Wrt), "s"(ntiles), "s"(val), "s"(col), "s"(x), "s"(xh), "s"(n_own), "s"(y),
+                 "s"(w), "s"(skip), "s"(skip_it));
     int64_t tile = XCD ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
     int64_t rloc = tile * 256 + threadIdx.x;
@@ -673,23 +685,26 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
     int64_t row = row_begin + rloc;
     const int32_t W = WT ? WT : Wrt;
     cplx sum = make_double2(0., 0.);
+    bool stopped = false;
     if (WT) {
         int32_t j[WT ? WT : 1];
         cplx xv[WT ? WT : 1];
 #pragma unroll
         for (int32_t c = 0; c < W; c++) j[c] = ldcol<NT>(col + (int64_t)c * npad + row);
+        stopped = stop_flag(skip, skip_it);
 #pragma unroll
         for (int32_t c = 0; c < W; c++) xv[c] = gather_x(x, xh, n_own, j[c]);
 #pragma unroll
         for (int32_t c = 0; c < W; c++) sum = cadd(sum, vmul<REALV, NT>(val, (int64_t)c * npad + row, xv[c]));
     } else {
+        stopped = stop_flag(skip, skip_it);
 #pragma unroll 4
         for (int32_t c = 0; c < W; c++) {
             int32_t j = ldcol<NT>(col + (int64_t)c * npad + row);
             sum = cadd(sum, vmul<REALV, NT>(val, (int64_t)c * npad + row, gather_x(x, xh, n_own, j)));
         }
     }
-    y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
+    if (!stopped) y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
 }
 
 // Row-pattern dictionary SpMV (L = 1): one thread per row; the row's 2-byte id selects the table row
@@ -832,61 +847,93 @@ __global__ void __launch_bounds__(BLK) sten_spmv(RowMat m, int64_t row_begin, in
 // parameter (the kernel exists for the mask of a 3-D stencil, slots 1..5 of 7): with a run-time mask the compiler keeps
 // the gathered values in scratch memory and waits for every load in turn — 4x slower than no window at all.
 template <int NS, bool RARE, bool SHIFT, int BLK, unsigned NEAR>
-__global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int32_t H, int64_t row_begin, int64_t row_end, int64_t first, int64_t ntiles, int xcd,
+__global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begin, int64_t row_end, int64_t first, int64_t ntiles, int xcd,
                                                       const cplx *__restrict__ x, cplx *__restrict__ y, const cplx *__restrict__ w,
                                                       const int *__restrict__ skip, int skip_it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sten_smem[];
     constexpr int NC = RARE ? STEN_COMMON : NS;   // rare-tail layout: slots NC.. are looked at after the common sum
-    if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
+    // A wave of this kernel lives ~3 us and every DEPENDENT scalar fetch in front of its gathers costs ~0.2 us of that (measured:
+    // one kernel argument fetched late = +6 % kernel time).  So: every argument the gathers need is fetched in ONE batch (the
+    // empty asm pins them), the gathers go out, and only then come the scalar loads from memory — presence words, the solver's
+    // stop flag (skip = {stop_at, base}, gcr.hip DevState), whose answers nobody needs before the window is filled.
+    const int32_t H = m.sten_halo, last = m.sten_last, n_own = m.n_own, nwaves = m.sten_nwaves, pstride = m.sten_stride;
+    const cplx *const xh = m.xh;
+    const uint64_t *const planes = m.sten_planes;
+    int32_t off[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) off[c] = m.sten_off[c];
+    asm volatile("" ::"s"(H), "s"(last), "s"(n_own), "s"(nwaves), "s"(pstride), "s"(xh), "s"(planes), "s"(x), "s"(first), "s"(ntiles), "s"(xcd),
+                 "s"(row_begin), "s"(row_end), "s"(skip), "s"(skip_it), "s"(y));
+    const int realv = m.realv;
+    double re[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        re[c] = m.sten_re[c];
+        asm volatile("" ::"s"(off[c]), "s"(re[c]));
+    }
+    asm volatile("" ::"s"(realv));
     const int64_t tile = xcd ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
     cplx *sx = reinterpret_cast<cplx *>(sten_smem);   // [H + BLK + H], entry e = column base - H + e
     const int64_t base = first + tile * BLK;
     const int64_t rloc = base + threadIdx.x;
     const bool live = rloc >= row_begin && rloc < row_end;
-    // presence words of this wave (rows beyond the padded end of the matrix have none: the planes array ends with a zero row)
-    int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
-    wave = wave < m.sten_nwaves ? wave : m.sten_nwaves;
-    const sten_planes_ptr pp = sten_wave_planes(m, wave);
-    uint64_t pl[NS];
-#pragma unroll
-    for (int c = 0; c < NS; c++) pl[c] = pp[c];
-    auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
+    auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > last ? last : j); };
     cplx xv[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         xv[c] = make_double2(0., 0.);
-        if (!(NEAR >> c & 1u)) xv[c] = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
+        if (!(NEAR >> c & 1u)) xv[c] = gather_x(x, xh, n_own, clampj(rloc + off[c]));
     }
-    const cplx own = gather_x(x, m.xh, m.n_own, clampj(rloc));
+    const cplx own = gather_x(x, xh, n_own, clampj(rloc));
     cplx halo = make_double2(0., 0.);
     int hidx = -1;
     if ((int)threadIdx.x < 2 * H) {
         const int t = (int)threadIdx.x;
-        halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + BLK + (t - H)));
+        halo = gather_x(x, xh, n_own, clampj(t < H ? base - H + t : base + BLK + (t - H)));
         hidx = t < H ? t : BLK + t;
     }
+    __builtin_amdgcn_sched_barrier(0);   // every gather is in flight before anything else is asked for
+    // presence words of this wave (rows beyond the padded end of the matrix have none: the planes array ends with a zero row)
+    int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(rloc >> 6));
+    wave = wave < nwaves ? wave : nwaves;
+    const sten_planes_ptr pp = (sten_planes_ptr)(uintptr_t)(planes + (int64_t)wave * pstride);
+    uint64_t pl[NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) pl[c] = pp[c];
+    const bool stopped = stop_flag(skip, skip_it);
     __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first one is waited for
     sx[H + threadIdx.x] = own;
     if (hidx >= 0) sx[hidx] = halo;
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63);
     cplx sum = make_double2(0., 0.);
+    // (the real / complex decision once, not per slot: per slot it put a scalar fetch and a branch between every two terms)
+    if (realv) {
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        // a window entry outside the matrix is a clamped copy: only read by rows whose presence bit for the slot is clear
-        const cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : xv[c];
-        const bool on = (pl[c] >> lane & 1ull) != 0ull;
-        const cplx t = m.realv ? make_double2(m.sten_re[c] * v.x, m.sten_re[c] * v.y) : cmul(make_double2(m.sten_re[c], m.sten_im[c]), v);
-        const cplx nsum = cadd(sum, t);
-        sum.x = on ? nsum.x : sum.x;
-        sum.y = on ? nsum.y : sum.y;
+        for (int c = 0; c < NC; c++) {
+            // a window entry outside the matrix is a clamped copy: only read by rows whose presence bit for the slot is clear
+            const cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + off[c]] : xv[c];
+            const bool on = (pl[c] >> lane & 1ull) != 0ull;
+            const cplx nsum = cadd(sum, make_double2(re[c] * v.x, re[c] * v.y));
+            sum.x = on ? nsum.x : sum.x;
+            sum.y = on ? nsum.y : sum.y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const cplx v = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + off[c]] : xv[c];
+            const bool on = (pl[c] >> lane & 1ull) != 0ull;
+            const cplx nsum = cadd(sum, cmul(make_double2(re[c], m.sten_im[c]), v));
+            sum.x = on ? nsum.x : sum.x;
+            sum.y = on ? nsum.y : sum.y;
+        }
     }
     if (RARE) {
 #pragma unroll
         for (int c = NC; c < NS; c++)
             if (pl[c] != 0ull) {   // wave-uniform: a wave of a boundary plane
-                const cplx xr = gather_x(x, m.xh, m.n_own, clampj(rloc + m.sten_off[c]));
+                const cplx xr = gather_x(x, xh, n_own, clampj(rloc + m.sten_off[c]));
                 const bool on = (pl[c] >> lane & 1ull) != 0ull;
                 const cplx t = m.realv ? make_double2(m.sten_re[c] * xr.x, m.sten_re[c] * xr.y) : cmul(make_double2(m.sten_re[c], m.sten_im[c]), xr);
                 const cplx nsum = cadd(sum, t);
@@ -894,7 +941,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int32_t H, int64
                 sum.y = on ? nsum.y : sum.y;
             }
     }
-    if (live) y[rloc] = SHIFT ? csub((w ? w : x)[rloc], cmul(m.k, sum)) : sum;
+    if (live && !stopped) y[rloc] = SHIFT ? csub((w ? w : x)[rloc], cmul(m.k, sum)) : sum;
 }
 
 // L in {2,4,8,16}: L consecutive lanes share a row; per chunk the (row, lane) pairs are contiguous
@@ -975,8 +1022,11 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     hipLaunchKernelGGL((sten_spmv<NS, RARE, SHIFT, STEN_TILE>), dim3(grid), dim3(STEN_TILE), 0, c.stream, m, row_begin, row_begin + row_count, \
                        first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
 #define SLT(NS, RARE, BLK, HH)                                                                                            \
-    hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * (HH)) * sizeof(cplx), \
-                       c.stream, m, (int32_t)(HH), row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
+    do {                                                                                                                  \
+        m.sten_halo = (HH);                                                                                               \
+        hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * (HH)) * sizeof(cplx), \
+                           c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it); \
+    } while (0)
         if (big) {
             if (A.sten_rare) SLT(9, true, RED_THREADS, A.sten_halo_f);
             else if (sten_slots(A) == 7) SLT(7, false, RED_THREADS, A.sten_halo_f);
