@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m,
 // and Ap_0 the row's result.  Same launch shape and row map as step_apply_kernel; while that map is the plain
 // grid-stride (gcr_dev.h: everything below 256^3) the sums have the order, hence the bits, of those two kernels.
 template <int MODE, int WT>
-__global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+__global__ void __launch_bounds__(RED_THREADS, ((MODE == 3 && WT <= 7) || MODE == 4 || MODE == 1 ? 8 : 4)) init_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                     const cplx *__restrict__ b, int64_t n, int nlogical, RowMap rm,
                                                                     double *__restrict__ partsA, double *__restrict__ partsR,
                                                                     double *__restrict__ partsN, const int *__restrict__ skip, int skip_it) {
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(RED_THREADS, 4) init_apply_kernel(RowMat m, co
 
 // init_apply_kernel with the LDS window of step_apply_tile_kernel (same conditions, same bits)
 template <int NS, bool RARE>
-__global__ void __launch_bounds__(RED_THREADS, 4) init_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+__global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                          const cplx *__restrict__ b, int64_t n, int nlogical, RowMap rm,
                                                                          double *__restrict__ partsA, double *__restrict__ partsR,
                                                                          double *__restrict__ partsN, const int *__restrict__ skip, int skip_it) {
