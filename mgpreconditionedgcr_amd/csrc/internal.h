@@ -120,6 +120,7 @@ struct BcsrDev {
     int32_t nbrow = 0, nbcol = 0, bs = 0, nblocks = 0;
     int32_t *browptr = nullptr, *bcol = nullptr;
     cplx *blocks = nullptr;  // [nblocks][bs][bs] row-major
+    int32_t *order = nullptr;  // block rows by falling block count: the order the wave kernels are dealt them (null: as stored)
 };
 
 struct GcrState;

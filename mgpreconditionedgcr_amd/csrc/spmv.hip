@@ -1173,11 +1173,11 @@ int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistC
 __global__ void __launch_bounds__(64) bcsr_wave_kernel(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
                                                        const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
                                                        const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t nb_own,
-                                                       cplx *__restrict__ y, const int *__restrict__ skip, int skip_it) {
+                                                       cplx *__restrict__ y, const int *__restrict__ skip, int skip_it, const int32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
-    const int32_t brow = blockIdx.x;
+    const int32_t brow = order ? order[blockIdx.x] : (int32_t)blockIdx.x;   // longest block rows first (bcsr_build_device)
     const int lane = threadIdx.x;
     const int32_t bs2 = bs * bs, ld = bs + 1;
     const int32_t beg = browptr[brow], end = browptr[brow + 1];
@@ -1219,11 +1219,11 @@ template <int TT, bool PREFETCH>
 __global__ void __launch_bounds__(64) bcsr_wave_kernel_t(int32_t nbrow, int32_t bs, const int32_t *__restrict__ browptr,
                                                          const int32_t *__restrict__ bcol, const cplx *__restrict__ blocks,
                                                          const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t nb_own,
-                                                         cplx *__restrict__ y, const int *__restrict__ skip, int skip_it) {
+                                                         cplx *__restrict__ y, const int *__restrict__ skip, int skip_it, const int32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx *prod = reinterpret_cast<cplx *>(smem_raw);  // [bs][bs+1]
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
-    const int32_t brow = blockIdx.x;
+    const int32_t brow = order ? order[blockIdx.x] : (int32_t)blockIdx.x;   // longest block rows first (bcsr_build_device)
     const int lane = threadIdx.x;
     const int32_t bs2 = bs * bs, ld = bs + 1;
     const int32_t beg = browptr[brow], end = browptr[brow + 1];
@@ -1274,7 +1274,7 @@ __global__ void __launch_bounds__(64) bcsr_wave_kernel_t(int32_t nbrow, int32_t 
 }
 
 void bcsr_free(BcsrDev *b) {
-    hipFree(b->browptr); hipFree(b->bcol); hipFree(b->blocks);
+    hipFree(b->browptr); hipFree(b->bcol); hipFree(b->blocks); hipFree(b->order);
     *b = BcsrDev();
 }
 
@@ -1291,6 +1291,25 @@ int bcsr_build_device(int32_t nbrow, int32_t nbcol, int32_t bs, const int32_t *h
     MGCR_TRY(dev_upload(&B.browptr, h_browptr, (size_t)nbrow + 1));
     MGCR_TRY(dev_upload(&B.bcol, h_bcol, (size_t)nb));
     MGCR_TRY(dev_upload(&B.blocks, (const cplx *)h_blocks, (size_t)nb * bs * bs));
+    // One wave per block row, rows of 5 .. 64 blocks: dealt in stored order, the rows that happen to come last decide when the
+    // kernel ends (a 64-block row started near the end runs almost alone).  Longest rows first (stable: equal counts keep
+    // their order) — each row is still summed by one wave in its own order, so the result does not change by a bit.
+    static const bool lpt_on = !(getenv("MGCR_BCSR_ORDER") && atoi(getenv("MGCR_BCSR_ORDER")) == 0);
+    if (lpt_on && nbrow >= 1024) {
+        int32_t cmin = INT32_MAX, cmax = 0;
+        for (int32_t r = 0; r < nbrow; r++) {
+            const int32_t c = h_browptr[r + 1] - h_browptr[r];
+            cmin = std::min(cmin, c); cmax = std::max(cmax, c);
+        }
+        if (cmax > cmin) {
+            std::vector<int32_t> order((size_t)nbrow);
+            for (int32_t r = 0; r < nbrow; r++) order[(size_t)r] = r;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+                return h_browptr[a + 1] - h_browptr[a] > h_browptr[b + 1] - h_browptr[b];
+            });
+            MGCR_TRY(dev_upload(&B.order, order.data(), (size_t)nbrow));
+        }
+    }
     MGCR_HIP(hipStreamSynchronize(ctx().stream));
     *out = B;
     return MGCR_OK;
@@ -1309,10 +1328,10 @@ int bcsr_apply(const BcsrDev &A, const cplx *x, cplx *y, const cplx *xh, int32_t
     const int tt = (A.bs * A.bs + 63) / 64;
 #define BT(T_)                                                                                                              \
     hipLaunchKernelGGL((bcsr_wave_kernel_t<T_, false>), dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr, \
-                       A.bcol, A.blocks, x, xh, nb_own, y, g_skip.p, g_skip.it)
+                       A.bcol, A.blocks, x, xh, nb_own, y, g_skip.p, g_skip.it, A.order)
     if (A.bs > 64 || tt > 16)  // rows beyond lane 63 / too many registers: generic kernel
         hipLaunchKernelGGL(bcsr_wave_kernel, dim3((unsigned)A.nbrow), dim3(64), lds, ctx().stream, A.nbrow, A.bs, A.browptr,
-                           A.bcol, A.blocks, x, xh, nb_own, y, g_skip.p, g_skip.it);
+                           A.bcol, A.blocks, x, xh, nb_own, y, g_skip.p, g_skip.it, A.order);
     else if (tt <= 1) BT(1);
     else if (tt <= 2) BT(2);
     else if (tt <= 4) BT(4);

@@ -335,6 +335,28 @@ def test_block_csr_vs_oracle(bs, nb):
     assert np.array_equal(y, ref)
 
 
+@pytest.mark.parametrize("bs,nb", [(9, 41), (12, 41), (16, 41), (18, 41), (20, 41), (23, 41), (27, 41), (32, 41), (4, 1500), (7, 1100)])
+def test_block_csr_more_shapes_vs_oracle(bs, nb):
+    """Block sizes with 2 .. 16 loads of 64 entries per block, block rows with 0, 1 and up to 12 blocks, duplicates; and, from
+    1024 block rows on, the wave kernels are dealt the rows longest first (spmv.hip bcsr_build_device): every row is still
+    summed by one wave in its stored order — the bits of the oracle (src/HierarchicalSparse.h:101-161)."""
+    rng = np.random.default_rng(1000 + bs)
+    rows, cols = [], []
+    for r in range(nb):
+        k = 0 if r % 7 == 3 else 1 if r % 7 == 5 else int(rng.integers(2, 13))
+        cs = rng.choice(nb, size=k, replace=True)
+        rows += [r] * k
+        cols += list(cs)
+    perm = rng.permutation(len(rows))
+    rows, cols = np.array(rows, np.int32)[perm], np.array(cols, np.int32)[perm]
+    blocks = rng.uniform(-1, 1, (rows.size, bs, bs)) + 1j * rng.uniform(-1, 1, (rows.size, bs, bs))
+    x = problems.rhs_grid(nb * bs, 7)
+    H = HierarchicalSparse(nb, nb, rows, cols, blocks)
+    ref = orc.bcsr_from_triplets(nb, nb, bs, rows, cols, blocks)(x)
+    xf = Field((nb * bs,), x)
+    assert np.array_equal(H(xf).to_numpy(), ref)
+
+
 @pytest.mark.parametrize("nrow,ncol,kw", [
     (1, 1, dict(min_len=1, max_len=1)),
     (257, 300, dict(min_len=0, max_len=9)),             # empty rows, ragged
