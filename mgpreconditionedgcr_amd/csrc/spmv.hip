@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv(RowMat m, int64_t row_begin, in
 // the expensive ones), 128^3: 20.4 against 21.9 us.  Same slot order, same selects: same bits.  NEAR is a template
 // parameter (the kernel exists for the mask of a 3-D stencil, slots 1..5 of 7): with a run-time mask the compiler keeps
 // the gathered values in scratch memory and waits for every load in turn — 4x slower than no window at all.
-template <int NS, bool RARE, bool SHIFT, int BLK, unsigned NEAR>
+template <int NS, bool RARE, bool SHIFT, int BLK, unsigned NEAR, bool DMA>
 __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begin, int64_t row_end, int64_t first, int64_t ntiles, int xcd,
                                                       const cplx *__restrict__ x, cplx *__restrict__ y, const cplx *__restrict__ w,
                                                       const int *__restrict__ skip, int skip_it) {
@@ -885,13 +885,32 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
         xv[c] = make_double2(0., 0.);
         if (!(NEAR >> c & 1u)) xv[c] = gather_x(x, xh, n_own, clampj(rloc + off[c]));
     }
-    const cplx own = gather_x(x, xh, n_own, clampj(rloc));
-    cplx halo = make_double2(0., 0.);
+    cplx own = make_double2(0., 0.), halo = make_double2(0., 0.);
     int hidx = -1;
-    if ((int)threadIdx.x < 2 * H) {
-        const int t = (int)threadIdx.x;
-        halo = gather_x(x, xh, n_own, clampj(t < H ? base - H + t : base + BLK + (t - H)));
-        hidx = t < H ? t : BLK + t;
+    if constexpr (DMA) {
+        // the window is filled by the memory system itself (gfx950 global_load_lds_dwordx4: 16 bytes per lane, a wave's 64 entries
+        // land contiguously at the LDS address in M0): no registers, no ds_write between the data's arrival and the barrier —
+        // 14.6-15.0 -> 14.3 us back to back at 128^3, 127-128 -> 122-123 us at 256^3 (cold: 22.0-22.6 -> 21.4, 131-132 -> 125-127).
+        // (H is a multiple of 64 here: a wave of halo threads lies entirely left or entirely right of the tile.  The same fill in
+        // the solver's windowed step kernels, gcr_fused.hip, LOSES 2 %: they need the row's own entry in registers afterwards
+        // and the per-lane addresses cost what the data registers saved — measured, not kept.)
+        const int wv = (int)(threadIdx.x >> 6) * 64;
+        const int32_t jo = clampj(rloc);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(jo < n_own ? x + jo : xh + (jo - n_own)),
+                                         (__attribute__((address_space(3))) void *)(sx + H + wv), 16, 0, 0);
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            const int32_t jh = clampj(t < H ? base - H + t : base + BLK + (t - H));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(jh < n_own ? x + jh : xh + (jh - n_own)),
+                                             (__attribute__((address_space(3))) void *)(sx + (t < H ? 0 : BLK) + wv), 16, 0, 0);
+        }
+    } else {
+        own = gather_x(x, xh, n_own, clampj(rloc));
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            halo = gather_x(x, xh, n_own, clampj(t < H ? base - H + t : base + BLK + (t - H)));
+            hidx = t < H ? t : BLK + t;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);   // every gather is in flight before anything else is asked for
     // presence words of this wave (rows beyond the padded end of the matrix have none: the planes array ends with a zero row)
@@ -903,8 +922,12 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
     for (int c = 0; c < NS; c++) pl[c] = pp[c];
     const bool stopped = stop_flag(skip, skip_it);
     __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first one is waited for
-    sx[H + threadIdx.x] = own;
-    if (hidx >= 0) sx[hidx] = halo;
+    if constexpr (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the window has landed
+    } else {
+        sx[H + threadIdx.x] = own;
+        if (hidx >= 0) sx[hidx] = halo;
+    }
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63);
     cplx sum = make_double2(0., 0.);
@@ -1021,11 +1044,16 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
 #define SL(NS, RARE)                                                                                                      \
     hipLaunchKernelGGL((sten_spmv<NS, RARE, SHIFT, STEN_TILE>), dim3(grid), dim3(STEN_TILE), 0, c.stream, m, row_begin, row_begin + row_count, \
                        first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it)
+        static const bool dma_on = !(getenv("MGCR_STENCIL_DMA") && atoi(getenv("MGCR_STENCIL_DMA")) == 0);
 #define SLT(NS, RARE, BLK, HH)                                                                                            \
     do {                                                                                                                  \
         m.sten_halo = (HH);                                                                                               \
-        hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * (HH)) * sizeof(cplx), \
-                           c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it); \
+        if (dma_on && (HH) % 64 == 0)                                                                                     \
+            hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu, true>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * (HH)) * sizeof(cplx), \
+                               c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((sten_spmv_tile<NS, RARE, SHIFT, BLK, 0x3eu, false>), dim3(grid), dim3(BLK), (size_t)(BLK + 2 * (HH)) * sizeof(cplx), \
+                               c.stream, m, row_begin, row_begin + row_count, first, ntiles, xcd ? 1 : 0, x, y, w, g_skip.p, g_skip.it); \
     } while (0)
         if (big) {
             if (A.sten_rare) SLT(9, true, RED_THREADS, A.sten_halo_f);
