@@ -899,7 +899,7 @@ def test_rare_tail_stencil_kernels_same_bits(monkeypatch):
         assert np.array_equal(a, c)
 
 
-@pytest.mark.parametrize("n,planes", [(300, 4), (512, 2), (200, 5)])
+@pytest.mark.parametrize("n,planes", [(300, 4), (512, 2), (200, 5), (320, 3), (192, 4), (64, 40)])   # halo 64 k: the window is filled by LDS-DMA
 def test_wide_plane_window_kernels_bit_exact(n, planes):
     """Grids whose lines are longer than 256 points: the +-n neighbours are served by the 1024-row LDS window (halo up to 512)
     of the stand-alone SpMV and of the fused apply + dots / fused step 0 (rows reach >= 2^15 rows away), n = 200 by the
