@@ -35,6 +35,7 @@ import json
 import os
 import socket
 import subprocess
+import tempfile
 import sys
 import time
 
@@ -142,14 +143,31 @@ def run_supervisor(args, argv):
         dist.broadcast(port, src=0)
         cmd, env = worker_command(argv, int(port[0]), mode_env)
         t0 = time.time()
-        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        try:
-            out, err = p.communicate(timeout=limit)
-            rc = p.returncode
-        except subprocess.TimeoutExpired:
-            p.kill()
-            out, err = p.communicate()
-            rc = -9
+        # (files, not pipes: nobody reads while the supervisors poll below)
+        with tempfile.TemporaryFile(mode="w+") as f_out, tempfile.TemporaryFile(mode="w+") as f_err:
+            p = subprocess.Popen(cmd, env=env, stdout=f_out, stderr=f_err, text=True)
+            # The supervisors poll in lockstep: as soon as ONE worker has failed (or run out of time) every supervisor ends its
+            # own — a rank that died at start-up must not leave the others waiting in a rendezvous until the time limit.
+            while True:
+                rc = p.poll()
+                if rc is None and time.time() - t0 > limit:
+                    p.kill()
+                    p.wait()
+                    rc = -9
+                st = torch.tensor([1 if rc not in (None, 0) else 0, 1 if rc is not None else 0], dtype=torch.int32)
+                dist.all_reduce(st)
+                if int(st[0]) > 0:
+                    if rc is None:
+                        p.kill()       # the exact process started above
+                        p.wait()
+                        rc = -15       # ended because another rank's worker failed
+                    break
+                if int(st[1]) == world:
+                    break
+                time.sleep(0.25)
+            f_out.seek(0)
+            f_err.seek(0)
+            out, err = f_out.read(), f_err.read()
         parsed = last_json_line(out) if rank == 0 else None
         good = rc == 0 and (rank != 0 or parsed is not None)
         flag = torch.tensor([1 if good else 0], dtype=torch.int32)

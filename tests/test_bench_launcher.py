@@ -58,7 +58,7 @@ def test_traffic_is_only_reported_for_the_sources_it_was_measured_on(tmp_path, m
     assert val is None and "other kernel sources" in note
 
 
-def _run_ladder(tmp_path, fail_modes):
+def _run_ladder(tmp_path, fail_modes, hang_modes=()):
     """Two supervisors over gloo with a stand-in worker that fails in the given transport modes."""
     fake = tmp_path / "fake_bench.py"
     fake.write_text(textwrap.dedent("""
@@ -69,12 +69,15 @@ def _run_ladder(tmp_path, fail_modes):
             mode = "host" if os.environ.get("MGCR_BENCH_TRANSPORT") == "host" else "rccl" if os.environ.get("MGCR_PEER_ALLREDUCE") == "0" else "default"
             if mode in %r and os.environ["RANK"] == "1":     # only ONE rank fails: every rank must move on together
                 sys.exit(3)
+            if mode in %r and os.environ["RANK"] == "0":     # ... even when the other one would wait for it for minutes
+                import time
+                time.sleep(120)
             if os.environ["RANK"] == "0":
                 print(json.dumps({"metric": "gcr_iterations_per_sec", "value": 1.0, "mode": mode}))
             sys.exit(0)
         bench.__file__ = os.path.abspath(__file__)
         sys.exit(bench.run_supervisor(None, sys.argv[1:]))
-    """ % (ROOT, list(fail_modes))))
+    """ % (ROOT, list(fail_modes), list(hang_modes))))
     port = bench.free_port()
     procs = []
     for r in range(2):
@@ -99,3 +102,15 @@ def test_supervisors_exit_non_zero_when_nothing_works(tmp_path):
     rcs, outs = _run_ladder(tmp_path, ["default", "rccl", "host"])
     assert rcs == [1, 1], outs
     assert bench.last_json_line(outs[0][0]) is None
+
+
+def test_a_rank_that_dies_at_start_up_ends_the_attempt_for_everybody(tmp_path):
+    """Rank 1's worker exits at once, rank 0's would wait two minutes (a rendezvous nobody else joins): the attempt ends within
+    seconds on both and the ladder moves on."""
+    import time
+    t0 = time.time()
+    rcs, outs = _run_ladder(tmp_path, ["default"], hang_modes=["default"])
+    assert time.time() - t0 < 60, time.time() - t0
+    assert rcs == [0, 0], outs
+    d = bench.last_json_line(outs[0][0])
+    assert d["mode"] == "rccl" and [a["ok"] for a in d["launch"]["attempts"]] == [False, True]
