@@ -1,5 +1,5 @@
 """Apply time of the unstructured block-CSR operator of the bcsr workload (bs 20, 5-64 blocks per row, 3 GB):
-    python tools/bcsr_apply_time.py [tag]      (environment: MGCR_BCSR_DMA, MGCR_BCSR_DMA_NB)"""
+    python tools/bcsr_apply_time.py [tag]      (environment: MGCR_BCSR_ORDER=0 for the stored row order)"""
 import json
 import os
 import sys
