@@ -104,6 +104,21 @@ int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width
  * holding column offsets and values, 2 row-pattern dictionary for the columns + value slab;
  * *n_patterns = dictionary size (0 for format 0) */
 int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
+/* how the rows of a Sparse are dealt to threads — what decides the order in which a row's products are added, i.e. the
+ * one thing in which y = A x may differ from the reference's row loop (src/Operator.h:338-341): *ell_width = W, entries
+ * 0..W-1 of a row sit in the ELL slab; *lanes = L, lane l of L adds entries l, l+L, ... in order and the L sums are
+ * combined by a tree (L = 1: CSR order, bit-identical to the reference); *tail_rows = rows longer than W, whose remaining
+ * entries one wave sums (64 lanes striding, tree) and adds to the row's ELL sum; *reach = max |column - row| when the
+ * operator has a row-pattern dictionary, else 0 (it decides the row -> workgroup map of the GCR kernels that embed the
+ * apply).  Any pointer may be NULL.  tests/test_gpu_bitwise.py feeds these to the CPU oracle's model of the device's
+ * summation order. */
+int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach);
+/* Sparse::dagger / mod_*_at (src/Operator.h:296-328,84-86) change a Sparse IN PLACE while a DiracOp, GCR or MG may hold a
+ * pointer to it (src/Operator.h:117): this replaces the matrix behind an existing handle, so that every operator that
+ * borrowed the handle (mgcr_dirac_create, mgcr_gcr_create) applies the new matrix.  On failure the old matrix stays.
+ * Not for the row block of a distributed Sparse.  (An MG hierarchy built from the old matrix is not rebuilt — nor is the
+ * reference's, src/MG.h:131-285.) */
+int mgcr_csr_replace(mgcr_op_t op, int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const double *val_ri);
 /* Implementation switches (default on unless noted; each also has an environment variable read at first use).
  * They select between code paths that compute the same thing; tests use them to compare the paths.
  *   "pattern_storage" ($MGCR_PATTERNS): try the row-pattern dictionary for every Sparse of >= 2^15 rows
@@ -124,7 +139,8 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);
 /* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init,
- * "step_build_launches" = steps that ran as one apply + build launch. */
+ * "step_build_launches" = steps that ran as one apply + build launch, "small_solves" = solves that ran as one launch of one
+ * workgroup (csrc/gcr_small.hip). */
 int mgcr_stat(const char *name, int64_t *value);
 
 /* ---- GCR: src/GCR.h, src/SolverParam.h ---------------------------------------------------- */

@@ -342,12 +342,14 @@ public:
     }
     mgcr_op_t handle() override {
         if (!op || dirty) {
-            drop();
             mgcr_detail::ensure_init();
             std::vector<int64_t> rp((size_t)nrow + 1), ci((size_t)ROW[nrow]);
             for (num_type i = 0; i <= nrow; i++) rp[(size_t)i] = (int64_t)ROW[i];
             for (num_type i = 0; i < ROW[nrow]; i++) ci[(size_t)i] = (int64_t)COL[i];
-            mgcr_detail::ok(mgcr_csr_create((int64_t)nrow, (int64_t)this->dim, rp.data(), ci.data(), reinterpret_cast<const double *>(VAL), &op), "Sparse upload");
+            // a matrix that changed (dagger, mod_*_at) is replaced BEHIND its handle: DiracOp / GCR objects that borrowed
+            // the handle — as the reference's keep a Sparse* — go on with the new matrix, and the handle never dangles
+            if (op) mgcr_detail::ok(mgcr_csr_replace(op, (int64_t)nrow, (int64_t)this->dim, rp.data(), ci.data(), reinterpret_cast<const double *>(VAL)), "Sparse re-upload");
+            else mgcr_detail::ok(mgcr_csr_create((int64_t)nrow, (int64_t)this->dim, rp.data(), ci.data(), reinterpret_cast<const double *>(VAL), &op), "Sparse upload");
             dirty = false;
         }
         return op;

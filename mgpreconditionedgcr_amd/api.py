@@ -186,6 +186,12 @@ class Operator:
         check(_lib.lib().mgcr_op_stored_bytes(self.h, C.byref(b), C.byref(w), C.byref(t)))
         return dict(matrix_bytes=b.value, ell_width=w.value, tail_nnz=t.value)
 
+    def ell_layout(self):
+        """dict(ell_width, lanes, tail_rows, reach): how a Sparse's rows are dealt to threads (include/mgcr.h)."""
+        w, l, t, r = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        check(_lib.lib().mgcr_op_ell_layout(self.h, C.byref(w), C.byref(l), C.byref(t), C.byref(r)))
+        return dict(ell_width=w.value, lanes=l.value, tail_rows=t.value, reach=r.value)
+
     def storage_format(self):
         """(format, n_patterns): 0 ELL slab, 1 row-pattern dictionary (columns + values), 2 (columns only)."""
         f, n = C.c_int32(), C.c_int32()
@@ -253,10 +259,12 @@ class Sparse(Operator):
         """void Sparse::dagger() (src/Operator.h:296-328): conjugate transpose IN PLACE (rows and columns swap)."""
         from . import hostalg
         nr, nc, rp, ci, va = hostalg.csr_dagger(self._shape[0], self._shape[1], self.ROW, self.COL, self.VAL)
-        new = Sparse(nr, nc, rp, ci, va)
-        _lib.lib().mgcr_op_destroy(self.h)
-        self.h, new.h = new.h, None
-        self._shape, self.ROW, self.COL, self.VAL = new._shape, new.ROW, new.COL, new.VAL
+        rp, ci, va = np.ascontiguousarray(rp, np.int64), np.ascontiguousarray(ci, np.int64), np.ascontiguousarray(va, c128)
+        # the matrix changes BEHIND the handle (mgcr_csr_replace): a DiracOp / GCR that borrowed this Sparse — the
+        # reference's DiracOp keeps a Sparse* (src/Operator.h:117) — applies the daggered matrix from now on
+        check(_lib.lib().mgcr_csr_replace(self.h, nr, nc, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+        self._shape, self.ROW, self.COL, self.VAL = (int(nr), int(nc)), rp, ci, va
+        self._nnz = int(rp[-1])
         return self
 
     def __mul__(self, a):

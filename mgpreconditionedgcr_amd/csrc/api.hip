@@ -28,6 +28,21 @@ int mgcr_csr_create(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int
     return MGCR_OK;
 }
 
+int mgcr_csr_replace(mgcr_op_t op, int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const double *val_ri) {
+    MGCR_TRY(require_ctx());
+    MGCR_CHECK(op && rowptr && (col || rowptr[nrow] == 0) && (val_ri || rowptr[nrow] == 0), MGCR_ERR_INVALID, "mgcr_csr_replace: null argument");
+    MGCR_CHECK(op->kind == OP_CSR && !op->dist, MGCR_ERR_INVALID, "mgcr_csr_replace: not a (single-GPU) Sparse");
+    LOCK();
+    MGCR_HIP(hipStreamSynchronize(ctx().stream));   // nothing queued may still read the old matrix
+    CsrDev fresh;
+    MGCR_TRY(csr_build_device(nrow, ncol, rowptr, col, val_ri, &fresh));
+    csr_free(&op->csr);
+    op->csr = fresh;
+    op->dim = ncol;
+    op->nrow = nrow;
+    return MGCR_OK;
+}
+
 int mgcr_dirac_create(mgcr_op_t csr, const double k_ri[2], mgcr_op_t *out) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(csr && k_ri && out, MGCR_ERR_INVALID, "mgcr_dirac_create: null argument");
@@ -133,6 +148,17 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns) {
     return MGCR_OK;
 }
 
+int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach) {
+    MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
+    const Op *o = op->kind == OP_DIRAC ? op->base : op;
+    MGCR_CHECK(o->kind == OP_CSR, MGCR_ERR_UNSUPPORTED, "mgcr_op_ell_layout: not a Sparse");
+    if (ell_width) *ell_width = o->csr.W;
+    if (lanes) *lanes = o->csr.L;
+    if (tail_rows) *tail_rows = o->csr.n_tail_rows;
+    if (reach) *reach = o->csr.reach;
+    return MGCR_OK;
+}
+
 int mgcr_op_halo_kind(mgcr_op_t op, int32_t *kind) {
     MGCR_CHECK(op && kind, MGCR_ERR_INVALID, "mgcr_op_halo_kind: null argument");
     const Op *o = op->kind == OP_DIRAC ? op->base : op;
@@ -160,6 +186,7 @@ int mgcr_stat(const char *name, int64_t *value) {
     MGCR_CHECK(name && value, MGCR_ERR_INVALID, "mgcr_stat: null argument");
     if (!strcmp(name, "resident_solves")) *value = resident_solve_count();
     else if (!strcmp(name, "step_build_launches")) *value = stepbuild_launch_count();
+    else if (!strcmp(name, "small_solves")) *value = gcr_small_solve_count();
     else { set_error("mgcr_stat: unknown counter '%s'", name); return MGCR_ERR_INVALID; }
     return MGCR_OK;
 }

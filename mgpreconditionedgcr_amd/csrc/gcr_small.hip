@@ -202,6 +202,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gcr_small_kernel(SmallArgs a) {
 }
 
 static int64_t g_small_limit = -1;
+static int64_t g_small_solves = 0;
+int64_t gcr_small_solve_count() { return g_small_solves; }
 void gcr_small_set_limit(int64_t rows) { g_small_limit = rows; }
 
 // can this solve take the one-workgroup path?
@@ -243,6 +245,7 @@ int gcr_small_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, cons
     a.outer_skip = outer.p; a.outer_it = outer.it;
     hipLaunchKernelGGL(gcr_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, ctx().stream, a);
     MGCR_HIP(hipGetLastError());
+    g_small_solves++;
     return MGCR_OK;
 }
 

@@ -267,6 +267,7 @@ void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused);
 
 // ---- gcr_small.hip ---------------------------------------------------------------------------
 void gcr_small_set_limit(int64_t rows);
+int64_t gcr_small_solve_count();
 bool gcr_small_eligible(const Op *A, const mgcr_gcr_param &p, int storage, int64_t n);
 int gcr_small_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, const cplx *rhs, cplx *x, cplx *r, cplx *ar,
                   cplx *const *ps, cplx *const *aps, double *hist, int hist_cap, int *state);

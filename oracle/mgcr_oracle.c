@@ -32,7 +32,10 @@ typedef double _Complex cplx;
 /* Summation order of the two reductions below.  0 (default) = the reference's: sequential in
  * index order.  1 = reverse index order, 2 = pairwise tree: equally valid orders, used by the
  * tests ONLY to measure how sensitive a residual history is to re-association, which is the one
- * thing a parallel reduction cannot reproduce. */
+ * thing a parallel reduction cannot reproduce.  3 = the order the HIP library sums in (the model
+ * below): with it a solve of the oracle and a solve on the GPU must agree BIT FOR BIT, which is
+ * how tests/test_gpu_bitwise.py proves that summation order is the only difference between the
+ * device path and the reference. */
 static int g_sum_order = 0;
 void orc_set_sum_order(int mode) { g_sum_order = mode; }
 
@@ -46,11 +49,98 @@ static cplx dot_pairwise(int64_t n, const cplx *a, const cplx *b) {
     return dot_pairwise(h, a, b) + dot_pairwise(n - h, a + h, b + h);
 }
 
+/* ---- order 3: model of the device's two-stage reduction (mgpreconditionedgcr_amd/csrc/reduce.h,
+ * blas1.hip:red_grid, gcr_dev.h:RowMap).  A reducing kernel runs `g` workgroups of 1024 threads;
+ * thread t of workgroup b adds the terms of its rows (first, first + step, ...: ascending) into a
+ * private accumulator that starts at 0; the 64 lanes of a wave are summed by the tree
+ * (l, l+32), (l, l+16), ..., (l, l+1), always lower + upper (reduce.h:wave_sum); the 16 wave sums
+ * are added in wave order onto 0 (block_sum_owner); the g workgroup partials are folded by the same
+ * 1024-wide tree with zeros beyond g (fold_partials).  Real and imaginary parts are separate sums.
+ * Row map: plain grid-stride (first = b*1024 + t, step = g*1024), or — only for the kernels that
+ * embed the operator apply, when the operator's rows reach far (RowMap::band != 0) — eight
+ * contiguous bands swept by g/8 workgroups each. */
+#define DEV_THREADS 1024
+#define DEV_MAX_BLOCKS 512
+static int g_dev_blocks = 0;      /* 0: red_grid(n) = min(ceil(n/1024), 512); 1: the one-workgroup solver (gcr_small.hip) */
+static int64_t g_dev_band = 0;    /* RowMap::band (0 = not banded) */
+static int g_dev_per = 0;         /* RowMap::per */
+static int g_dev_init_banded = 0; /* step 0's sums come out of the kernel that embeds the apply (gcr_fused.hip init_apply_kernel) */
+static int g_dev_ell_w = -1;      /* SpMV layout: ELL width W (rows longer than W keep a CSR tail); -1: every row sequential */
+static int g_dev_ell_l = 1;       /* lanes per row of the ELL part (1: sequential in CSR order) */
+void orc_set_device_model(int blocks, int64_t band, int per, int init_banded, int ell_width, int ell_lanes) {
+    g_dev_blocks = blocks; g_dev_band = band; g_dev_per = per; g_dev_init_banded = init_banded;
+    g_dev_ell_w = ell_width; g_dev_ell_l = ell_lanes < 1 ? 1 : ell_lanes;
+}
+
+static int dev_grid(int64_t n) {
+    if (g_dev_blocks > 0) return g_dev_blocks;
+    int64_t g = (n + DEV_THREADS - 1) / DEV_THREADS;
+    if (g < 1) g = 1;
+    if (g > DEV_MAX_BLOCKS) g = DEV_MAX_BLOCKS;
+    return (int)g;
+}
+static double dev_wave_tree(double *v) { /* v[64], destroyed */
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int l = 0; l < off; l++) v[l] = v[l] + v[l + off];
+    return v[0];
+}
+static double dev_block_sum(double *acc) { /* acc[1024], destroyed */
+    double t = 0.;
+    for (int w = 0; w < DEV_THREADS / 64; w++) t += dev_wave_tree(acc + 64 * w);
+    return t;
+}
+/* sum of term[0..n) in the device's order; banded != 0 selects the RowMap of the apply-embedding kernels */
+static double dev_sum(int64_t n, const double *term, int banded) {
+    const int g = dev_grid(n);
+    double acc[DEV_THREADS], parts[DEV_THREADS];
+    for (int b = 0; b < DEV_THREADS; b++) parts[b] = 0.;
+    const int use_band = banded && g_dev_band > 0 && g_dev_per > 0 && g % 8 == 0;
+    for (int b = 0; b < g; b++) {
+        for (int t = 0; t < DEV_THREADS; t++) {
+            int64_t first, end, step;
+            if (use_band) {
+                const int64_t xb = b / g_dev_per;
+                first = xb * g_dev_band + (int64_t)(b % g_dev_per) * DEV_THREADS + t;
+                end = (xb + 1) * g_dev_band; if (end > n) end = n;
+                step = (int64_t)g_dev_per * DEV_THREADS;
+            } else {
+                first = (int64_t)b * DEV_THREADS + t; end = n; step = (int64_t)g * DEV_THREADS;
+            }
+            double a = 0.;
+            for (int64_t i = first; i < end; i += step) a += term[i];
+            acc[t] = a;
+        }
+        parts[b] = dev_block_sum(acc);
+    }
+    if (g == 1) return parts[0] + 0.; /* fold_partials: one partial is loaded as it is (x + 0.0) */
+    return dev_block_sum(parts);
+}
+static int g_dev_banded_now = 0; /* set by the GCR loop around the sums the apply-embedding kernels take */
+static cplx dot_device(int64_t n, const cplx *a, const cplx *b) {
+    double *re = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1)), *im = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) {
+        const double ax = creal(a[i]), ay = cimag(a[i]), bx = creal(b[i]), by = cimag(b[i]);
+        re[i] = ax * bx + ay * by;   /* conj(a) * b, un-fused (reduce.h:cconj_mul) */
+        im[i] = ax * by - ay * bx;
+    }
+    const double sr = dev_sum(n, re, g_dev_banded_now), si = dev_sum(n, im, g_dev_banded_now);
+    free(re); free(im);
+    return sr + si * I;
+}
+static double sqnorm_device(int64_t n, const cplx *a) {
+    double *t = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) { const double x = creal(a[i]), y = cimag(a[i]); t[i] = x * x + y * y; }
+    const double s = dev_sum(n, t, g_dev_banded_now);
+    free(t);
+    return s;
+}
+
 /* src/Fields.h:216-226  dot(a,b) = sum_i conj(a_i) * b_i, sequential, index order */
 void orc_dot(int64_t n, const cplx *a, const cplx *b, cplx *out) {
     cplx s = 0.0;
     if (g_sum_order == 1) for (int64_t i = n - 1; i >= 0; i--) s += conj(a[i]) * b[i];
     else if (g_sum_order == 2) s = dot_pairwise(n, a, b);
+    else if (g_sum_order == 3) s = dot_device(n, a, b);
     else for (int64_t i = 0; i < n; i++) s += conj(a[i]) * b[i];
     *out = s;
 }
@@ -60,6 +150,7 @@ double orc_sqnorm(int64_t n, const cplx *a) {
     cplx s = 0.0;
     if (g_sum_order == 1) for (int64_t i = n - 1; i >= 0; i--) s += conj(a[i]) * a[i];
     else if (g_sum_order == 2) s = dot_pairwise(n, a, a);
+    else if (g_sum_order == 3) return sqnorm_device(n, a);
     else for (int64_t i = 0; i < n; i++) s += conj(a[i]) * a[i];
     return creal(s);
 }
@@ -123,8 +214,47 @@ typedef struct orc_op {
 
 void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
 
-/* src/Operator.h:330-346  y_row = sum_l VAL[l] * x[COL[l]], sequential per row */
+/* src/Operator.h:330-346  y_row = sum_l VAL[l] * x[COL[l]], sequential per row.
+ * Order 3 with a device layout set (orc_set_device_model: W, L): the row's first min(len, W) entries are summed the way
+ * csrc/spmv.hip:ell_spmv_lanes does — lane l of L adds entries l, l+L, ... in order, the L lane sums are combined by the tree
+ * (l, l+L/2), ..., (l, l+1), lower + upper — and the entries beyond W the way csr_tail_kernel does: 64 lanes stride them,
+ * wave tree, then y_row = y_ell + y_tail (DiracOp: y = (x - k y_ell) - k y_tail, see dirac_apply).  L = 1 and no tail is
+ * the reference's order. */
+static void csr_row_device(const orc_op *op, int64_t row, const cplx *x, cplx *ell, cplx *tail, int *has_tail) {
+    const int64_t b = op->rowptr[row], e = op->rowptr[row + 1];
+    const int W = g_dev_ell_w, L = g_dev_ell_l;
+    const int64_t ne = (e - b) < W ? (e - b) : W;
+    double lr[16], li[16];
+    for (int l = 0; l < L; l++) { lr[l] = 0.; li[l] = 0.; }
+    for (int64_t w = 0; w < ne; w++) {
+        const cplx t = op->val[b + w] * x[op->col[b + w]];
+        lr[w % L] += creal(t); li[w % L] += cimag(t);
+    }
+    for (int off = L / 2; off >= 1; off >>= 1)
+        for (int l = 0; l < off; l++) { lr[l] = lr[l] + lr[l + off]; li[l] = li[l] + li[l + off]; }
+    *ell = lr[0] + li[0] * I;
+    *has_tail = (e - b) > W;
+    if (*has_tail) {
+        double tr[64], ti[64];
+        for (int l = 0; l < 64; l++) { tr[l] = 0.; ti[l] = 0.; }
+        for (int64_t j = b + W; j < e; j++) {
+            const cplx t = op->val[j] * x[op->col[j]];
+            tr[(j - b - W) % 64] += creal(t); ti[(j - b - W) % 64] += cimag(t);
+        }
+        const double sr = dev_wave_tree(tr), si = dev_wave_tree(ti);
+        *tail = sr + si * I;
+    }
+}
+static int csr_device_layout(void) { return g_sum_order == 3 && g_dev_ell_w >= 0 && g_dev_ell_l <= 16; }
 static void csr_apply(const orc_op *op, const cplx *x, cplx *y) {
+    if (csr_device_layout()) {
+        for (int64_t row = 0; row < op->nrow; row++) {
+            cplx ell, tail = 0.0; int ht;
+            csr_row_device(op, row, x, &ell, &tail, &ht);
+            y[row] = ht ? ell + tail : ell;
+        }
+        return;
+    }
     for (int64_t row = 0; row < op->nrow; row++) {
         cplx sum = 0.0;
         for (int64_t l = op->rowptr[row]; l < op->rowptr[row + 1]; l++) sum += op->val[l] * x[op->col[l]];
@@ -134,6 +264,16 @@ static void csr_apply(const orc_op *op, const cplx *x, cplx *y) {
 
 /* src/Operator.h:569-575  f - (D f) * k */
 static void dirac_apply(const orc_op *op, const cplx *x, cplx *y) {
+    if (csr_device_layout() && op->D->kind == OP_CSR) { /* the shift sits in the SpMV epilogue of each of the two kernels */
+        for (int64_t row = 0; row < op->D->nrow; row++) {
+            cplx ell, tail = 0.0; int ht;
+            csr_row_device(op->D, row, x, &ell, &tail, &ht);
+            cplx v = x[row] - op->k * ell;
+            if (ht) v = v - op->k * tail;
+            y[row] = v;
+        }
+        return;
+    }
     cplx *t = (cplx *)malloc(sizeof(cplx) * (size_t)op->dim);
     orc_op_apply(op->D, x, t);
     for (int64_t i = 0; i < op->dim; i++) y[i] = x[i] - op->k * t[i];
@@ -254,7 +394,17 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
     cplx *r = vnew(n), *p = vnew(n), *Ap = vnew(n), *Ar = vnew(n), *t = vnew(n);
     cplx *z = NULL;
     /* r = rhs (src/GCR.h:189) — the reference ignores x0 here */
-    if (gp->use_x0) {
+    if (gp->use_x0 && csr_device_layout() && A->kind == OP_CSR && g_dev_blocks != 1) {
+        /* order 3, Sparse with multi-lane rows / a CSR tail: the device forms b - A x0 in the SpMV's epilogue
+         * (gcr.hip:op_residual_raw), i.e. (b - ell part) - tail part, not b - (ell part + tail part) */
+        for (int64_t row = 0; row < A->nrow; row++) {
+            cplx ell, tail = 0.0; int ht;
+            csr_row_device(A, row, x, &ell, &tail, &ht);
+            cplx v = rhs[row] - ell;
+            if (ht) v = v - tail;
+            r[row] = v;
+        }
+    } else if (gp->use_x0) {
         orc_op_apply(A, x, t);
         for (int64_t i = 0; i < n; i++) r[i] = rhs[i] - t[i];
     } else {
@@ -280,10 +430,16 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
     memcpy(Aps[0], Ap, sizeof(cplx) * (size_t)n);
     memcpy(ps[0], p, sizeof(cplx) * (size_t)n);
 
+    /* order 3: step 0's sums come out of the kernel that embeds the apply when the device fuses the start */
+    g_dev_banded_now = g_dev_init_banded;
     double bnorm2 = orc_sqnorm(n, rhs);
     double bnorm = sqrt(bnorm2);
     if (hist && hist_cap > 0) hist[0] = sqrt(orc_sqnorm(n, r)) / bnorm;
     if (gp->verbose) printf("Step %d residual norm = %.10e\n", 0, sqrt(orc_sqnorm(n, r)) / bnorm);
+    /* order 3: the device keeps <Ap_i,Ap_i> from the pass that formed Ap_i (gcr.hip: den[slot]) instead of summing it
+     * again for every beta — the same number unless the two passes deal their rows differently (banded RowMap) */
+    cplx *den_cache = (cplx *)calloc((size_t)storage, sizeof(cplx));
+    int cur_slot = 0, first_step = 1;
 
     int iter_count = 0, global_count = 0;
     cplx *Ap_corr = vnew(n), *p_corr = vnew(n);
@@ -293,8 +449,12 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         iter_count++;
         /* alpha = r.dot(Ap) / Ap.dot(Ap)   (src/GCR.h:230) */
         cplx num, den;
+        g_dev_banded_now = first_step ? g_dev_init_banded : 0;
         orc_dot(n, r, Ap, &num);
         orc_dot(n, Ap, Ap, &den);
+        g_dev_banded_now = 0;
+        first_step = 0;
+        den_cache[cur_slot] = den;
         cplx alpha = num / den;
         /* x = x + p*alpha ; r = r - Ap*alpha  (src/GCR.h:232-233) */
         for (int64_t i = 0; i < n; i++) x[i] = x[i] + alpha * p[i];
@@ -316,8 +476,11 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         for (int64_t i = 0; i < n; i++) { Ap_corr[i] = 0.0; p_corr[i] = 0.0; }
         for (int i = 0; i < lim; i++) { /* src/GCR.h:257-262 */
             cplx bn, bd;
+            g_dev_banded_now = 1; /* the beta numerators are summed by the apply-embedding kernel / multidot_kernel (RowMap) */
             orc_dot(n, Ar, Aps[i], &bn);
-            orc_dot(n, Aps[i], Aps[i], &bd);
+            g_dev_banded_now = 0;
+            if (g_sum_order == 3) bd = den_cache[i];
+            else orc_dot(n, Aps[i], Aps[i], &bd);
             cplx beta = bn / bd;
             for (int64_t j = 0; j < n; j++) p_corr[j] = p_corr[j] - beta * ps[i][j];
             for (int64_t j = 0; j < n; j++) Ap_corr[j] = Ap_corr[j] - beta * Aps[i][j];
@@ -334,6 +497,7 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         if (!Aps[slot]) { Aps[slot] = vnew(n); ps[slot] = vnew(n); }
         memcpy(Aps[slot], Ap, sizeof(cplx) * (size_t)n);
         memcpy(ps[slot], p, sizeof(cplx) * (size_t)n);
+        cur_slot = slot;
     } while ((rn2 / bnorm2) > gp->tol * gp->tol && global_count < gp->max_iter); /* src/GCR.h:288 */
 
     if (converged) *converged = (global_count == gp->max_iter) ? 0 : 1;
@@ -344,7 +508,7 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
             printf("GCR converged after %d steps. Residual norm=%.10e\n", global_count, sqrt(rn2) / bnorm);
     }
     for (int i = 0; i < storage; i++) { free(Aps[i]); free(ps[i]); }
-    free(Aps); free(ps); free(Ap_corr); free(p_corr);
+    free(Aps); free(ps); free(Ap_corr); free(p_corr); free(den_cache);
     free(r); free(p); free(Ap); free(Ar); free(t); free(z);
     return global_count;
 }

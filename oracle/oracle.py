@@ -73,6 +73,7 @@ def lib():
         L.orc_op_dim.argtypes = [C.c_void_p]
         L.orc_op_dim.restype = C.c_int64
         L.orc_set_sum_order.argtypes = [C.c_int]
+        L.orc_set_device_model.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_op_nrow.argtypes = [C.c_void_p]
         L.orc_op_nrow.restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
@@ -240,6 +241,38 @@ def gcr_reorder_sensitivity(A, param, rhs, x0=None):
     finally:
         lib().orc_set_sum_order(0)
     return ref, dev, (min(its), max(its))
+
+
+class device_order:
+    """Context manager: inside it the oracle sums its dot products in the order the HIP library does
+    (orc_set_sum_order(3), model in mgcr_oracle.c) and, when `ell_width` is given, forms SpMV rows the way the
+    multi-lane / CSR-tail kernels do.  `blocks`: 0 = the multi-kernel solver's grid (red_grid(n)), 1 = the
+    one-workgroup solver.  `band`, `per`, `init_banded`: the RowMap of the kernels that embed the operator apply
+    (gcr_dev.h:make_row_map), needed from about 182^3 rows on (`row_map(n, reach)` below computes them)."""
+
+    def __init__(self, blocks=0, band=0, per=0, init_banded=False, ell_width=-1, ell_lanes=1):
+        self.args = (int(blocks), int(band), int(per), int(bool(init_banded)), int(ell_width), int(ell_lanes))
+
+    def __enter__(self):
+        lib().orc_set_device_model(*self.args)
+        lib().orc_set_sum_order(3)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_sum_order(0)
+        lib().orc_set_device_model(0, 0, 0, 0, -1, 1)
+        return False
+
+
+def row_map(n, reach):
+    """(band, per) of gcr_dev.h:make_row_map for a solve on n rows whose operator's rows reach `reach` rows away
+    (0: unknown): banded when 2 * reach >= rows one XCD covers per trip of the plain grid-stride."""
+    g = min(max((n + 1023) // 1024, 1), 512)
+    slice_ = g * 1024 // 8
+    wide = (2 * reach >= slice_) if reach > 0 else (n >= 1 << 23)
+    if g >= 64 and g % 8 == 0 and wide:
+        return ((n + 7) // 8 + 1023) // 1024 * 1024, g // 8
+    return 0, 0
 
 
 def gcr_x_sensitivity(A, param, rhs, x0=None):
