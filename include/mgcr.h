@@ -140,8 +140,17 @@ int mgcr_csr_replace(mgcr_op_t op, int64_t nrow, int64_t ncol, const int64_t *ro
 int mgcr_set_option(const char *name, int value, int *previous);
 /* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init,
  * "step_build_launches" = steps that ran as one apply + build launch, "small_solves" = solves that ran as one launch of one
- * workgroup (csrc/gcr_small.hip). */
+ * workgroup (csrc/gcr_small.hip), "one_launch_fallbacks" = top-level solves that were repeated on the multi-kernel path
+ * because a one-launch path gave up (foreign work on the device: its grid was not co-resident). */
 int mgcr_stat(const char *name, int64_t *value);
+
+/* Self-test of the hardware behaviour the one-launch solver paths (csrc/gcr_resident.hip, gcr_stepbuild.hip) build on: inside
+ * ONE launch, rows stored with `buffer_store ... sc1` by one workgroup are read correctly with `buffer_load ... sc1` by
+ * workgroups of other XCDs after a fence-free {value, generation} exchange.  Runs `steps` dependent steps over one
+ * workgroup per CU with the library's own primitives and bounded polls; *rows_wrong = entries that differ from what the
+ * host computes (0 expected).  coherent = 0 runs the control with ordinary loads / stores (expected to FAIL: it shows the
+ * test can).  tests/test_gpu_resident.py runs both on every GPU test pass. */
+int mgcr_selftest_coherence(int32_t steps, int32_t coherent, int64_t *rows_wrong);
 
 /* ---- GCR: src/GCR.h, src/SolverParam.h ---------------------------------------------------- */
 typedef struct mgcr_gcr_param {

@@ -83,6 +83,7 @@ _SIGS = {
     "mgcr_op_storage_format": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mgcr_op_ell_layout": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mgcr_csr_replace": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "mgcr_selftest_coherence": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "mgcr_set_option": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "mgcr_stat": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "mgcr_gcr_solve": (C.c_int, [_vp, C.POINTER(GcrParamC), _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

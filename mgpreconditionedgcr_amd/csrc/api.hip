@@ -187,8 +187,15 @@ int mgcr_stat(const char *name, int64_t *value) {
     if (!strcmp(name, "resident_solves")) *value = resident_solve_count();
     else if (!strcmp(name, "step_build_launches")) *value = stepbuild_launch_count();
     else if (!strcmp(name, "small_solves")) *value = gcr_small_solve_count();
+    else if (!strcmp(name, "one_launch_fallbacks")) *value = gcr_fallback_count();
     else { set_error("mgcr_stat: unknown counter '%s'", name); return MGCR_ERR_INVALID; }
     return MGCR_OK;
+}
+
+int mgcr_selftest_coherence(int32_t steps, int32_t coherent, int64_t *rows_wrong) {
+    MGCR_TRY(require_ctx());
+    LOCK();
+    return coherence_selftest(steps, coherent, rows_wrong);
 }
 
 int mgcr_op_stored_bytes(mgcr_op_t op, int64_t *matrix_bytes, int32_t *ell_width, int64_t *tail_nnz) {
@@ -227,7 +234,7 @@ int mgcr_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y) {
     // input again after it has started to write the output (post-smoother, x0 handling)
     MGCR_CHECK(x->d != y->d, MGCR_ERR_INVALID, "mgcr_op_apply: input and output must be different Fields");
     LOCK();
-    return op_apply_raw(op, x->d, y->d, x->n);
+    return op_apply_raw(op, x->d, y->w(), x->n);
 }
 
 int mgcr_gcr_solve(mgcr_op_t A, const mgcr_gcr_param *param, mgcr_vec_t rhs, mgcr_vec_t x, double *hist, int32_t hist_cap,
@@ -242,7 +249,8 @@ int mgcr_gcr_solve(mgcr_op_t A, const mgcr_gcr_param *param, mgcr_vec_t rhs, mgc
     GcrState *s = nullptr;
     MGCR_TRY(gcr_state_create(A, param, 1, &s));
     int it = 0, conv = 0;
-    int rc = gcr_run(s, rhs->d, x->d, false, hist, hist_cap, &it, &conv);
+    const bool xz = x->zero_known;
+    int rc = gcr_run(s, rhs->d, x->w(), false, hist, hist_cap, &it, &conv, xz);
     gcr_state_destroy(s);
     if (n_iter) *n_iter = it;
     if (converged) *converged = conv;
@@ -286,7 +294,8 @@ int mgcr_gcr_solve_op(mgcr_op_t gcr, mgcr_vec_t rhs, mgcr_vec_t x, double *hist,
     MGCR_CHECK(rhs->d != x->d, MGCR_ERR_INVALID, "rhs and x must be different Fields");
     LOCK();
     int it = 0, conv = 0;
-    int rc = gcr_run(gcr->gcr, rhs->d, x->d, false, hist, hist_cap, &it, &conv);
+    const bool xz = x->zero_known;
+    int rc = gcr_run(gcr->gcr, rhs->d, x->w(), false, hist, hist_cap, &it, &conv, xz);
     if (n_iter) *n_iter = it;
     if (converged) *converged = conv;
     return rc;
@@ -321,7 +330,7 @@ int mgcr_bench_op_apply(mgcr_op_t op, mgcr_vec_t x, mgcr_vec_t y, int32_t reps, 
     Context &c = ctx();
     MGCR_TRY(mgcr_op_apply(op, x, y));  // warm-up (and argument checks)
     MGCR_HIP(hipEventRecord(c.ev0, c.stream));
-    for (int i = 0; i < reps; i++) MGCR_TRY(op_apply_raw(op, x->d, y->d, x->n));
+    for (int i = 0; i < reps; i++) MGCR_TRY(op_apply_raw(op, x->d, y->w(), x->n));
     MGCR_HIP(hipEventRecord(c.ev1, c.stream));
     MGCR_HIP(hipEventSynchronize(c.ev1));
     float ms = 0.f;

@@ -155,7 +155,7 @@ int mgcr_vec_upload(mgcr_vec_t v, const double *host_ri) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(v && host_ri, MGCR_ERR_INVALID, "mgcr_vec_upload: null argument");
     LOCK();
-    MGCR_HIP(hipMemcpyAsync(v->d, host_ri, sizeof(cplx) * (size_t)v->n, hipMemcpyHostToDevice, ctx().stream));
+    MGCR_HIP(hipMemcpyAsync(v->w(), host_ri, sizeof(cplx) * (size_t)v->n, hipMemcpyHostToDevice, ctx().stream));
     MGCR_HIP(hipStreamSynchronize(ctx().stream));
     return MGCR_OK;
 }
@@ -176,28 +176,30 @@ int mgcr_vec_copy(mgcr_vec_t dst, mgcr_vec_t src) {
     // Field::operator= on a size mismatch prints "Dimension mismatch." and exits (src/Fields.h:279-283)
     MGCR_CHECK(dst->n == src->n, MGCR_ERR_INVALID, "Dimension mismatch. (%lld vs %lld)", (long long)dst->n, (long long)src->n);
     LOCK();
-    return k_copy(dst->d, src->d, dst->n);
+    return k_copy(dst->w(), src->d, dst->n);
 }
 
 int mgcr_vec_zero(mgcr_vec_t v) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(v, MGCR_ERR_INVALID, "mgcr_vec_zero: null argument");
     LOCK();
-    return k_zero(v->d, v->n);
+    MGCR_TRY(k_zero(v->w(), v->n));
+    v->zero_known = true;
+    return MGCR_OK;
 }
 
 int mgcr_vec_set_constant(mgcr_vec_t v, const double c_ri[2]) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(v && c_ri, MGCR_ERR_INVALID, "mgcr_vec_set_constant: null argument");
     LOCK();
-    return k_set_constant(v->d, make_double2(c_ri[0], c_ri[1]), v->n);
+    return k_set_constant(v->w(), make_double2(c_ri[0], c_ri[1]), v->n);
 }
 
 int mgcr_vec_fill_rhs(mgcr_vec_t v, uint64_t seed, int64_t global_offset) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(v, MGCR_ERR_INVALID, "mgcr_vec_fill_rhs: null argument");
     LOCK();
-    return k_fill_rhs(v->d, v->n, seed, global_offset);
+    return k_fill_rhs(v->w(), v->n, seed, global_offset);
 }
 
 static int dot_to_host(const cplx *a, const cplx *b, int64_t n, double out[2]) {
@@ -241,7 +243,7 @@ int mgcr_add_scaled(mgcr_vec_t out, mgcr_vec_t a, const double alpha_ri[2], mgcr
     MGCR_CHECK(out && a && b && alpha_ri, MGCR_ERR_INVALID, "mgcr_add_scaled: null argument");
     MGCR_CHECK(out->n == a->n && a->n == b->n, MGCR_ERR_INVALID, "Lengths of two fields do not match!");
     LOCK();
-    return k_add_scaled(out->d, a->d, make_double2(alpha_ri[0], alpha_ri[1]), b->d, a->n);
+    return k_add_scaled(out->w(), a->d, make_double2(alpha_ri[0], alpha_ri[1]), b->d, a->n);
 }
 
 int mgcr_axpy(const double alpha_ri[2], mgcr_vec_t x, mgcr_vec_t y) {
@@ -249,14 +251,14 @@ int mgcr_axpy(const double alpha_ri[2], mgcr_vec_t x, mgcr_vec_t y) {
     MGCR_CHECK(x && y && alpha_ri, MGCR_ERR_INVALID, "mgcr_axpy: null argument");
     MGCR_CHECK(x->n == y->n, MGCR_ERR_INVALID, "Field dimensions do not match!");
     LOCK();
-    return k_add_scaled(y->d, y->d, make_double2(alpha_ri[0], alpha_ri[1]), x->d, x->n);
+    return k_add_scaled(y->w(), y->d, make_double2(alpha_ri[0], alpha_ri[1]), x->d, x->n);
 }
 
 int mgcr_scale(mgcr_vec_t v, const double alpha_ri[2]) {
     MGCR_TRY(require_ctx());
     MGCR_CHECK(v && alpha_ri, MGCR_ERR_INVALID, "mgcr_scale: null argument");
     LOCK();
-    return k_scale(v->d, make_double2(alpha_ri[0], alpha_ri[1]), v->n);
+    return k_scale(v->w(), make_double2(alpha_ri[0], alpha_ri[1]), v->n);
 }
 
 int mgcr_vec_gamma5(mgcr_vec_t in, mgcr_vec_t out, int64_t inner) {
@@ -264,7 +266,7 @@ int mgcr_vec_gamma5(mgcr_vec_t in, mgcr_vec_t out, int64_t inner) {
     MGCR_CHECK(in && out && in != out && in->n == out->n, MGCR_ERR_INVALID, "mgcr_vec_gamma5: two distinct fields of one size");
     MGCR_CHECK(inner >= 1 && in->n % (4 * inner) == 0, MGCR_ERR_INVALID, "mgcr_vec_gamma5: the spinor dimension must have 4 entries");
     LOCK();
-    return k_gamma5(out->d, in->d, in->n, inner);
+    return k_gamma5(out->w(), in->d, in->n, inner);
 }
 
 int mgcr_normalise(mgcr_vec_t v) {
@@ -274,7 +276,7 @@ int mgcr_normalise(mgcr_vec_t v) {
     double r[2];
     MGCR_TRY(dot_to_host(v->d, v->d, v->n, r));
     // field[i] *= 1./norm  (src/Fields.h:237-243)
-    return k_scale(v->d, make_double2(1. / sqrt(r[0]), 0.), v->n);
+    return k_scale(v->w(), make_double2(1. / sqrt(r[0]), 0.), v->n);
 }
 
 }  // extern "C"

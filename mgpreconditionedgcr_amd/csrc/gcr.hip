@@ -89,6 +89,8 @@ struct GcrState {
     cplx *r = nullptr, *ar = nullptr, *z = nullptr, *tmp = nullptr, *accp = nullptr, *accap = nullptr;
     cplx *x0 = nullptr;
     cplx *res_ring = nullptr;   // gcr_resident.hip
+    cplx *xbak = nullptr;       // copy of the caller's x while a one-launch path may have to be abandoned (gcr_run)
+    int64_t xbak_n = 0;
     DevState *st = nullptr;
     double *partsA = nullptr, *partsR = nullptr, *partsN = nullptr, *partsB = nullptr;
     cplx *den = nullptr;  // cached <Aps[i],Aps[i]> per slot
@@ -791,6 +793,7 @@ void gcr_state_destroy(GcrState *s) {
     if (!s) return;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     gcr_free_vectors(s);
+    hipFree(s->xbak);
     hipFree(s->x0); hipFree(s->st); hipFree(s->partsA); hipFree(s->partsR); hipFree(s->partsN);
     hipFree(s->dA); hipFree(s->dN); hipFree(s->lc);
     delete s;
@@ -1098,7 +1101,7 @@ static int gcr_finish(GcrState *s, double *hist, int hist_cap, int *n_iter, int 
     return MGCR_OK;
 }
 
-int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged) {
+static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged) {
     Context &c = ctx();
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
     const int64_t n = s->A->dim;
@@ -1134,7 +1137,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
             s->r_after.clear();
             if (nested) return MGCR_OK;
             MGCR_TRY(gcr_finish(s, hist, hist_cap, n_iter, converged));
-            return resident_check();
+            return resident_check(true);
         }
     }
     hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, c.stream, s->st, outer.p, outer.it, p.tol * p.tol);
@@ -1543,8 +1546,45 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);
     if (multi) MGCR_TRY(comm_check(comm));   // a peer-write wait that timed out poisoned the scalars with NaN
-    MGCR_TRY(resident_check());              // a one-launch step (gcr_stepbuild.hip) that was not co-resident gave up
+    MGCR_TRY(resident_check(true));          // a one-launch step (gcr_stepbuild.hip) that was not co-resident gave up: gcr_run repeats the solve
     return frc;
+}
+
+// GCR::solve.  A top-level solve that took a one-launch path (gcr_resident.hip, gcr_stepbuild.hip: workgroups that wait for each
+// other) and whose launch gave up — another process's kernels held CUs, so the grid was not co-resident; bounded polls, NaN
+// results — is REPEATED here on the multi-kernel path, from the untouched right-hand side and the x the caller handed in: the
+// caller gets the solve it asked for from its first call (mgcr_stat "one_launch_fallbacks" counts these).  The one-launch paths
+// have switched themselves off by then (resident_check).  x on entry: zero when the caller says so (the Field was zeroed by
+// mgcr_vec_zero and not written since: re-zeroed for the second run), otherwise a copy is kept whenever a one-launch path may run.
+static int64_t g_fallbacks = 0;
+int64_t gcr_fallback_count() { return g_fallbacks; }
+int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter, int *converged, bool x_known_zero) {
+    if (nested) return gcr_run_once(s, rhs, x, true, hist, hist_cap, n_iter, converged);
+    MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
+    const int64_t n = s->A->dim;
+    const bool risky = one_launch_paths_enabled() && comm_live_count() == 0;   // (the paths' own conditions are narrower: a copy too many costs one pass)
+    bool have_copy = false;
+    if (risky && !x_known_zero) {
+        if (s->xbak_n != n) {
+            hipStreamSynchronize(ctx().stream);
+            hipFree(s->xbak); s->xbak = nullptr; s->xbak_n = 0;
+            MGCR_TRY(dalloc(&s->xbak, (size_t)n));
+            s->xbak_n = n;
+        }
+        MGCR_TRY(k_copy(s->xbak, x, n));
+        have_copy = true;
+    }
+    int rc = gcr_run_once(s, rhs, x, false, hist, hist_cap, n_iter, converged);
+    if (rc != MGCR_INT_GAVE_UP) return rc;
+    if (!risky) {   // (cannot happen: nothing that waits on other workgroups ran) — report like a host synchronisation point would
+        set_error("one-launch solver kernel gave up and no copy of x was kept");
+        return MGCR_ERR_HIP;
+    }
+    if (have_copy) MGCR_TRY(k_copy(x, s->xbak, n));
+    else MGCR_TRY(k_zero(x, n));
+    g_fallbacks++;
+    rc = gcr_run_once(s, rhs, x, false, hist, hist_cap, n_iter, converged);
+    return rc == MGCR_INT_GAVE_UP ? MGCR_ERR_HIP : rc;
 }
 
 void gcr_set_discard_residual(GcrState *s, bool on) { s->discard_residual = on; }

@@ -624,8 +624,9 @@ void resident_shutdown() {
     if (s.abort_host) hipHostFree(s.abort_host);
     s = ExchangeShared();
 }
-// did a resident solve give up since the last look?  (called where results are handed back to the host)
-int resident_check() {
+// did a resident solve give up since the last look?  (called where results are handed back to the host; gcr_run, which can
+// repeat the solve, asks with internal = true and gets MGCR_INT_GAVE_UP instead of an error for the caller)
+int resident_check(bool internal) {
     ExchangeShared &s = exchange_shared();
     if (s.abort_host && *(volatile int *)s.abort_host != 0) {
         *(volatile int *)s.abort_host = 0;
@@ -633,11 +634,55 @@ int resident_check() {
         // whatever kept the launch from being co-resident may still be there: this process stays with the multi-kernel paths
         set_resident_enabled(false);
         set_stepbuild_enabled(false);
+        if (internal) return MGCR_INT_GAVE_UP;
         set_error("one-launch solver kernel: a workgroup waited too long for the others (the launch was not co-resident); its results were "
-                  "poisoned with NaN.  The one-launch paths are now off in this process: solve again");
+                  "poisoned with NaN.  The one-launch paths are now off in this process: repeat the operation (GCR::solve repeats itself; "
+                  "this came from an operator apply or a V-cycle whose output the library does not own)");
         return MGCR_ERR_HIP;
     }
     return MGCR_OK;
+}
+bool one_launch_paths_enabled() { return resident_enabled() || stepbuild_is_enabled(); }
+
+// which instantiation a solve launches, with how much dynamic LDS, on how many workgroups (shared by the eligibility test,
+// which asks the runtime whether that launch is co-resident, and the launch itself)
+struct ResidentPlan {
+    const void *kernel;
+    size_t lds_bytes;
+    unsigned grid;
+    int threads, tile_h, g;
+};
+static ResidentPlan resident_plan(const CsrDev &M, int storage, int restart, int max_it) {
+    ResidentPlan pl{};
+    const int64_t n = M.nrow;
+    pl.g = red_grid(n);
+    pl.grid = (unsigned)(pl.g >= 64 ? (pl.g + 7) / 8 * 8 : pl.g);
+    static const bool tile_on = !(getenv("MGCR_RESIDENT_TILE") && atoi(getenv("MGCR_RESIDENT_TILE")) == 0);
+    const bool tile = tile_on && csr_stencil_active(M) && !M.sten_rare && sten_slots(M) == 7 && M.sten_near_f == 0x3eu && M.sten_halo_f > 0 &&
+                      M.sten_halo_f <= RES_TILE_HALO;
+    pl.tile_h = tile ? M.sten_halo_f : 0;
+    pl.lds_bytes = tile ? sizeof(cplx) * (size_t)(RED_THREADS + 2 * pl.tile_h) : csr_stencil_active(M) ? 0 : row_mat_lds_bytes(M);
+    const int R = storage <= 5 && (restart == 5 || max_it < restart) ? 5 : 10;
+    static const int rpt_env = getenv("MGCR_RESIDENT_RPT") ? atoi(getenv("MGCR_RESIDENT_RPT")) : 0;
+    int rpt = rpt_env == 1 || rpt_env == 2 || rpt_env == 4 ? rpt_env : RES_RPT_DEFAULT;
+#define RES_K(MODE, NS, RR, RPT) ((const void *)gcr_resident_kernel<MODE, NS, RR, RPT>)
+#ifdef MGCR_RES_ALL_RPT   /* experiments: one and four rows per thread as well (build with EXTRA=-DMGCR_RES_ALL_RPT) */
+#define RES_K_R(MODE, NS, RR) (rpt == 1 ? RES_K(MODE, NS, RR, 1) : rpt == 2 ? RES_K(MODE, NS, RR, 2) : RES_K(MODE, NS, RR, 4))
+#else
+    rpt = 2;
+#define RES_K_R(MODE, NS, RR) RES_K(MODE, NS, RR, 2)
+#endif
+#define RES_K_M(MODE, NS) (R == 5 ? RES_K_R(MODE, NS, 5) : RES_K_R(MODE, NS, 10))
+    if (tile) pl.kernel = RES_K_M(6, 7);
+    else if (csr_stencil_active(M)) pl.kernel = sten_slots(M) == 7 ? RES_K_M(3, 7) : RES_K_M(3, 9);
+    else if (M.pat_mode == 1) pl.kernel = RES_K_M(1, 0);
+    else if (M.pat_mode == 2) pl.kernel = RES_K_M(2, 0);
+    else pl.kernel = RES_K_M(0, 0);
+#undef RES_K_M
+#undef RES_K_R
+#undef RES_K
+    pl.threads = RED_THREADS / rpt;
+    return pl;
 }
 
 bool gcr_resident_eligible(const Op *A, const mgcr_gcr_param &p, int storage, int restart, int64_t n, bool lean, bool nested_handoff) {
@@ -656,12 +701,16 @@ bool gcr_resident_eligible(const Op *A, const mgcr_gcr_param &p, int storage, in
     const bool never_closes = max_it < restart;
     if (storage > 10) return false;
     if (!never_closes && !(restart == storage && (restart == 5 || restart == 10))) return false;
+    // every step consumes three exchange generations: the counter is 32 bits wide (exchange_take_generations)
+    if (max_it > (1 << 28)) return false;
     if (exchange_shared_init() != MGCR_OK) return false;
-    const int g = red_grid(n);
-    const int grid = g >= 64 ? (g + 7) / 8 * 8 : g;
+    const ResidentPlan pl = resident_plan(M, storage, restart, max_it);
     int cus = exchange_shared().cus;
-    if (cus > 256) cus = 256;   // one workgroup per CU
-    return (int64_t)g * RED_THREADS >= n && grid <= cus;
+    if (cus > 256) cus = 256;   // one workgroup per CU by design (two rows per thread, the Krylov vectors in registers)
+    if ((int64_t)pl.g * RED_THREADS < n || (int)pl.grid > cus) return false;
+    // the workgroups wait for each other: the whole grid has to be on the chip at once — asked of the runtime for the
+    // instantiation that would run (gcr_stepbuild.hip launch_is_coresident)
+    return launch_is_coresident(pl.kernel, pl.threads, pl.lds_bytes, (int)pl.grid);
 }
 
 int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, const cplx *rhs, cplx *x, bool from_zero, bool alpha_only_last,
@@ -682,10 +731,8 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     a.storage = storage;
     a.from_zero = from_zero ? 1 : 0;
     a.alpha_only_last = alpha_only_last ? 1 : 0;
-    static const bool tile_on = !(getenv("MGCR_RESIDENT_TILE") && atoi(getenv("MGCR_RESIDENT_TILE")) == 0);
-    const bool tile = tile_on && csr_stencil_active(M) && !M.sten_rare && sten_slots(M) == 7 && M.sten_near_f == 0x3eu && M.sten_halo_f > 0 &&
-                      M.sten_halo_f <= RES_TILE_HALO;
-    a.tile_h = tile ? M.sten_halo_f : 0;
+    const ResidentPlan pl = resident_plan(M, storage, restart, a.max_it);
+    a.tile_h = pl.tile_h;
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     a.test_stall = getenv("MGCR_TEST_RESIDENT_STALL") ? atoi(getenv("MGCR_TEST_RESIDENT_STALL")) : 0;
     {   // how far a row's gathers go: exactly for the stencil view, CsrDev::reach otherwise (0 = unknown: every workgroup)
@@ -701,33 +748,9 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
     static unsigned long long *dbg = nullptr;
     if (timing && !dbg) { MGCR_HIP(hipMalloc((void **)&dbg, 16 * sizeof(unsigned long long))); }
     a.dbg = timing ? dbg : nullptr;
-    a.gen0 = exchange_take_generations(3u * (unsigned)a.max_it + 4u);
-    const unsigned grid = (unsigned)(g >= 64 ? (g + 7) / 8 * 8 : g);
-    const int R = storage <= 5 && (restart == 5 || a.max_it < restart) ? 5 : 10;
-    static const int rpt_env = getenv("MGCR_RESIDENT_RPT") ? atoi(getenv("MGCR_RESIDENT_RPT")) : 0;
-    const int rpt = rpt_env == 1 || rpt_env == 2 || rpt_env == 4 ? rpt_env : RES_RPT_DEFAULT;
-    const size_t lds_bytes = tile ? sizeof(cplx) * (size_t)(RED_THREADS + 2 * a.tile_h) : csr_stencil_active(M) ? 0 : row_mat_lds_bytes(M);
-#define RES_LAUNCH(MODE, NS, RR, RPT) \
-    hipLaunchKernelGGL((gcr_resident_kernel<MODE, NS, RR, RPT>), dim3(grid), dim3(RED_THREADS / RPT), lds_bytes, ctx().stream, a)
-#ifdef MGCR_RES_ALL_RPT   /* experiments: one and four rows per thread as well (build with EXTRA=-DMGCR_RES_ALL_RPT) */
-#define RES_LAUNCH_R(MODE, NS, RR)                             \
-    do {                                                       \
-        if (rpt == 1) RES_LAUNCH(MODE, NS, RR, 1);             \
-        else if (rpt == 2) RES_LAUNCH(MODE, NS, RR, 2);        \
-        else RES_LAUNCH(MODE, NS, RR, 4);                      \
-    } while (0)
-#else
-#define RES_LAUNCH_R(MODE, NS, RR) do { (void)rpt; RES_LAUNCH(MODE, NS, RR, 2); } while (0)
-#endif
-#define RES_LAUNCH_M(MODE, NS) do { if (R == 5) RES_LAUNCH_R(MODE, NS, 5); else RES_LAUNCH_R(MODE, NS, 10); } while (0)
-    if (tile) RES_LAUNCH_M(6, 7);
-    else if (csr_stencil_active(M)) { if (sten_slots(M) == 7) RES_LAUNCH_M(3, 7); else RES_LAUNCH_M(3, 9); }
-    else if (M.pat_mode == 1) RES_LAUNCH_M(1, 0);
-    else if (M.pat_mode == 2) RES_LAUNCH_M(2, 0);
-    else RES_LAUNCH_M(0, 0);
-#undef RES_LAUNCH_M
-#undef RES_LAUNCH_R
-#undef RES_LAUNCH
+    a.gen0 = exchange_take_generations(3u * (unsigned)a.max_it + 4u);   // (max_it <= 2^28: gcr_resident_eligible)
+    void *kargs[1] = {(void *)&a};
+    MGCR_HIP(hipLaunchKernel(pl.kernel, dim3(pl.grid), dim3(pl.threads), kargs, pl.lds_bytes, ctx().stream));
     MGCR_HIP(hipGetLastError());
     g_resident_solves++;
     if (timing) {   // development aid: where the steps of this solve spent their time (workgroup 0)
@@ -740,6 +763,110 @@ int gcr_resident_run(Op *A, const mgcr_gcr_param &p, int storage, int restart, c
         for (int q = 0; q < 8; q++) fprintf(stderr, " [%s] %.1f + %.1f us", names[q], (double)h[q] * 0.01, (double)h[q + 8] * 0.01);
         fprintf(stderr, " (totals over the steps at cycle positions 0-4 + 5-9)\n");
     }
+    return MGCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Self-test of what the one-launch paths rely on (mgcr_selftest_coherence): rows written by one workgroup with
+// `buffer_store ... sc1` (+ s_waitcnt) are seen by workgroups of OTHER XCDs through `buffer_load ... sc1` after nothing
+// but this file's fence-free exchange in between.  That is hardware behaviour the HIP memory model does not promise, so it
+// is checked on the chip and by every GPU test run, with the library's own primitives (st_coh / ld_coh, res_contrib /
+// res_publish / res_collect) and the bounded polls of the solvers: `steps` times, every thread adds (1, -1) to the entry
+// `shift` rows away in the vector the previous step wrote (a far gather: other workgroups, other XCDs), ping-pong between two
+// vectors; the host knows what every entry must be after `steps` steps.  coherent = 0 runs the same steps with ordinary
+// loads and stores (which the L2s of the 8 XCDs do not keep coherent inside a launch): the control that shows the test can fail.
+// ------------------------------------------------------------------------------------------------
+struct CohArgs {
+    cplx *a, *b;
+    int n, shift, steps, coherent, nblk;
+    v4i *slots;
+    unsigned gen0;
+    unsigned *abort_dev;
+    int *abort_host;
+    int spin_limit;
+};
+__global__ void __launch_bounds__(RED_THREADS) coherence_selftest_kernel(CohArgs a) {
+    __shared__ double lds_pw[RES_NV * 17], lds_ws[RES_NV * RES_GRP];
+    __shared__ int gave_up;
+    ResSync sy;
+    sy.slots = res_rsrc(a.slots, (unsigned)RES_SLOT_BYTES);
+    sy.gen = a.gen0;
+    sy.nblk = a.nblk;
+    sy.lb = (int)blockIdx.x;
+    sy.abort_dev = a.abort_dev;
+    sy.spin_limit = a.spin_limit;
+    sy.pw = lds_pw;
+    sy.ws = lds_ws;
+    sy.gave_up = &gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    __syncthreads();
+    const int i = (int)blockIdx.x * RED_THREADS + (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t ra = res_rsrc(a.a, (unsigned)a.n * 16u), rb = res_rsrc(a.b, (unsigned)a.n * 16u);
+    for (int r = 0; r < a.steps; r++) {
+        const int j = (int)(((int64_t)i + a.shift) % a.n);
+        if (i < a.n) {
+            cplx v;
+            if (a.coherent) v = ld_coh((r & 1) ? rb : ra, j, 0);
+            else v = ((r & 1) ? a.b : a.a)[j];
+            v.x += 1.; v.y -= 1.;
+            if (a.coherent) st_coh((r & 1) ? ra : rb, i, 0, v);
+            else ((r & 1) ? a.a : a.b)[i] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged before the workgroup publishes (as in the solvers)
+        double one[1] = {1.};
+        res_contrib<1>(sy, 0, one, (int)threadIdx.x >> 6);
+        res_publish<1>(sy, 1);
+        if (!res_collect<1>(sy, 1)) {
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(a.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.abort_host, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+}
+// rows_wrong: entries that are not what `steps` coherent steps must leave (-1: the launch gave up / was not co-resident)
+int coherence_selftest(int steps, int coherent, int64_t *rows_wrong) {
+    MGCR_CHECK(steps >= 1 && steps <= 100000 && rows_wrong, MGCR_ERR_INVALID, "mgcr_selftest_coherence: 1..100000 steps");
+    MGCR_TRY(exchange_shared_init());
+    ExchangeShared &sh = exchange_shared();
+    const int cus = sh.cus > 256 ? 256 : sh.cus;
+    const int nblk = cus >= 64 ? cus / 8 * 8 : cus;   // one workgroup per CU
+    *rows_wrong = -1;
+    if (!launch_is_coresident((const void *)coherence_selftest_kernel, RED_THREADS, 0, nblk)) {
+        set_error("mgcr_selftest_coherence: %d workgroups are not co-resident on this device", nblk);
+        return MGCR_ERR_UNSUPPORTED;
+    }
+    const int n = nblk * RED_THREADS, shift = 77777 % n;
+    cplx *a = nullptr, *b = nullptr;
+    MGCR_HIP(hipMalloc((void **)&a, sizeof(cplx) * (size_t)n));
+    MGCR_HIP(hipMalloc((void **)&b, sizeof(cplx) * (size_t)n));
+    std::vector<cplx> h((size_t)n);
+    for (int i = 0; i < n; i++) h[(size_t)i] = make_double2((double)i, -(double)i);
+    MGCR_HIP(hipMemcpyAsync(a, h.data(), sizeof(cplx) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
+    MGCR_HIP(hipMemsetAsync(b, 0xff, sizeof(cplx) * (size_t)n, ctx().stream));
+    CohArgs ca;
+    ca.a = a; ca.b = b; ca.n = n; ca.shift = shift; ca.steps = steps; ca.coherent = coherent; ca.nblk = nblk;
+    ca.slots = sh.slots; ca.abort_dev = sh.abort_dev; ca.abort_host = sh.abort_host;
+    ca.gen0 = exchange_take_generations((unsigned)steps + 1u);
+    ca.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
+    hipLaunchKernelGGL(coherence_selftest_kernel, dim3((unsigned)nblk), dim3(RED_THREADS), 0, ctx().stream, ca);
+    MGCR_HIP(hipGetLastError());
+    MGCR_HIP(hipMemcpyAsync(h.data(), (steps & 1) ? b : a, sizeof(cplx) * (size_t)n, hipMemcpyDeviceToHost, ctx().stream));
+    MGCR_HIP(hipStreamSynchronize(ctx().stream));
+    hipFree(a); hipFree(b);
+    if (*(volatile int *)sh.abort_host != 0) {   // (the self-test's own give-up: does not switch the solvers' paths off)
+        *(volatile int *)sh.abort_host = 0;
+        MGCR_HIP(hipMemsetAsync(sh.abort_dev, 0, sizeof(unsigned), ctx().stream));
+        set_error("mgcr_selftest_coherence: a workgroup waited too long for the others");
+        return MGCR_ERR_HIP;
+    }
+    int64_t bad = 0;
+    for (int i = 0; i < n; i++) {
+        const double want = (double)(((int64_t)i + (int64_t)steps * shift) % n) + steps;
+        if (h[(size_t)i].x != want || h[(size_t)i].y != -(want - steps) - steps) bad++;
+    }
+    *rows_wrong = bad;
     return MGCR_OK;
 }
 

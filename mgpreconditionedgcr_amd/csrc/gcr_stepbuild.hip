@@ -283,6 +283,7 @@ static bool stepbuild_enabled() {
     if (g_stepbuild < 0) g_stepbuild = !(getenv("MGCR_STEPBUILD") && atoi(getenv("MGCR_STEPBUILD")) == 0);
     return g_stepbuild != 0;
 }
+bool stepbuild_is_enabled() { return stepbuild_enabled(); }
 bool set_stepbuild_enabled(bool on) {
     bool prev = stepbuild_enabled();
     g_stepbuild = on ? 1 : 0;
@@ -290,6 +291,46 @@ bool set_stepbuild_enabled(bool on) {
 }
 static int64_t g_stepbuild_launches = 0;
 int64_t stepbuild_launch_count() { return g_stepbuild_launches; }
+
+// the instantiation a step with `nd` stored directions launches
+static const void *sb_kernel(int nd, bool xr, bool close) {
+#define SBK(NDT) (close ? (xr ? (const void *)step_build_kernel<3, 7, NDT, true, true> : (const void *)step_build_kernel<3, 7, NDT, false, true>) \
+                        : (xr ? (const void *)step_build_kernel<3, 7, NDT, true, false> : (const void *)step_build_kernel<3, 7, NDT, false, false>))
+    switch (nd) {
+        case 1: return SBK(1);
+        case 2: return SBK(2);
+        case 3: return SBK(3);
+        case 4: return SBK(4);
+        default: return SBK(5);
+    }
+#undef SBK
+}
+// Do `grid` workgroups of this instantiation, with this much dynamic LDS, fit the chip AT ONCE?  The workgroups wait for each
+// other inside the launch, so the answer has to come from the runtime (registers and LDS of the code object that was actually
+// built: another compiler, -DMGCR_RES_TIMING, ... change them), not from arithmetic on what the kernel is meant to need.
+// Asked once per instantiation and LDS size.  (What the runtime cannot know — CUs held by another process — is what the bounded
+// polls and gcr_run's repeat are for.)
+bool launch_is_coresident(const void *kernel, int threads, size_t dyn_lds, int grid) {
+    struct Key { const void *k; size_t lds; int threads; int per_cu; };
+    static std::vector<Key> seen;
+    int per_cu = -1;
+    for (const Key &e : seen)
+        if (e.k == kernel && e.lds == dyn_lds && e.threads == threads) per_cu = e.per_cu;
+    if (per_cu < 0) {
+        if (dyn_lds > 0) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dyn_lds > 64 * 1024 ? dyn_lds : 64 * 1024));
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, dyn_lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        per_cu = nb;
+        seen.push_back(Key{kernel, dyn_lds, threads, per_cu});
+    }
+    static const int force = getenv("MGCR_TEST_OCCUPANCY") ? atoi(getenv("MGCR_TEST_OCCUPANCY")) : -1;   // tests: pretend the runtime said so
+    if (force >= 0) per_cu = force;
+    return exchange_shared_init() == MGCR_OK && (int64_t)per_cu * exchange_shared().cus >= grid;
+}
+
+static size_t sb_lds_bytes(const CsrDev &A, int g) {
+    return sizeof(cplx) * RED_THREADS * (size_t)((A.nrow + (int64_t)g * RED_THREADS - 1) / ((int64_t)g * RED_THREADS));
+}
 
 // can step `lim` of a lean cycle on A run as one launch?  (single GPU, 7-slot stencil view, <= 5 stored directions, A r in LDS)
 bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim) {
@@ -300,7 +341,13 @@ bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim) {
     if ((int64_t)g * RED_THREADS * SB_MAX_TRIPS < A.nrow) return false;
     if (A.reach >= ((int64_t)1 << 15)) return false;   // rows that reach this far take the LDS-window kernels (gcr_fused.hip)
     if (exchange_shared_init() != MGCR_OK) return false;
-    return g <= 2 * exchange_shared().cus && g <= RES_BLK;
+    if (g > RES_BLK) return false;
+    // every form the step may be launched in (with / without the next residual update, closing or not) must be co-resident
+    const size_t lds = sb_lds_bytes(A, g);
+    for (int xr = 0; xr < 2; xr++)
+        for (int cl = 0; cl < 2; cl++)
+            if (!launch_is_coresident(sb_kernel(lim, xr != 0, cl != 0), RED_THREADS, lds, g)) return false;
+    return true;
 }
 
 int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cplx *const *aps, int nd, DevState *st, int it, const double *partsR,
@@ -328,30 +375,11 @@ int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cpl
     a.test_stall = getenv("MGCR_TEST_STEPBUILD_STALL") ? atoi(getenv("MGCR_TEST_STEPBUILD_STALL")) : 0;
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     const unsigned grid = (unsigned)g;
-    const size_t lds_bytes = sizeof(cplx) * RED_THREADS * (size_t)((A.nrow + (int64_t)g * RED_THREADS - 1) / ((int64_t)g * RED_THREADS));
-#define SB1(NDT, XRF, CL)                                                                                                          \
-    do {                                                                                                                           \
-        static bool big_lds = false;   /* 64 KB of dynamic LDS: above the default limit */                                          \
-        if (!big_lds) {                                                                                                            \
-            MGCR_HIP(hipFuncSetAttribute((const void *)step_build_kernel<3, 7, NDT, XRF, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-            big_lds = true;                                                                                                        \
-        }                                                                                                                          \
-        hipLaunchKernelGGL((step_build_kernel<3, 7, NDT, XRF, CL>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, a);    \
-    } while (0)
-#define SB(NDT)                                                                    \
-    do {                                                                           \
-        if (close_ps) { if (xr_out) SB1(NDT, true, true); else SB1(NDT, false, true); }   \
-        else { if (xr_out) SB1(NDT, true, false); else SB1(NDT, false, false); }          \
-    } while (0)
-    switch (nd) {
-        case 1: SB(1); break;
-        case 2: SB(2); break;
-        case 3: SB(3); break;
-        case 4: SB(4); break;
-        default: SB(5); break;
-    }
-#undef SB1
-#undef SB
+    const size_t lds_bytes = sb_lds_bytes(A, g);
+    const void *kernel = sb_kernel(nd, xr_out != nullptr, close_ps != nullptr);
+    MGCR_CHECK(launch_is_coresident(kernel, RED_THREADS, lds_bytes, g), MGCR_ERR_INVALID, "csr_step_build: launch would not be co-resident");
+    void *kargs[1] = {(void *)&a};
+    MGCR_HIP(hipLaunchKernel(kernel, dim3(grid), dim3(RED_THREADS), kargs, lds_bytes, ctx().stream));
     MGCR_HIP(hipGetLastError());
     g_stepbuild_launches++;
     return MGCR_OK;

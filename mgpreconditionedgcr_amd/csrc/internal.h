@@ -66,6 +66,10 @@ struct Vec {
     int64_t n = 0;
     cplx *d = nullptr;
     bool owns = true;
+    // set by mgcr_vec_zero, cleared by whatever writes the Field next (every writer takes the pointer through w()): a solve
+    // that has to be repeated on another kernel path (gcr.hip gcr_run) then re-zeroes x instead of keeping a copy of it
+    bool zero_known = false;
+    cplx *w() { zero_known = false; return d; }
 };
 
 enum OpKind { OP_CSR = 1, OP_DIRAC = 2, OP_BCSR = 3, OP_GCR = 4, OP_MG = 5 };
@@ -169,11 +173,17 @@ bool set_lean_enabled(bool on);
 bool set_fuse_enabled(bool on);
 bool set_graph_enabled(bool on);
 bool set_resident_enabled(bool on);   // gcr_resident.hip: whole small solves in one launch
-int resident_check();                  // did such a solve give up (launch not co-resident)?  Called at host synchronisation points
+constexpr int MGCR_INT_GAVE_UP = 1001;   // internal status: a one-launch path gave up (gcr_run repeats the solve; never leaves the library)
+int resident_check(bool internal = false);   // did such a solve give up (launch not co-resident)?  Called at host synchronisation points
+                                       // (internal: MGCR_INT_GAVE_UP instead of MGCR_ERR_HIP + message)
 void resident_shutdown();
 int64_t resident_solve_count();
 bool set_stepbuild_enabled(bool on);   // gcr_stepbuild.hip: apply + dots + build of a lean step as one launch
 int64_t stepbuild_launch_count();
+int coherence_selftest(int steps, int coherent, int64_t *rows_wrong);   // gcr_resident.hip
+bool stepbuild_is_enabled();
+bool launch_is_coresident(const void *kernel, int threads, size_t dyn_lds, int grid);   // gcr_stepbuild.hip: asks the runtime
+bool one_launch_paths_enabled();       // either of the two above
 // y = A x   or (shift) y = w - k*(A x) with w = x unless given (w = b, k = 1: the residual b - A x in one pass);
 // dist != nullptr: row block with halo exchange
 int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistCsr *dist = nullptr, const cplx *w = nullptr);
@@ -259,7 +269,8 @@ bool gcr_take_pending(GcrState *s, PendingX *out);
 int gcr_flush_pending(const PendingX &pd, cplx *x, int64_t n);  // nested solves whose caller never looks at the final residual
 int gcr_run_from_zero(GcrState *s, const cplx *rhs, cplx *x);  // nested, x0 = 0, x's content on entry is irrelevant
 int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, int hist_cap, int *n_iter,
-            int *converged);
+            int *converged, bool x_known_zero = false);
+int64_t gcr_fallback_count();   // solves that were repeated on the multi-kernel path after a one-launch path gave up
 void gcr_state_set_use_x0(GcrState *s, bool use_x0);
 int gcr_state_set_param(GcrState *s, const mgcr_gcr_param *p);
 int gcr_apply_as_operator(GcrState *s, const cplx *f, cplx *y);

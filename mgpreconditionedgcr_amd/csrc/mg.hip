@@ -380,7 +380,7 @@ int mgcr_mg_restrict(mgcr_op_t mg, int32_t level, mgcr_vec_t fine, mgcr_vec_t co
     const MgLevel &L = mg->mg->lev[(size_t)level];
     MGCR_CHECK(fine->n == L.n && coarse->n == L.nagg * L.ne, MGCR_ERR_INVALID, "Lengths of two fields do not match!");
     LOCK();
-    return mg_restrict(mg->mg, level, fine->d, coarse->d, nullptr);
+    return mg_restrict(mg->mg, level, fine->d, coarse->w(), nullptr);
 }
 
 int mgcr_mg_expand(mgcr_op_t mg, int32_t level, mgcr_vec_t coarse, mgcr_vec_t fine) {
@@ -390,7 +390,7 @@ int mgcr_mg_expand(mgcr_op_t mg, int32_t level, mgcr_vec_t coarse, mgcr_vec_t fi
     const MgLevel &L = mg->mg->lev[(size_t)level];
     MGCR_CHECK(fine->n == L.n && coarse->n == L.nagg * L.ne, MGCR_ERR_INVALID, "Lengths of two fields do not match!");
     LOCK();
-    return mg_expand(mg->mg, level, coarse->d, fine->d, false, 1.0, nullptr);
+    return mg_expand(mg->mg, level, coarse->d, fine->w(), false, 1.0, nullptr);
 }
 
 int mgcr_mg_level_op(mgcr_op_t mg, int32_t level, mgcr_op_t *out) {

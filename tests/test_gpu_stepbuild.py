@@ -68,8 +68,10 @@ def test_step_build_stops_like_the_two_kernels():
 
 
 def test_step_build_gives_up_instead_of_hanging():
-    """a workgroup that never publishes (told to leave at once) must not leave the other 511 spinning: bounded polls, NaN
-    results, an error at the next host synchronisation.  Child process: the switches are read from the environment once."""
+    """a workgroup that never publishes (told to leave at once) must not leave the other 511 spinning: bounded polls, and
+    GCR::solve repeats the solve on the three-kernel path inside the library — the FIRST call returns a finite, correct x
+    (bit for bit the three-kernel result), for a Field known to be zero and for an x0 the library had to keep a copy of.
+    Child process: the switches are read from the environment once."""
     import subprocess
     code = r'''
 import sys
@@ -82,24 +84,29 @@ N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
 A = mg.Sparse(N, ncol, rowptr, col, val)
 g = mg.GCR(A, mg.GCR_Param(0, 5, 12, 1e-30, False))
 b = mg.Field((n, n, n)).fill_rhs(0)
-x = mg.Field((n, n, n)).set_zero()
-try:
-    g.solve(b, x)          # the solve itself reports it (gcr_run ends with the check)
-    print("NO-ERROR")
-except mg.MgcrError as e:
-    print("ERROR:", e)
+x0 = problems.rhs_grid(N, 3)
+x = mg.Field((n, n, n), x0)
+f0, l0 = mg.stat("one_launch_fallbacks"), mg.stat("step_build_launches")
+g.solve(b, x)              # the first one-launch step gives up; the solve is repeated from the copy of x0
+first = (mg.stat("one_launch_fallbacks") - f0, mg.stat("step_build_launches") - l0, x.to_numpy(), g.last_history.copy(), g.last_iterations)
 print("LIBRARY-USABLE" if mg.lib().mgcr_synchronize() == 0 else "STILL-FAILING")
-# the one-launch paths switched themselves off: the same solve now goes through (the stalled workgroup was theirs)
-x.set_zero()
-g.solve(b, x)
-print("RETRY-OK" if np.isfinite(x.to_numpy()).all() and g.last_iterations == 12 and mg.stat("step_build_launches") > 0 else "RETRY-BAD")
+x = mg.Field((n, n, n), x0)
+l1 = mg.stat("step_build_launches")
+g.solve(b, x)              # the three-kernel path (the one-launch paths switched themselves off)
+print("fallbacks", first[0], "launches", first[1], "then", mg.stat("step_build_launches") - l1)
+ok = np.isfinite(first[2]).all() and np.array_equal(first[2], x.to_numpy()) and np.array_equal(first[3], g.last_history) and first[4] == 12
+r = b.to_numpy() - A(mg.Field((n, n, n), first[2] - x0)).to_numpy()      # r0 = b whatever x0 is (src/GCR.h:189): x - x0 solves A y = b
+ok = ok and abs(np.linalg.norm(r) / np.linalg.norm(b.to_numpy()) - first[3][-1]) <= 1e-6 * first[3][-1]
+print("FIRST-CALL-RIGHT" if ok else "FIRST-CALL-WRONG")
 '''
     env = dict(os.environ, MGCR_TEST_STEPBUILD_STALL="7", MGCR_TEST_RESIDENT_SPIN_LIMIT="20000")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180,
                          cwd=os.path.join(os.path.dirname(__file__), ".."))
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "ERROR:" in out.stdout and "co-resident" in out.stdout, out.stdout
-    assert "LIBRARY-USABLE" in out.stdout and "RETRY-OK" in out.stdout, out.stdout
+    assert "LIBRARY-USABLE" in out.stdout and "FIRST-CALL-RIGHT" in out.stdout, out.stdout
+    import re
+    m = re.search(r"fallbacks (\d+) launches (\d+) then (\d+)", out.stdout)
+    assert m and int(m.group(1)) == 1 and int(m.group(2)) >= 1 and int(m.group(3)) == 0, out.stdout
 
 
 def test_vcycle_with_one_launch_smoother_steps_is_bit_identical():
