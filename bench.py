@@ -84,20 +84,43 @@ def run_launcher(args, argv):
     0's line through, exit non-zero if any rank failed."""
     procs = []
     for r, (cmd, env) in enumerate(launcher_plan(args.gpus, argv, free_port())):
-        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+        # every rank leads a process group of its own: the GPU-holding worker is the supervisor's CHILD, and ending a rank
+        # must end that worker too (a killed supervisor would otherwise leave it running with the device)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
     rc = 0
-    deadline = time.time() + sum(ATTEMPT_TIMEOUT_S) + 300
+    deadline = time.time() + launcher_deadline_s()
     pending = list(procs)
-    while pending and time.time() < deadline:
-        for p in list(pending):
-            if p.poll() is not None:
-                pending.remove(p)
-                rc = rc or p.returncode
-        time.sleep(0.2)
-    for p in pending:   # the exact processes started above
-        p.kill()
-        rc = rc or 1
+    try:
+        while pending and time.time() < deadline:
+            for p in list(pending):
+                if p.poll() is not None:
+                    pending.remove(p)
+                    rc = rc or p.returncode
+            time.sleep(0.2)
+    finally:
+        for p in procs:   # the exact process groups started above (a rank that has exited may have left its worker behind)
+            if p in pending:
+                rc = rc or 1
+            end_process_group(p)
     return 1 if rc else 0
+
+
+def launcher_deadline_s():
+    return float(os.environ.get("MGCR_BENCH_LAUNCHER_DEADLINE_S", sum(ATTEMPT_TIMEOUT_S) + 300))
+
+
+def end_process_group(p):
+    """SIGKILL the process group `p` leads (it was started with start_new_session=True) — the process and whatever it
+    started — and reap p.  Harmless when everything has already exited."""
+    import signal
+    try:
+        os.killpg(p.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        p.wait(timeout=10)
+    except Exception:
+        pass
 
 
 def worker_command(argv, port, mode_env, base_env=None):
@@ -148,23 +171,30 @@ def run_supervisor(args, argv):
             p = subprocess.Popen(cmd, env=env, stdout=f_out, stderr=f_err, text=True)
             # The supervisors poll in lockstep: as soon as ONE worker has failed (or run out of time) every supervisor ends its
             # own — a rank that died at start-up must not leave the others waiting in a rendezvous until the time limit.
-            while True:
-                rc = p.poll()
-                if rc is None and time.time() - t0 > limit:
+            try:
+                while True:
+                    rc = p.poll()
+                    if rc is None and time.time() - t0 > limit:
+                        p.kill()
+                        p.wait()
+                        rc = -9
+                    st = torch.tensor([1 if rc not in (None, 0) else 0, 1 if rc is not None else 0], dtype=torch.int32)
+                    dist.all_reduce(st)
+                    if int(st[0]) > 0:
+                        if rc is None:
+                            p.kill()       # the exact process started above
+                            p.wait()
+                            rc = -15       # ended because another rank's worker failed
+                        break
+                    if int(st[1]) == world:
+                        break
+                    time.sleep(0.25)
+            finally:
+                # whatever ends this loop — a collective that raises because a peer supervisor died included — the worker
+                # (it holds the GPU) does not outlive it
+                if p.poll() is None:
                     p.kill()
                     p.wait()
-                    rc = -9
-                st = torch.tensor([1 if rc not in (None, 0) else 0, 1 if rc is not None else 0], dtype=torch.int32)
-                dist.all_reduce(st)
-                if int(st[0]) > 0:
-                    if rc is None:
-                        p.kill()       # the exact process started above
-                        p.wait()
-                        rc = -15       # ended because another rank's worker failed
-                    break
-                if int(st[1]) == world:
-                    break
-                time.sleep(0.25)
             f_out.seek(0)
             f_err.seek(0)
             out, err = f_out.read(), f_err.read()

@@ -54,6 +54,13 @@ int main(int argc, char **argv) {
         g.solve(rhs.data(), x.data(), c.tol, c.max_iter, c.trunc);
         wr(d + "/out_x_" + c.tag + ".bin", x);
     }
+    {   // rhs = 0, x0 != 0: the absolute test keeps iterating on r0 = -A x0 (src/GCR.h:85-103)
+        GCR<long> g(A.data(), n);
+        std::vector<cplx> x(x0), rhs0((size_t)n, cplx(0., 0.));
+        std::printf("LEGACY rhs0\n");
+        g.solve(rhs0.data(), x.data(), 1e-12, 30, 4);
+        wr(d + "/out_x_rhs0.bin", x);
+    }
     std::printf("LEGACY end\n");
     return 0;
 }

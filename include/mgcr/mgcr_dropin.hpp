@@ -603,6 +603,22 @@ public:
             for (int k = 1; k <= it; k++) std::printf("Step %d residual norm = %.10e\n", k, hist[(size_t)k] * bn);
             rr = (hist[(size_t)it] * bn) * (hist[(size_t)it] * bn);
             for (num_type i = 0; i < d; i++) x[i] = xf.val_at(i);
+        } else if (rr > tol && max_iter > 0) {
+            // rhs = 0 with x0 != 0: the reference iterates on r0 = -A x0 and drives x towards 0 (its test is absolute).  The
+            // Field solve's test is relative to its right-hand side: hand it r0 AS the right-hand side (r = rhs there whatever
+            // x is, src/GCR.h:189) and let it update x0 in place — the same recurrence, tolerance sqrt(tol) / |r0|
+            mgcr_gcr_param p;
+            std::memset(&p, 0, sizeof(p));
+            const double rn = std::sqrt(rr);
+            p.truncation = truncation; p.restart = 0; p.max_iter = max_iter; p.tol = std::sqrt(tol) / rn;
+            std::vector<double> hist((size_t)max_iter + 1, 0.);
+            int32_t n = 0, conv = 0;
+            mgcr_detail::ok(mgcr_gcr_solve(dense_op, &p, r0.device(), xf.device(), hist.data(), max_iter + 1, &n, &conv), "GCR dense solve");
+            xf.device_written();
+            it = n;
+            for (int k = 1; k <= it; k++) std::printf("Step %d residual norm = %.10e\n", k, hist[(size_t)k] * rn);
+            rr = (hist[(size_t)it] * rn) * (hist[(size_t)it] * rn);
+            for (num_type i = 0; i < d; i++) x[i] = xf.val_at(i);
         }
         if (it == max_iter) std::printf("GCR did not converge after %d steps! Residual norm = %.10e\n", max_iter, rr);
         iterations = it;

@@ -416,6 +416,15 @@ def legacy_dense_gcr(matrix, rhs, x, tol, max_iter, truncation, verbose=True):
         g.solve(b, xf)
         norms = g.last_history[1:] * np.sqrt(bn2)
         rr = float(norms[-1] ** 2)
+    elif rr > tol and max_iter > 0:
+        # rhs = 0 with x0 != 0: the reference iterates on r0 = -A x0 and drives x towards 0 (its test is absolute).  The Field
+        # solve's test is relative to its right-hand side, so hand it r0 AS the right-hand side (r = rhs there whatever x is,
+        # src/GCR.h:189) and let it update x0 in place: the same recurrence, tolerance sqrt(tol) / |r0|
+        g = GCR(A, GCR_Param(int(truncation), 0, int(max_iter), float(np.sqrt(tol) / np.sqrt(rr)), False))
+        rn = np.sqrt(rr)
+        g.solve(r0, xf)
+        norms = g.last_history[1:] * rn
+        rr = float(norms[-1] ** 2)
     if verbose:
         for k, v in enumerate(norms):
             print("Step %d residual norm = %.10e" % (k + 1, v))

@@ -495,6 +495,13 @@ static void case_legacy() {
         g.solve(rhs.data(), xs.data(), 1e6, 10, 2);
         dump_vec("g16_x_zero", xs);
     }
+    {   // rhs = 0, x0 != 0: the absolute test keeps iterating on r0 = -A x0 and x is driven towards 0
+        GCR<long> g(A.data(), d);
+        std::vector<cplx> xs(x), rhs0(d, cplx(0., 0.));
+        printf("LEGACY rhs0\n");
+        g.solve(rhs0.data(), xs.data(), 1e-12, 30, 4);
+        dump_vec("g16_x_rhs0", xs);
+    }
     printf("LEGACY end\n");
     // utils BLAS on the same data
     std::vector<cplx> z(d), y(d), Ax(d), nrm(rhs), sc(4);

@@ -39,10 +39,38 @@ def d(out, name, dtype=np.float64):
     return np.fromfile(os.path.join(out, name + ".bin"), dtype=dtype)
 
 
+def legacy(out):
+    """tests/golden/legacy_dense.npz (harness case `legacy`); `python make_golden.py legacy` regenerates it alone"""
+    stdout, _ = run(out, "legacy")
+    printed, cur = {}, None
+    for line in stdout.splitlines():
+        if line.startswith("LEGACY "):
+            cur = line.split()[1]
+            printed[cur] = []
+        elif line.startswith("Step ") and cur:
+            printed[cur].append(float(line.split("=")[1]))
+        elif line.startswith("GCR did not converge") and cur:
+            printed[cur + "_final_sq"] = [float(line.split("=")[1])]
+    np.savez_compressed(
+        os.path.join(HERE, "legacy_dense.npz"), A=c(out, "g16_A"), rhs=c(out, "g16_rhs"), x0=c(out, "g16_x0"),
+        x_trunc3=c(out, "g16_x_trunc3"), x_trunc8=c(out, "g16_x_trunc8"), x_zero=c(out, "g16_x_zero"), x_rhs0=c(out, "g16_x_rhs0"),
+        printed_trunc3=np.array(printed["trunc3"]), printed_trunc8=np.array(printed["trunc8_tol"]),
+        printed_zero=np.array(printed["zero_steps"]), printed_rhs0=np.array(printed["rhs0"]),
+        final_sq_trunc3=np.array(printed.get("trunc3_final_sq", [])),
+        u_add=c(out, "g16_u_add"), u_amult=c(out, "g16_u_amult"), u_scalars=c(out, "g16_u_scalars"),
+        u_normalised=c(out, "g16_u_normalised"), u_matvec=c(out, "g16_u_matvec"))
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build the harness first: make -C oracle _ref")
     out = tempfile.mkdtemp(prefix="mgcr_gold_")
+    if sys.argv[1:] == ["legacy"]:
+        try:
+            legacy(out)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+        return
     try:
         stdout, _ = run(out, "sample")
         # the printed history of the first (restart-5) solve, as a cross-check of the spy
@@ -150,23 +178,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "arnoldi_4x4.npz"), k=0.1, start=c(out, "g14_start"), vec0=c(out, "g14_vec0"),
                             vec1_x0zero=c(out, "g14_vec1_x0zero"))
 
-        stdout, _ = run(out, "legacy")
-        printed, cur = {}, None
-        for line in stdout.splitlines():
-            if line.startswith("LEGACY "):
-                cur = line.split()[1]
-                printed[cur] = []
-            elif line.startswith("Step ") and cur:
-                printed[cur].append(float(line.split("=")[1]))
-            elif line.startswith("GCR did not converge") and cur:
-                printed[cur + "_final_sq"] = [float(line.split("=")[1])]
-        np.savez_compressed(
-            os.path.join(HERE, "legacy_dense.npz"), A=c(out, "g16_A"), rhs=c(out, "g16_rhs"), x0=c(out, "g16_x0"),
-            x_trunc3=c(out, "g16_x_trunc3"), x_trunc8=c(out, "g16_x_trunc8"), x_zero=c(out, "g16_x_zero"),
-            printed_trunc3=np.array(printed["trunc3"]), printed_trunc8=np.array(printed["trunc8_tol"]),
-            printed_zero=np.array(printed["zero_steps"]), final_sq_trunc3=np.array(printed.get("trunc3_final_sq", [])),
-            u_add=c(out, "g16_u_add"), u_amult=c(out, "g16_u_amult"), u_scalars=c(out, "g16_u_scalars"),
-            u_normalised=c(out, "g16_u_normalised"), u_matvec=c(out, "g16_u_matvec"))
+        legacy(out)
 
         src = os.path.join(REF, "data", "sample_matrix", "4x4parsed.txt")
         with open(src, "rb") as fi, gzip.GzipFile(

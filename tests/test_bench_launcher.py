@@ -114,3 +114,34 @@ def test_a_rank_that_dies_at_start_up_ends_the_attempt_for_everybody(tmp_path):
     assert rcs == [0, 0], outs
     d = bench.last_json_line(outs[0][0])
     assert d["mode"] == "rccl" and [a["ok"] for a in d["launch"]["attempts"]] == [False, True]
+
+
+def test_launcher_ends_the_workers_of_ranks_it_kills(tmp_path, monkeypatch):
+    """At its deadline the launcher ends every rank's whole process GROUP: the GPU-holding worker is the supervisor's child
+    and must not outlive it (a killed supervisor used to leave it running with the device)."""
+    import time
+    import types
+    pidfile = tmp_path / "grandchild.pid"
+    rank = tmp_path / "rank.py"
+    rank.write_text(textwrap.dedent("""
+        import subprocess, sys, time
+        p = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])   # the stand-in worker
+        open(%r, "w").write(str(p.pid))
+        time.sleep(300)                                                                # the supervisor hangs
+    """ % str(pidfile)))
+    monkeypatch.setattr(bench, "launcher_plan", lambda n, argv, port, base_env=None: [([sys.executable, str(rank)], dict(os.environ))] * n)
+    monkeypatch.setenv("MGCR_BENCH_LAUNCHER_DEADLINE_S", "3")
+    t0 = time.time()
+    rc = bench.run_launcher(types.SimpleNamespace(gpus=2), [])
+    assert rc == 1 and time.time() - t0 < 30
+    pid = int(pidfile.read_text())
+    for _ in range(50):        # the grandchild is gone (reaped by init) — not merely orphaned
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        if open("/proc/%d/stat" % pid).read().split()[2] == "Z":
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the worker outlived its supervisor")
