@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "bcsr", "sample", "latency64"]
+EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "irregular_spmv", "poisson128_gcr_general", "bcsr", "bcsr_mg", "sample", "latency64"]
 MG_PARITY_NOTE = ("unpinned: the reference's MG::operator() returns uninitialised memory (src/MG.h:124-129,405-430), so no reference "
                   "output exists; the cycle is checked against the oracle's corrected cycle (tests/test_gpu_mg.py)")
 # transports a multi-GPU run falls back through (environment of the worker processes)
@@ -311,6 +311,21 @@ def pmc_traffic(key, n, lims=None, restart=0):
         if all(v is not None for v in per):
             return sum(per) / len(per), note + ", per kernel, weighted by the kernels the timed iterations launched"
     return d["phase_hbm_bytes_per_launch"].get(key), note + ", average over the launches of the profiled run"
+
+
+def pmc_traffic_workload(name):
+    """(HBM bytes per apply of workload `name` measured by PMC, note): profiles/pmc_traffic.json "workloads" section, only
+    when it was measured on the current kernel sources."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    w = (d.get("workloads") or {}).get(name)
+    if not w:
+        return None, "not measured for this workload"
+    if w.get("src_sha16", d.get("src_sha16")) != source_sha16():
+        return None, "measured on other kernel sources (%s, now %s)" % (w.get("src_sha16", d.get("src_sha16")), source_sha16())
+    return w.get("hbm_bytes_per_apply"), w.get("note", "PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)")
 
 
 def stats(samples):
@@ -896,20 +911,9 @@ def wl_bcsr(args):
     import mgpreconditionedgcr_amd as mg
     from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, HierarchicalSparse
     mg.init(0)
-    rng = np.random.default_rng(5)
     bs, nb = 20, 36000
-    per_row = np.where(rng.random(nb) < 0.8, rng.integers(5, 10, nb), rng.integers(10, 65, nb))
-    rows = np.repeat(np.arange(nb, dtype=np.int32), per_row)
-    cols = rng.integers(0, nb, rows.size).astype(np.int32)
-    first = np.concatenate([[0], np.cumsum(per_row)[:-1]])
-    cols[first] = np.arange(nb, dtype=np.int32)
+    rows, cols, blocks = make_unstructured_blocks(nb, bs)
     nblk = rows.size
-    blocks = np.empty((nblk, bs, bs), np.complex128)
-    for s in range(0, nblk, 20000):
-        e = min(nblk, s + 20000)
-        blocks[s:e] = (rng.uniform(-1, 1, (e - s, bs, bs)) + 1j * rng.uniform(-1, 1, (e - s, bs, bs))) * (0.5 / bs)
-    offsum = np.bincount(rows, weights=np.abs(blocks).sum(axis=(1, 2)) / bs, minlength=nb)
-    blocks[first] = np.eye(bs)[None] * (1.0 + offsum)[:, None, None]
     H = HierarchicalSparse(nb, nb, rows, cols, blocks)
     del blocks
     n = nb * bs
@@ -929,6 +933,202 @@ def wl_bcsr(args):
                          "frac": b_alg / ms["median"] / 1e6 / HBM_PEAK_GBS, "traffic": None},
             "gcr_iterations": gcr.last_iterations, "gcr_converged": gcr.last_converged, "gcr_seconds": sv["median"], "gcr_timing_seconds": sv,
             "gcr_it_per_s": gcr.last_iterations / sv["median"], "true_rel_residual": r.norm() / rhs.norm()}
+
+
+def wl_irregular_spmv(args):
+    """north_star's layout for GENERAL matrices measured at HBM scale: an irregular scalar CSR of ~2 GB —
+    80 % of the rows 5-9 entries, 20 % 10-64, a handful of rows ~2000 — stored as ELL slab + CSR tail.  The two kernels of the
+    hybrid are timed separately (mgcr_set_option("spmv_part")) and together, cold (a 512 MiB copy sweeps the caches between
+    applies).  Reference apply: src/Operator.h:330-346.  Checks at full size: ELL part + tail part == the whole apply bit for
+    bit, and 2000 sampled rows against a host loop in the reference's order."""
+    import numpy as np
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, Sparse, problems
+    mg.init(0)
+    N = int(os.environ.get("MGCR_BENCH_IRREGULAR_ROWS", 8 * 1024 * 1024))
+    rng = np.random.default_rng(12)
+    t0 = time.perf_counter()
+    window = int(os.environ.get("MGCR_BENCH_IRREGULAR_WINDOW", 1 << 17))
+    rowptr, col, val = problems.skewed_csr(N, rng, window=window, long_rows=64)
+    gen_s = time.perf_counter() - t0
+    nnz = int(rowptr[-1])
+    t0 = time.perf_counter()
+    A = Sparse(N, N, rowptr, col, val)
+    build_s = time.perf_counter() - t0
+    lay, stored = A.ell_layout(), A.stored_bytes()
+    fmt, npat = A.storage_format()
+    W, tail_nnz, tail_rows = lay["ell_width"], stored["tail_nnz"], lay["tail_rows"]
+    lens = np.diff(rowptr)
+    ell_nnz = int(np.minimum(lens, W).sum())
+    npad = (N + 63) // 64 * 64
+    b_ell = npad * W * 20 + 32 * N                       # slab (values + int32 columns, padding included) + x read once + y written
+    b_tail = tail_nnz * 20 + tail_rows * (8 + 4 + 32)     # entries + (row id, pointer, y read-modify-write) per tail row; x is booked with the ELL part
+    xf, yf, y1 = Field((N,)).fill_rhs(0), Field((N,)), Field((N,))
+    A(xf, out=yf)
+    # parts: ELL kernel then tail kernel into the same y == the whole apply
+    mg.set_option("spmv_part", 1); A(xf, out=y1)
+    mg.set_option("spmv_part", 2); A(xf, out=y1)
+    mg.set_option("spmv_part", 0)
+    yh = yf.to_numpy()
+    parts_equal = bool(np.array_equal(yh, y1.to_numpy()))
+    xh = xf.to_numpy()
+    worst = 0.0
+    for r in np.concatenate([rng.integers(0, N, 1990), np.argsort(lens)[-10:]]):
+        acc = 0j
+        for l in range(rowptr[r], rowptr[r + 1]):
+            acc += val[l] * xh[col[l]]
+        worst = max(worst, abs(acc - yh[r]) / max(abs(acc), 1.0))
+    out = {"workload": "SpMV alone, irregular scalar CSR (80 % of rows 5-9 entries, 20 % 10-64, 64 rows ~2000; columns within +-2^17 of the row), "
+                       "ELL slab + CSR tail, complex fp64 (north_star's general-matrix layout; configs[4] 'irregular nnz/row')",
+           "rows": N, "nnz": nnz, "column_window": window, "generate_seconds": gen_s, "build_seconds": build_s, "matrix_storage": storage_name(fmt, npat),
+           "ell_width": W, "lanes_per_row": lay["lanes"], "ell_entries": ell_nnz, "ell_padding_fraction": 1.0 - ell_nnz / float(npad * W),
+           "tail_rows": tail_rows, "tail_entries": tail_nnz, "matrix_GB_stored": stored["matrix_bytes"] / 1e9,
+           "check_parts_sum_to_whole_bitwise": parts_equal, "check_sampled_rows_max_rel_err": worst}
+    del rowptr, col, val
+    for tag, part, nbytes in (("whole", 0, b_ell + b_tail), ("ell_part", 1, b_ell), ("tail_part", 2, b_tail)):
+        mg.set_option("spmv_part", part)
+        try:
+            cold, _ = cold_apply_ms(mg, A, xf, yf, 12, Field)
+            warm = A.bench_apply(xf, yf, reps=10)
+        finally:
+            mg.set_option("spmv_part", 0)
+        out[tag] = {"bytes_moved_stored_layout": nbytes, "ms_cold_caches": cold["median"], "stats": cold, "GBps": nbytes / cold["median"] / 1e6,
+                    "frac_hbm_peak": nbytes / cold["median"] / 1e6 / HBM_PEAK_GBS, "ms_back_to_back": warm, "GBps_back_to_back": nbytes / warm / 1e6}
+    out["algorithmic_bytes_survey_formula"] = spmv_algorithmic_bytes(nnz, N, N)
+    out["GBps_survey_formula"] = out["algorithmic_bytes_survey_formula"] / out["whole"]["ms_cold_caches"] / 1e6
+    tr, note = pmc_traffic_workload("irregular_spmv")
+    out["roofline"] = {"kernel": "ell_spmv_rowthread + csr_tail_kernel (whole apply)", "bound": "hbm", "achieved": out["whole"]["GBps"], "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": out["whole"]["frac_hbm_peak"], "traffic": tr, "traffic_note": note,
+                       "bytes_per_launch": b_ell + b_tail}
+    return out
+
+
+def wl_poisson128_gcr_general(args):
+    """The headline solve on GENERAL storage: Poisson 128^3, GCR restart 5, with the row-pattern dictionary and
+    the stencil view switched off — the matrix is an ELL slab with int32 columns, as any matrix without repeating rows is stored.
+    it/s and whole-iteration bytes / time."""
+    import ctypes
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, Sparse, problems
+    mg.init(0)
+    n, R, iters = 128, 5, 20
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    nnz = int(rowptr[-1])
+    out = {"workload": "3D 7-point Poisson 128^3, unpreconditioned GCR restart 5, complex fp64, matrix stored as a GENERAL matrix (pattern_storage=0): "
+                       "ELL slab + int32 columns", "rows": N, "nnz": nnz, "iterations_per_solve": iters}
+    dims = (n, n, n)
+    rhs, x = Field(dims).fill_rhs(0), Field(dims)
+    prev = mg.set_option("pattern_storage", 0)
+    try:
+        ops = {"real_values_12B_per_entry": Sparse(N, ncol, rowptr, col, val), "complex_values_20B_per_entry": Sparse(N, ncol, rowptr, col, val * (1.0 + 0.25j))}
+    finally:
+        mg.set_option("pattern_storage", prev)
+    del rowptr, col, val
+    V = 16 * N
+    for tag, A in ops.items():
+        prm = GCR_Param(0, R, iters, 0.0, False, check_every=iters)
+        gcr = GCR(A, prm)
+        timed_solve(mg, gcr, rhs, x)
+        st = stats(repeat_timed(lambda: timed_solve(mg, gcr, rhs, x), min_total=0.25, min_reps=5))
+        prm.profile_spmv = True
+        gcr = GCR(A, prm)
+        timed_solve(mg, gcr, rhs, x)
+        ph, na, fu = (ctypes.c_double * 3)(), ctypes.c_int32(), ctypes.c_int32()
+        mg.lib().mgcr_gcr_last_profile(ph, ctypes.byref(na), ctypes.byref(fu))
+        ph_us = [1e3 * v / max(na.value, 1) for v in ph]
+        stored = A.stored_bytes()
+        fmt, npat = A.storage_format()
+        b_phase, mean_lim = gcr_phase_model(na.value, R, V, stored["matrix_bytes"], ncol, N, fu.value)
+        ms = st["median"] * 1e3 / iters
+        keys = ["xr", "apply_dots", "build"]
+        out[tag] = {"matrix_storage": storage_name(fmt, npat), "matrix_bytes": stored["matrix_bytes"], "it_per_s": iters / st["median"], "ms_per_iteration": ms,
+                    "timing_seconds": st, "fused_apply": fu.value,
+                    "phases": {keys[k]: {"us_per_iteration": ph_us[k], "bytes_per_launch": b_phase[k], "GBps": b_phase[k] / ph_us[k] / 1e3 if ph_us[k] > 0 else None} for k in range(3)},
+                    "iteration": {"bytes_moved_model": sum(b_phase), "GBps": sum(b_phase) / ms / 1e6, "frac_hbm_peak": sum(b_phase) / ms / 1e6 / HBM_PEAK_GBS},
+                    "final_rel_residual": float(gcr.last_history[-1])}
+    c = out["complex_values_20B_per_entry"]
+    out["roofline"] = {"kernel": "whole iteration (3 kernels), complex slab", "bound": "hbm", "achieved": c["iteration"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": c["iteration"]["frac_hbm_peak"], "traffic": None, "bytes_per_launch": c["iteration"]["bytes_moved_model"]}
+    return out
+
+
+def make_unstructured_blocks(nb, bs, seed=5):
+    """configs[4]'s operator: unstructured HierarchicalSparse, skewed blocks per row (80 % of the block rows
+    5-9 blocks, 20 % 10-64), diagonally dominant."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    per_row = np.where(rng.random(nb) < 0.8, rng.integers(5, 10, nb), rng.integers(10, 65, nb))
+    rows = np.repeat(np.arange(nb, dtype=np.int32), per_row)
+    cols = rng.integers(0, nb, rows.size).astype(np.int32)
+    first = np.concatenate([[0], np.cumsum(per_row)[:-1]])
+    cols[first] = np.arange(nb, dtype=np.int32)
+    nblk = rows.size
+    blocks = np.empty((nblk, bs, bs), np.complex128)
+    for s in range(0, nblk, 20000):
+        e = min(nblk, s + 20000)
+        blocks[s:e] = (rng.uniform(-1, 1, (e - s, bs, bs)) + 1j * rng.uniform(-1, 1, (e - s, bs, bs))) * (0.5 / bs)
+    offsum = np.bincount(rows, weights=np.abs(blocks).sum(axis=(1, 2)) / bs, minlength=nb)
+    blocks[first] = np.eye(bs)[None] * (1.0 + offsum)[:, None, None]
+    return rows, cols, blocks
+
+
+def wl_bcsr_mg(args):
+    """configs[4] as BASELINE states it, on one GPU: MG-preconditioned GCR on the ~3 GB unstructured HierarchicalSparse — aggregates
+    of 4 consecutive block rows (mesh = block rows x block size, only the first dimension blocked), 4 near-null vectors, one
+    coarse level (a HierarchicalSparse of 4 x 4 blocks, Galerkin product on the device), smoother 2 GCR sweeps, coarsest solve GCR
+    to 1e-2 / 50 iterations, flexible outer GCR restart 5 to 1e-10.  Reference: src/HierarchicalSparse.h:101-161, src/MG.h:405-430."""
+    import numpy as np
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, HierarchicalSparse, MG, MG_Param, Mesh
+    mg.init(0)
+    bs, nb, sub, ne = 20, int(os.environ.get("MGCR_BENCH_BCSR_ROWS", 36000)), 4, 4
+    rows, cols, blocks = make_unstructured_blocks(nb, bs)
+    nblk = rows.size
+    H = HierarchicalSparse(nb, nb, rows, cols, blocks)
+    del blocks
+    n = nb * bs
+    dims = (nb, bs)
+    rng = np.random.default_rng(9)
+    vecs = np.ones((ne, n), np.complex128)
+    vecs[1:] += 0.5 * (rng.standard_normal((ne - 1, n)) + 1j * rng.standard_normal((ne - 1, n)))
+    rhs, x, y = Field(dims).fill_rhs(2), Field(dims).set_zero(), Field(dims)
+    t0 = time.perf_counter()
+    prm = MG_Param(Mesh(dims), sub, ne, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1,
+                   None, None, spacetime=[True, False], null_vectors=vecs)
+    M = MG(H, prm)
+    mg.lib().mgcr_synchronize()
+    setup_s = time.perf_counter() - t0
+    M(rhs, out=y)
+
+    def cycle():
+        mg.lib().mgcr_synchronize()
+        t = time.perf_counter()
+        M(rhs, out=y)
+        mg.lib().mgcr_synchronize()
+        return time.perf_counter() - t
+    vc = stats(repeat_timed(cycle, min_total=0.2, min_reps=5, max_reps=30))
+    outer = GCR(H, GCR_Param(0, 5, 200, 1e-10, False, None, M, flexible=True, check_every=2))
+    timed_solve(mg, outer, rhs, x)
+    sv = stats(repeat_timed(lambda: timed_solve(mg, outer, rhs, x), min_total=0.2, min_reps=3, max_reps=8))
+    r = rhs - H(x)
+    plain = GCR(H, GCR_Param(0, 5, 200, 1e-10, False, check_every=5))
+    timed_solve(mg, plain, rhs, x)
+    sp = stats(repeat_timed(lambda: timed_solve(mg, plain, rhs, x), min_total=0.2, min_reps=3, max_reps=8))
+    b_apply = nblk * (bs * bs * 16 + 4) + (nb + 1) * 4 + 2 * n * 16
+    # fine level of a cycle: 2 + 2 smoother sweeps (4 applies; the residual is the pre-smoother's recurrence residual) — lower bound of the bytes
+    b_cycle_lb = 4 * b_apply
+    return {"workload": "unstructured HierarchicalSparse (block-CSR, bs 20, 5-64 blocks/row, ~3 GB), 2-level MG V-cycle preconditioner (aggregates of 4 block "
+                        "rows, 4 near-null vectors), flexible GCR restart 5 to 1e-10, 1 GPU (configs[4] as stated)",
+            "parity": MG_PARITY_NOTE, "block_rows": nb, "bs": bs, "blocks": int(nblk), "matrix_GB": nblk * bs * bs * 16 / 1e9,
+            "levels": [M.level_info(l) for l in range(2)], "mg_setup_seconds": setup_s, "vcycle_ms": vc["median"] * 1e3, "vcycle_timing_seconds": vc,
+            "vcycle_bytes_lower_bound_fine_applies": b_cycle_lb, "vcycle_GBps_lower_bound": b_cycle_lb / vc["median"] / 1e9,
+            "vcycle_frac_hbm_peak_lower_bound": b_cycle_lb / vc["median"] / 1e9 / HBM_PEAK_GBS,
+            "outer_iterations": outer.last_iterations, "converged": outer.last_converged, "seconds_to_tol": sv["median"], "solve_timing_seconds": sv,
+            "final_rel_residual": float(outer.last_history[-1]), "true_rel_residual": r.norm() / rhs.norm(),
+            "unpreconditioned": {"iterations": plain.last_iterations, "seconds_to_tol": sp["median"], "timing_seconds": sp},
+            "roofline": {"kernel": "V-cycle (lower bound: its 4 fine-level block-CSR applies)", "bound": "hbm", "achieved": b_cycle_lb / vc["median"] / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cycle_lb / vc["median"] / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+
 
 
 def wl_sample(args):
@@ -1179,10 +1379,11 @@ DIST_WORKLOADS = {"dist_mg": wl_dist_mg, "dist_bcsr": wl_dist_bcsr}
 DIST_EXTRA_TIMEOUT_S = 240
 
 WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
-             "sample": wl_sample, "latency64": wl_latency64}
+             "sample": wl_sample, "latency64": wl_latency64, "irregular_spmv": wl_irregular_spmv, "poisson128_gcr_general": wl_poisson128_gcr_general,
+             "bcsr_mg": wl_bcsr_mg}
 
 
-def run_extras(argv_base, budget_s=240.0):
+def run_extras(argv_base, budget_s=420.0):
     """Every other workload in its own child process (python bench.py --workload NAME), bounded in time."""
     out = {}
     t_end = time.time() + budget_s
@@ -1194,7 +1395,7 @@ def run_extras(argv_base, budget_s=240.0):
         env = dict(os.environ, MGCR_BENCH_ROLE="worker")
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name], env=env, capture_output=True, text=True,
-                               timeout=min(left, 120))
+                               timeout=min(left, 150))
             d = last_json_line(p.stdout)
             out[name] = d if (p.returncode == 0 and d is not None) else {"failed": "rc %d" % p.returncode, "stderr_tail": p.stderr[-500:]}
         except subprocess.TimeoutExpired:

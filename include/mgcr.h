@@ -107,12 +107,13 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
 /* how the rows of a Sparse are dealt to threads — what decides the order in which a row's products are added, i.e. the
  * one thing in which y = A x may differ from the reference's row loop (src/Operator.h:338-341): *ell_width = W, entries
  * 0..W-1 of a row sit in the ELL slab; *lanes = L, lane l of L adds entries l, l+L, ... in order and the L sums are
- * combined by a tree (L = 1: CSR order, bit-identical to the reference); *tail_rows = rows longer than W, whose remaining
- * entries one wave sums (64 lanes striding, tree) and adds to the row's ELL sum; *reach = max |column - row| when the
+ * combined by a tree (L = 1: CSR order, bit-identical to the reference); *tail_rows = rows longer than W: their remaining
+ * entries are summed in CSR order by one thread (products staged in LDS) and added to the row's ELL sum — unless there are
+ * more than *tail_chunk_cap of them, which one wave sums (64 lanes striding, tree); *reach = max |column - row| when the
  * operator has a row-pattern dictionary, else 0 (it decides the row -> workgroup map of the GCR kernels that embed the
  * apply).  Any pointer may be NULL.  tests/test_gpu_bitwise.py feeds these to the CPU oracle's model of the device's
  * summation order. */
-int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach);
+int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap);
 /* Sparse::dagger / mod_*_at (src/Operator.h:296-328,84-86) change a Sparse IN PLACE while a DiracOp, GCR or MG may hold a
  * pointer to it (src/Operator.h:117): this replaces the matrix behind an existing handle, so that every operator that
  * borrowed the handle (mgcr_dirac_create, mgcr_gcr_create) applies the new matrix.  On failure the old matrix stays.
@@ -136,6 +137,8 @@ int mgcr_csr_replace(mgcr_op_t op, int64_t nrow, int64_t ncol, const int64_t *ro
  *   "step_build"      ($MGCR_STEPBUILD): a lean step with up to 5 stored directions on a 7-point stencil-view operator of 2^19 .. 2^21
  *                      rows runs its apply, dot products and direction build as one launch, A r staying in LDS
  *                      (csrc/gcr_stepbuild.hip; same iterates, bit for bit, as the two kernels).
+ *   "spmv_part"       (measurement aid, default 0): 1 = a Sparse apply launches only its ELL-slab kernel, 2 = only its CSR-tail
+ *                      kernel (bench.py times the two parts of the hybrid layout separately); 0 = the whole apply.
  * *previous (may be NULL) receives the old value. */
 int mgcr_set_option(const char *name, int value, int *previous);
 /* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init,

@@ -148,7 +148,7 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns) {
     return MGCR_OK;
 }
 
-int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach) {
+int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap) {
     MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
     const Op *o = op->kind == OP_DIRAC ? op->base : op;
     MGCR_CHECK(o->kind == OP_CSR, MGCR_ERR_UNSUPPORTED, "mgcr_op_ell_layout: not a Sparse");
@@ -156,6 +156,7 @@ int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t
     if (lanes) *lanes = o->csr.L;
     if (tail_rows) *tail_rows = o->csr.n_tail_rows;
     if (reach) *reach = o->csr.reach;
+    if (tail_chunk_cap) *tail_chunk_cap = TAIL_CAP;
     return MGCR_OK;
 }
 
@@ -169,6 +170,11 @@ int mgcr_op_halo_kind(mgcr_op_t op, int32_t *kind) {
 
 int mgcr_set_option(const char *name, int value, int *previous) {
     MGCR_CHECK(name, MGCR_ERR_INVALID, "null option name");
+    if (!strcmp(name, "spmv_part")) {   // measurement aid: 0 whole apply, 1 ELL slab only, 2 CSR tail only (spmv.hip)
+        const int p = set_spmv_part(value);
+        if (previous) *previous = p;
+        return MGCR_OK;
+    }
     bool prev;
     if (!strcmp(name, "pattern_storage")) prev = set_patterns_enabled(value != 0);
     else if (!strcmp(name, "stencil_storage")) prev = set_stencil_enabled(value != 0);

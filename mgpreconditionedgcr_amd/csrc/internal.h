@@ -118,7 +118,15 @@ struct CsrDev {
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]
     int32_t *tail_col = nullptr;    // [tail_nnz]
     cplx *tail_val = nullptr;
+    // how the tail kernels are dealt the tail rows (spmv.hip csr_tail_chunk_kernel): runs of consecutive tail rows with at most
+    // TAIL_CAP entries and TAIL_THREADS rows together ("chunks": one workgroup each, products staged in LDS, every row then summed
+    // by one thread in CSR order), and the rows that are longer than a chunk on their own (one wave each, csr_tail_kernel)
+    int32_t n_tail_chunks = 0, n_tail_long = 0;
+    int4 *tail_chunk = nullptr;     // [n_tail_chunks] {first tail row (index into tail_rows), one past the last, first entry, one past the last entry}
+    int32_t *tail_long = nullptr;   // [n_tail_long] indices into tail_rows
 };
+constexpr int TAIL_CAP = 2048;      // entries per chunk (32 KB of LDS products, 8 entries per thread in flight)
+constexpr int TAIL_THREADS = 256;
 
 struct BcsrDev {
     int32_t nbrow = 0, nbcol = 0, bs = 0, nblocks = 0;
@@ -169,6 +177,7 @@ void csr_free(CsrDev *c);
 bool set_patterns_enabled(bool on);
 bool set_stencil_enabled(bool on);
 bool csr_stencil_active(const CsrDev &A);  // the apply kernels read A through its stencil view (CsrDev::sten_*)
+int set_spmv_part(int part);
 bool set_lean_enabled(bool on);
 bool set_fuse_enabled(bool on);
 bool set_graph_enabled(bool on);

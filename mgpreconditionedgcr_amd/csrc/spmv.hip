@@ -102,6 +102,7 @@ void csr_free(CsrDev *c) {
     hipFree(c->ell_val); hipFree(c->ell_val_re); hipFree(c->ell_col);
     hipFree(c->pat_id); hipFree(c->pat_off); hipFree(c->pat_re); hipFree(c->pat_im); hipFree(c->sten_planes);
     hipFree(c->tail_rows); hipFree(c->tail_ptr); hipFree(c->tail_col); hipFree(c->tail_val);
+    hipFree(c->tail_chunk); hipFree(c->tail_long);
     *c = CsrDev();
 }
 
@@ -565,6 +566,24 @@ static int ell_from_device_csr(int64_t nrow, int64_t ncol, const int64_t *h_rowp
                            d_rowptr, d_col, d_val, A.W, A.L, A.nchunk, A.npad, A.ell_val, A.ell_col);
         MGCR_HIP(hipGetLastError());
     }
+    std::vector<int4> chunks;
+    std::vector<int32_t> long_rows;
+    if (A.n_tail_rows) {
+        // deal the tail rows to workgroups: runs of consecutive tail rows of at most TAIL_CAP entries / TAIL_THREADS rows
+        int32_t i = 0;
+        const int32_t nt = (int32_t)trows.size();
+        while (i < nt) {
+            if (tptr[(size_t)i + 1] - tptr[(size_t)i] > TAIL_CAP) { long_rows.push_back(i); i++; continue; }
+            const int32_t first = i;
+            const int32_t e0 = tptr[(size_t)i];
+            while (i < nt && i - first < TAIL_THREADS && tptr[(size_t)i + 1] - e0 <= TAIL_CAP) i++;
+            chunks.push_back(make_int4(first, i, e0, tptr[(size_t)i]));
+        }
+        A.n_tail_chunks = (int32_t)chunks.size();
+        A.n_tail_long = (int32_t)long_rows.size();
+        if (A.n_tail_chunks) MGCR_TRY(dev_upload(&A.tail_chunk, chunks.data(), chunks.size()));
+        if (A.n_tail_long) MGCR_TRY(dev_upload(&A.tail_long, long_rows.data(), long_rows.size()));
+    }
     if (A.n_tail_rows) {
         MGCR_TRY(dev_upload(&A.tail_rows, trows.data(), trows.size()));
         MGCR_TRY(dev_upload(&A.tail_ptr, tptr.data(), tptr.size()));
@@ -995,9 +1014,9 @@ __global__ void __launch_bounds__(256) ell_spmv_lanes(int64_t row_begin, int64_t
     if (row < nrow && l == 0) y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
 }
 
-// CSR tail: one wave per long row, lanes stride the remaining entries, wave64 shuffle reduction
+// CSR tail, rows longer than a chunk on their own (> TAIL_CAP entries): one wave per row, lanes stride the entries, wave64 tree
 template <bool SHIFT>
-__global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, const int32_t *__restrict__ tail_rows,
+__global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_long, const int32_t *__restrict__ tail_long, const int32_t *__restrict__ tail_rows,
                                                        const int32_t *__restrict__ tail_ptr,
                                                        const int32_t *__restrict__ tail_col,
                                                        const cplx *__restrict__ tail_val, const cplx *__restrict__ x,
@@ -1006,15 +1025,68 @@ __global__ void __launch_bounds__(256) csr_tail_kernel(int64_t n_tail_rows, cons
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
-    if (wave >= n_tail_rows) return;
-    int32_t beg = tail_ptr[wave], end = tail_ptr[wave + 1];
+    if (wave >= n_long) return;
+    const int32_t t = tail_long[wave];
+    int32_t beg = tail_ptr[t], end = tail_ptr[t + 1];
     cplx sum = make_double2(0., 0.);
     for (int32_t i = beg + lane; i < end; i += 64) sum = cadd(sum, cmul(tail_val[i], gather_x(x, xh, n_own, tail_col[i])));
     sum.x = wave_sum(sum.x);
     sum.y = wave_sum(sum.y);
     if (lane == 0) {
-        int32_t row = tail_rows[wave];
+        int32_t row = tail_rows[t];
         y[row] = SHIFT ? csub(y[row], cmul(k, sum)) : cadd(y[row], sum);
+    }
+}
+
+// CSR tail, everything else: one workgroup per CHUNK — a run of consecutive tail rows with at most TAIL_CAP entries and
+// TAIL_THREADS rows (dealt at build time, ell_from_device_csr).  The chunk's entries are one contiguous piece of the tail
+// arrays: all threads stream it with coalesced loads (4 entries per thread in flight: columns, values, the gathers of x),
+// the products val * x are staged in LDS, and thread t then adds row t's products in CSR order — the reference's order
+// (src/Operator.h:338-341) — onto the row's ELL sum.  Against one wave per row (rows of 1..55 entries: 1.7 M waves that each
+// fetch half-used lines and spend their life in three dependent memory round trips) this streams whole lines once and keeps
+// 32 waves per CU busy: 8 M-row skewed matrix (bench.py irregular_spmv), tail part: 0.69 ms -> see DESIGN.md.
+template <bool SHIFT>
+__global__ void __launch_bounds__(TAIL_THREADS) csr_tail_chunk_kernel(const int4 *__restrict__ chunks,
+                                                                      const int32_t *__restrict__ tail_rows, const int32_t *__restrict__ tail_ptr,
+                                                                      const int32_t *__restrict__ tail_col, const cplx *__restrict__ tail_val,
+                                                                      const cplx *__restrict__ x, const cplx *__restrict__ xh, int32_t n_own,
+                                                                      cplx *__restrict__ y, cplx k, const int *__restrict__ skip, int skip_it) {
+    __shared__ cplx prod[TAIL_CAP];
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    const int t = threadIdx.x;
+    const int4 ch = chunks[blockIdx.x];   // one record: the entry range does not wait for a second, dependent fetch
+    const int32_t r0 = ch.x, r1 = ch.y, e0 = ch.z, e1 = ch.w;
+    // this thread's row (phase 2): requested now, used after the barrier
+    int32_t rb = 0, re = 0, row = 0;
+    if (r0 + t < r1) { rb = tail_ptr[r0 + t]; re = tail_ptr[r0 + t + 1]; row = tail_rows[r0 + t]; }
+    constexpr int PER = TAIL_CAP / TAIL_THREADS;
+    int32_t j[PER];
+    cplx v[PER], xv[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int32_t e = e0 + q * TAIL_THREADS + t;
+        j[q] = e < e1 ? tail_col[e] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int32_t e = e0 + q * TAIL_THREADS + t;
+        v[q] = e < e1 ? make_double2(__builtin_nontemporal_load(&tail_val[e].x), __builtin_nontemporal_load(&tail_val[e].y)) : make_double2(0., 0.);
+        xv[q] = j[q] >= 0 ? gather_x(x, xh, n_own, j[q]) : make_double2(0., 0.);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) prod[q * TAIL_THREADS + t] = cmul(v[q], xv[q]);
+    __syncthreads();
+    if (r0 + t < r1) {
+        const cplx y0 = y[row];     // (requested before the LDS walk)
+        cplx sum = make_double2(0., 0.);
+        int32_t i = rb - e0;
+        const int32_t ie = re - e0;
+        for (; i + 4 <= ie; i += 4) {   // four independent LDS reads in flight, added in CSR order
+            const cplx p0 = prod[i], p1 = prod[i + 1], p2 = prod[i + 2], p3 = prod[i + 3];
+            sum = cadd(cadd(cadd(cadd(sum, p0), p1), p2), p3);
+        }
+        for (; i < ie; i++) sum = cadd(sum, prod[i]);
+        y[row] = SHIFT ? csub(y0, cmul(k, sum)) : cadd(y0, sum);
     }
 }
 
@@ -1156,6 +1228,15 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     return MGCR_OK;
 }
 
+// measurement aid (bench.py: the ELL part and the CSR tail of a hybrid matrix timed separately): 0 = the whole apply,
+// 1 = only the ELL slab's kernel, 2 = only the tail kernel (which then adds to whatever y holds).  mgcr_set_option("spmv_part").
+static int g_spmv_part = 0;
+int set_spmv_part(int part) {
+    const int prev = g_spmv_part;
+    g_spmv_part = part < 0 || part > 2 ? 0 : part;
+    return prev;
+}
+
 template <bool SHIFT>
 static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr *dist, const cplx *w) {
     Context &c = ctx();
@@ -1173,14 +1254,21 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
         MGCR_TRY(dist_halo_end(dist));
         MGCR_TRY(ell_rows<SHIFT>(A, 0, ib, x, xh, n_own, y, k, w));
         MGCR_TRY(ell_rows<SHIFT>(A, ie, A.nrow - ie, x, xh, n_own, y, k, w));
-    } else {
+    } else if (g_spmv_part != 2) {
         MGCR_TRY(ell_rows<SHIFT>(A, 0, A.nrow, x, xh, n_own, y, k, w));
     }
-    if (A.n_tail_rows) {
-        int64_t threads = A.n_tail_rows * 64;
-        hipLaunchKernelGGL((csr_tail_kernel<SHIFT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream,
-                           A.n_tail_rows, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);
-        MGCR_HIP(hipGetLastError());
+    if (A.n_tail_rows && g_spmv_part != 1) {
+        if (A.n_tail_chunks) {
+            hipLaunchKernelGGL((csr_tail_chunk_kernel<SHIFT>), dim3((unsigned)A.n_tail_chunks), dim3(TAIL_THREADS), 0, c.stream, (const int4 *)A.tail_chunk,
+                               A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, g_skip.p, g_skip.it);
+            MGCR_HIP(hipGetLastError());
+        }
+        if (A.n_tail_long) {
+            int64_t threads = (int64_t)A.n_tail_long * 64;
+            hipLaunchKernelGGL((csr_tail_kernel<SHIFT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, (int64_t)A.n_tail_long,
+                               A.tail_long, A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, w, g_skip.p, g_skip.it);
+            MGCR_HIP(hipGetLastError());
+        }
     }
     return MGCR_OK;
 }

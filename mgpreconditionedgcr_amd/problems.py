@@ -62,3 +62,25 @@ def random_csr(nrow, ncol, rng, min_len=0, max_len=12, long_rows=0, long_len=200
         col[rowptr[r]:rowptr[r + 1]] = np.sort(rng.choice(ncol, size=lens[r], replace=False))
     val = (rng.uniform(-1, 1, rowptr[-1]) + 1j * rng.uniform(-1, 1, rowptr[-1])).astype(np.complex128)
     return rowptr, col, val
+
+
+def skewed_csr(nrow, rng, window=1 << 17, long_rows=0, long_len=2000):
+    """An irregular scalar CSR for the ELL + CSR-tail hybrid (BASELINE configs[4] "irregular nnz/row"; the reference's
+    general apply is src/Operator.h:330-346): 80 % of the rows have 5-9 entries, 20 % have 10-64, `long_rows` rows have
+    ~long_len; columns are the row number plus a random offset within +-window (clamped to the matrix: graph-like
+    locality; duplicates inside a row are possible and are separate entries, as CSR allows).  Vectorised: 8 M rows /
+    100 M entries in seconds.  Returns (rowptr, col, val), square nrow x nrow."""
+    lens = np.where(rng.random(nrow) < 0.8, rng.integers(5, 10, nrow), rng.integers(10, 65, nrow)).astype(np.int64)
+    if long_rows:
+        idx = rng.choice(nrow, size=long_rows, replace=False)
+        lens[idx] = rng.integers(long_len // 2, long_len + 1, size=long_rows)
+    rowptr = np.zeros(nrow + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    col = np.repeat(np.arange(nrow, dtype=np.int64), lens)
+    col += rng.integers(-window, window + 1, nnz)
+    np.clip(col, 0, nrow - 1, out=col)
+    val = np.empty(nnz, np.complex128)
+    val.real = rng.uniform(-1, 1, nnz)
+    val.imag = rng.uniform(-1, 1, nnz)
+    return rowptr, col, val

@@ -67,9 +67,10 @@ static int g_dev_per = 0;         /* RowMap::per */
 static int g_dev_init_banded = 0; /* step 0's sums come out of the kernel that embeds the apply (gcr_fused.hip init_apply_kernel) */
 static int g_dev_ell_w = -1;      /* SpMV layout: ELL width W (rows longer than W keep a CSR tail); -1: every row sequential */
 static int g_dev_ell_l = 1;       /* lanes per row of the ELL part (1: sequential in CSR order) */
-void orc_set_device_model(int blocks, int64_t band, int per, int init_banded, int ell_width, int ell_lanes) {
+static int g_dev_tail_cap = 0;    /* tail entries of a row: up to this many are summed in CSR order by one thread, more by a wave (lanes + tree) */
+void orc_set_device_model(int blocks, int64_t band, int per, int init_banded, int ell_width, int ell_lanes, int tail_cap) {
     g_dev_blocks = blocks; g_dev_band = band; g_dev_per = per; g_dev_init_banded = init_banded;
-    g_dev_ell_w = ell_width; g_dev_ell_l = ell_lanes < 1 ? 1 : ell_lanes;
+    g_dev_ell_w = ell_width; g_dev_ell_l = ell_lanes < 1 ? 1 : ell_lanes; g_dev_tail_cap = tail_cap;
 }
 
 static int dev_grid(int64_t n) {
@@ -217,8 +218,9 @@ void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
 /* src/Operator.h:330-346  y_row = sum_l VAL[l] * x[COL[l]], sequential per row.
  * Order 3 with a device layout set (orc_set_device_model: W, L): the row's first min(len, W) entries are summed the way
  * csrc/spmv.hip:ell_spmv_lanes does — lane l of L adds entries l, l+L, ... in order, the L lane sums are combined by the tree
- * (l, l+L/2), ..., (l, l+1), lower + upper — and the entries beyond W the way csr_tail_kernel does: 64 lanes stride them,
- * wave tree, then y_row = y_ell + y_tail (DiracOp: y = (x - k y_ell) - k y_tail, see dirac_apply).  L = 1 and no tail is
+ * (l, l+L/2), ..., (l, l+1), lower + upper — and the entries beyond W the way the tail kernels do: in CSR order by one thread
+ * (csr_tail_chunk_kernel; rows with at most tail_cap tail entries), or 64 lanes striding them + wave tree (csr_tail_kernel),
+ * then y_row = y_ell + y_tail (DiracOp: y = (x - k y_ell) - k y_tail, see dirac_apply).  L = 1 and no tail is
  * the reference's order. */
 static void csr_row_device(const orc_op *op, int64_t row, const cplx *x, cplx *ell, cplx *tail, int *has_tail) {
     const int64_t b = op->rowptr[row], e = op->rowptr[row + 1];
@@ -234,7 +236,11 @@ static void csr_row_device(const orc_op *op, int64_t row, const cplx *x, cplx *e
         for (int l = 0; l < off; l++) { lr[l] = lr[l] + lr[l + off]; li[l] = li[l] + li[l + off]; }
     *ell = lr[0] + li[0] * I;
     *has_tail = (e - b) > W;
-    if (*has_tail) {
+    if (*has_tail && (e - b) - W <= g_dev_tail_cap) { /* csr_tail_chunk_kernel: products in LDS, one thread adds them in CSR order */
+        cplx t = 0.0;
+        for (int64_t j = b + W; j < e; j++) t = t + op->val[j] * x[op->col[j]];
+        *tail = t;
+    } else if (*has_tail) {
         double tr[64], ti[64];
         for (int l = 0; l < 64; l++) { tr[l] = 0.; ti[l] = 0.; }
         for (int64_t j = b + W; j < e; j++) {

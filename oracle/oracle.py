@@ -73,7 +73,7 @@ def lib():
         L.orc_op_dim.argtypes = [C.c_void_p]
         L.orc_op_dim.restype = C.c_int64
         L.orc_set_sum_order.argtypes = [C.c_int]
-        L.orc_set_device_model.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_set_device_model.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_op_nrow.argtypes = [C.c_void_p]
         L.orc_op_nrow.restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
@@ -250,8 +250,8 @@ class device_order:
     one-workgroup solver.  `band`, `per`, `init_banded`: the RowMap of the kernels that embed the operator apply
     (gcr_dev.h:make_row_map), needed from about 182^3 rows on (`row_map(n, reach)` below computes them)."""
 
-    def __init__(self, blocks=0, band=0, per=0, init_banded=False, ell_width=-1, ell_lanes=1):
-        self.args = (int(blocks), int(band), int(per), int(bool(init_banded)), int(ell_width), int(ell_lanes))
+    def __init__(self, blocks=0, band=0, per=0, init_banded=False, ell_width=-1, ell_lanes=1, tail_cap=0):
+        self.args = (int(blocks), int(band), int(per), int(bool(init_banded)), int(ell_width), int(ell_lanes), int(tail_cap))
 
     def __enter__(self):
         lib().orc_set_device_model(*self.args)
@@ -260,7 +260,7 @@ class device_order:
 
     def __exit__(self, *exc):
         lib().orc_set_sum_order(0)
-        lib().orc_set_device_model(0, 0, 0, 0, -1, 1)
+        lib().orc_set_device_model(0, 0, 0, 0, -1, 1, 0)
         return False
 
 

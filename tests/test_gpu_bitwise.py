@@ -65,7 +65,7 @@ def device_model(A, N, took_small):
     band, per = orc.row_map(N, lay["reach"])
     lanes = lay["lanes"] > 1 or lay["tail_rows"] > 0
     return orc.device_order(blocks=0, band=band, per=per, init_banded=band > 0,
-                            ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"])
+                            ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"])
 
 
 def solve_both(A, Ao, N, gp, po, b, x0=None, dims=None):
@@ -328,3 +328,36 @@ def test_dagger_behind_a_borrowed_handle():
     assert np.array_equal(gcr.last_history, ref[1])
     S.dagger()                                         # twice = the original matrix
     assert np.array_equal(Dk(fx).to_numpy(), before)
+
+
+@pytest.mark.parametrize("nrow,ncol,kw", [
+    (257, 300, dict(min_len=0, max_len=9)),                                  # empty rows, ragged
+    (3000, 2500, dict(min_len=0, max_len=6, long_rows=5, long_len=900)),     # tail rows summed by the chunk kernel (one thread, CSR order)
+    (6000, 6000, dict(min_len=1, max_len=7, long_rows=7, long_len=3000)),    # ... and rows longer than a chunk (one wave, lanes + tree)
+    (40000, 40000, dict(min_len=3, max_len=40)),                             # many tail rows: chunks of up to 256 rows / 1024 entries
+    (700, 700, dict(min_len=30, max_len=45)),                                # multi-lane rows
+    (64, 4096, dict(min_len=1000, max_len=1500)),                            # everything long
+])
+def test_irregular_spmv_bit_for_bit(nrow, ncol, kw):
+    """Sparse::operator() (src/Operator.h:330-346) on ELL slab + CSR tail layouts: the device's row sums are the oracle's with
+    the rows associated as the layout says (mgcr_op_ell_layout) — and exactly the reference's wherever a row is summed by one
+    thread in CSR order."""
+    rng = np.random.default_rng(nrow * 7 + ncol)
+    rowptr, col, val = problems.random_csr(nrow, ncol, rng, **kw)
+    x = problems.rhs_grid(ncol, 3)
+    A = Sparse(nrow, ncol, rowptr, col, val)
+    Ao = orc.csr(nrow, ncol, rowptr, col, val)
+    lay = A.ell_layout()
+    y = A(Field((ncol,), x)).to_numpy()
+    with device_model(A, nrow, False):
+        assert np.array_equal(y, Ao(x)), lay
+    if nrow == ncol:
+        k = 0.3 - 0.2j
+        yd = DiracOp(A, k)(Field((ncol,), x)).to_numpy()
+        with device_model(A, nrow, False):
+            assert np.array_equal(yd, orc.dirac(Ao, k)(x)), lay
+    if lay["lanes"] == 1:
+        # rows whose tail is summed by one thread: y_row = fl(ELL sum in CSR order) + fl(tail sum in CSR order)
+        tails = np.diff(rowptr) - lay["ell_width"]
+        seq = tails <= 0
+        assert np.array_equal(y[seq], Ao(x)[seq])      # no tail: the reference's bits
