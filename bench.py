@@ -665,6 +665,31 @@ def run_headline(args, with_cpu=True):
     spmv_bytes = stored["matrix_bytes"] + 16 * ncol + 16 * N
     cold_ms = cold["median"] if cold else None
 
+    # N > 1: what ONE GPU does on its own shard with the kernel path the distributed solve runs — the three kernels per
+    # iteration; the one-launch steps (gcr_stepbuild.hip) stop at the process boundary, their in-launch sums do not cross GPUs —
+    # so that per_shard_it_per_s / scaling_baseline_it_per_s is the price of the communication alone, and the N = 1 headline
+    # (one-launch steps) is not what an N-GPU line gets divided by.  Every rank measures its own shard; the slowest counts.
+    scaling_baseline = None
+    if world > 1:
+        Nl, ncl, rp, ci, va = problems.poisson3d_csr(n)
+        Aloc = Sparse(Nl, ncl, rp, ci, va)
+        del rp, ci, va
+        prev_sb, prev_res = mg.set_option("step_build", 0), mg.set_option("resident_solver", 0)
+        try:
+            gl = GCR(Aloc, GCR_Param(0, args.restart, args.steps, 0.0, False, check_every=args.steps))
+            xl, rl = Field(dims), Field(dims).fill_rhs(0)
+            timed_solve(mg, gl, rl, xl)
+            sb = stats(repeat_timed(lambda: timed_solve(mg, gl, rl, xl), min_total=0.15, min_reps=5))
+        finally:
+            mg.set_option("step_build", prev_sb)
+            mg.set_option("resident_solver", prev_res)
+        t = torch.tensor([sb["median"]], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        scaling_baseline = {"it_per_s": args.steps / float(t[0]), "this_rank_seconds": sb,
+                            "what": "single-GPU solve of one %d^3 shard, same %d iterations, three kernels per iteration (step_build and the resident "
+                                    "solver off: the path a distributed shard runs); max over ranks" % (n, args.steps)}
+        del Aloc, gl, xl, rl
+
     out = {
         "metric": "gcr_iterations_per_sec", "value": it_per_s * world, "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -676,6 +701,9 @@ def run_headline(args, with_cpu=True):
                            "repeated; value and ms_per_step come from the median" % args.steps,
                    "seconds": st, "it_per_s_min": args.steps / st["max"] * world, "it_per_s_max": args.steps / st["min"] * world},
         "per_shard_it_per_s": it_per_s,
+        "scaling_baseline_it_per_s": None if scaling_baseline is None else scaling_baseline["it_per_s"],
+        "scaling_baseline": scaling_baseline,
+        "one_launch_fallbacks": mg.stat("one_launch_fallbacks"),
         "config": {"workload": "3D 7-point Poisson %d^3 per GPU, unpreconditioned GCR restart %d, complex fp64, x0=0, "
                                "RHS splitmix64 seed 0" % (n, args.restart),
                    "rows": N, "nnz": nnz, "complex": True,

@@ -137,6 +137,9 @@ int mgcr_csr_replace(mgcr_op_t op, int64_t nrow, int64_t ncol, const int64_t *ro
  *   "step_build"      ($MGCR_STEPBUILD): a lean step with up to 5 stored directions on a 7-point stencil-view operator of 2^19 .. 2^21
  *                      rows runs its apply, dot products and direction build as one launch, A r staying in LDS
  *                      (csrc/gcr_stepbuild.hip; same iterates, bit for bit, as the two kernels).
+ *   "halo_split"      ($MGCR_HALO_SPLIT): the stand-alone apply of a distributed Sparse whose halo travels by peer writes stores and
+ *                      publishes its boundary rows, multiplies the rows that need no halo, THEN waits for the neighbours and
+ *                      multiplies the boundary rows (same bits; off: the exchange completes before any row).
  *   "spmv_part"       (measurement aid, default 0): 1 = a Sparse apply launches only its ELL-slab kernel, 2 = only its CSR-tail
  *                      kernel (bench.py times the two parts of the hybrid layout separately); 0 = the whole apply.
  * *previous (may be NULL) receives the old value. */
@@ -144,7 +147,8 @@ int mgcr_set_option(const char *name, int value, int *previous);
 /* Counters for tests and benchmarks: "resident_solves" = GCR solves that took the one-launch path since mgcr_init,
  * "step_build_launches" = steps that ran as one apply + build launch, "small_solves" = solves that ran as one launch of one
  * workgroup (csrc/gcr_small.hip), "one_launch_fallbacks" = top-level solves that were repeated on the multi-kernel path
- * because a one-launch path gave up (foreign work on the device: its grid was not co-resident). */
+ * because a one-launch path gave up (foreign work on the device: its grid was not co-resident), "halo_split_exchanges" =
+ * peer-write halo exchanges of distributed applies that ran split (store + publish | interior rows | wait | boundary rows). */
 int mgcr_stat(const char *name, int64_t *value);
 
 /* Self-test of the hardware behaviour the one-launch solver paths (csrc/gcr_resident.hip, gcr_stepbuild.hip) build on: inside

@@ -539,6 +539,7 @@ struct DistCsr {
     int *pw_ticket = nullptr;              // device: workgroups of the running exchange that have stored their rows
     uint32_t pw_seq = 0;
     unsigned pw_grid_x = 1;
+    bool pw_wait_pending = false;          // a split exchange has stored and published; its wait kernel is still to be launched (dist_halo_end)
 };
 
 static bool halo_overlap() {
@@ -579,6 +580,32 @@ struct HaloPwPeer {
     int64_t recv_cnt;             // ... and how many: poisoned with NaN when the peer never arrives
 };
 
+// what the last workgroup of an exchange (or the wait kernel) does for peer q: wait — bounded — for the neighbour's flag
+__device__ __forceinline__ void halo_pw_wait_peer(const HaloPwPeer &q, int slot, uint32_t seq, int *err, long long timeout) {
+    const long long t0 = wall_clock64();
+    bool ok = false;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        for (;;) {
+            if (__hip_atomic_load(q.flag_local[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (uint64_t)seq) { ok = true; break; }
+            if (wall_clock64() - t0 > timeout) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    if (!ok) {
+        // the neighbour never published: flag it (every host synchronisation point turns the flag into MGCR_ERR_COMM,
+        // comm_check_all) and poison the rows it owed with NaN, as the all-reduce does with its sums — a missed
+        // check must not be able to yield plausible numbers from a stale or half-written slot
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int64_t i = 0; i < q.recv_cnt; i++) q.rx_local[slot][i] = make_double2(nan, nan);
+    }
+}
+
+// WAIT = false: the exchange is SPLIT — this kernel stores and publishes, and halo_pw_wait_kernel, launched after the rows
+// that need no halo have been multiplied, waits for the neighbours (spmv.hip csr_apply_t): the wait — the neighbour's own
+// kernels plus the link — then overlaps with the interior rows instead of preceding them.  Same protocol: the wait kernel is
+// never skipped and precedes this rank's next exchange in stream order, so every exchange remains a rendezvous.
+template <bool WAIT>
 __global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restrict__ tab, int npeer, const int32_t *__restrict__ idx,
                                                       const cplx *__restrict__ x, uint32_t seq, int *ticket, int *err, long long timeout) {
     const int p = blockIdx.y, slot = (int)(seq & 1u);
@@ -596,25 +623,13 @@ __global__ void __launch_bounds__(256) halo_pw_kernel(const HaloPwPeer *__restri
     if ((int)threadIdx.x < npeer) {
         const HaloPwPeer q = tab[threadIdx.x];
         __hip_atomic_store(q.flag_remote[slot], (uint64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const long long t0 = wall_clock64();
-        bool ok = false;
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-            for (;;) {
-                if (__hip_atomic_load(q.flag_local[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (uint64_t)seq) { ok = true; break; }
-                if (wall_clock64() - t0 > timeout) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        if (!ok) {
-            // the neighbour never published: flag it (every host synchronisation point turns the flag into MGCR_ERR_COMM,
-            // comm_check_all) and poison the rows it owed with NaN, as the all-reduce does with its sums — a missed
-            // check must not be able to yield plausible numbers from a stale or half-written slot
-            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const double nan = __longlong_as_double(0x7ff8000000000000LL);
-            for (int64_t i = 0; i < q.recv_cnt; i++) q.rx_local[slot][i] = make_double2(nan, nan);
-        }
+        if (WAIT) halo_pw_wait_peer(q, slot, seq, err, timeout);
     }
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// second half of a split exchange: one wave, lane p waits for peer p
+__global__ void __launch_bounds__(64) halo_pw_wait_kernel(const HaloPwPeer *__restrict__ tab, int npeer, uint32_t seq, int *err, long long timeout) {
+    if ((int)threadIdx.x < npeer) halo_pw_wait_peer(tab[threadIdx.x], (int)(seq & 1u), seq, err, timeout);
 }
 
 __global__ void __launch_bounds__(256) halo_test_fill_kernel(cplx *x, int64_t n, int64_t row0, double im) {
@@ -628,15 +643,35 @@ static const cplx *halo_pw_slot(const DistCsr *d, uint32_t seq) {
     return reinterpret_cast<const cplx *>(d->pw_rx + (size_t)(seq & 1u) * halo_pw_slot_bytes(d));
 }
 
-static int halo_pw_launch(DistCsr *d, const cplx *x) {
+static int g_halo_split = -1;
+static bool halo_split_enabled() {   // MGCR_HALO_SPLIT=0 / mgcr_set_option("halo_split", 0): the stand-alone apply waits for its halo before any row, as the fused GCR steps do
+    if (g_halo_split < 0) g_halo_split = !(getenv("MGCR_HALO_SPLIT") && atoi(getenv("MGCR_HALO_SPLIT")) == 0);
+    return g_halo_split != 0;
+}
+bool set_halo_split(bool on) {
+    const bool prev = halo_split_enabled();
+    g_halo_split = on ? 1 : 0;
+    return prev;
+}
+static int halo_pw_launch(DistCsr *d, const cplx *x, bool split = false) {
     Comm *c = d->comm;
     d->pw_seq = pw_advance(d->pw_seq);
     const int np = (int)d->plan->peers.size();
-    hipLaunchKernelGGL(halo_pw_kernel, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
-                       (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, d->pw_on ? pw_timeout_run() : PW_TIMEOUT_TEST);
+    MGCR_CHECK(np <= 64, MGCR_ERR_UNSUPPORTED, "peer-write halo exchange: at most 64 neighbours");
+    const long long timeout = d->pw_on ? pw_timeout_run() : PW_TIMEOUT_TEST;
+    if (split && halo_split_enabled()) {
+        hipLaunchKernelGGL(halo_pw_kernel<false>, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
+                           (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, timeout);
+        d->pw_wait_pending = true;
+    } else {
+        hipLaunchKernelGGL(halo_pw_kernel<true>, dim3(d->pw_grid_x, (unsigned)np), dim3(256), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np,
+                           (const int32_t *)d->send_idx, x, d->pw_seq, d->pw_ticket, c->pw_err, timeout);
+    }
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
+static int64_t g_halo_split_count = 0;
+int64_t dist_halo_split_count() { return g_halo_split_count; }
 
 static void halo_pw_release(DistCsr *d) {
     for (unsigned char *q : d->pw_peer_rx)
@@ -768,12 +803,12 @@ static int halo_pw_setup(DistCsr *d) {
 // the halo segment the exchange begun last delivers into (call after dist_halo_begin)
 const cplx *dist_halo_ptr(DistCsr *d) { return d->pw_on ? halo_pw_slot(d, d->pw_seq) : d->xh; }
 
-int dist_halo_begin(DistCsr *d, const cplx *x) {
+int dist_halo_begin(DistCsr *d, const cplx *x, bool overlap_interior) {
     Comm *c = d->comm;
     Plan *P = d->plan;
     const int np = (int)P->peers.size();
     if (np == 0) return MGCR_OK;
-    if (d->pw_on) return halo_pw_launch(d, x);
+    if (d->pw_on) return halo_pw_launch(d, x, overlap_interior);
     hipStream_t main = ctx().stream;
     int64_t tot_send = d->send_off.empty() ? 0 : d->send_off.back() + d->send_cnt.back();
     // pack the non-contiguous send lists
@@ -832,6 +867,14 @@ int dist_halo_begin(DistCsr *d, const cplx *x) {
 
 int dist_halo_end(DistCsr *d) {
     Comm *c = d->comm;
+    if (d->pw_wait_pending) {   // second half of a split peer-write exchange (halo_pw_kernel<false>)
+        d->pw_wait_pending = false;
+        const int np = (int)d->plan->peers.size();
+        hipLaunchKernelGGL(halo_pw_wait_kernel, dim3(1), dim3(64), 0, ctx().stream, (const HaloPwPeer *)d->pw_tab, np, d->pw_seq, c->pw_err, pw_timeout_run());
+        MGCR_HIP(hipGetLastError());
+        g_halo_split_count++;
+        return MGCR_OK;
+    }
     if (c->is_rccl && halo_overlap() && !d->plan->peers.empty()) MGCR_HIP(hipStreamWaitEvent(ctx().stream, c->ev_done, 0));
     return MGCR_OK;
 }

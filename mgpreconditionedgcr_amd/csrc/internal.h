@@ -226,7 +226,11 @@ void set_apply_skip(SkipRef s);
 SkipRef get_apply_skip();
 
 // ---- comm.hip --------------------------------------------------------------------------------
-int dist_halo_begin(DistCsr *d, const cplx *x);
+// overlap_interior: the caller multiplies the rows that need no halo between begin and end — a peer-write exchange is then split
+// into store + publish (begin) and the wait for the neighbours (end)
+int dist_halo_begin(DistCsr *d, const cplx *x, bool overlap_interior = false);
+int64_t dist_halo_split_count();
+bool set_halo_split(bool on);
 int dist_halo_end(DistCsr *d);
 bool dist_halo_overlaps();  // MGCR_HALO_OVERLAP: exchange on the communication stream, overlapped with interior rows
 const cplx *dist_halo_ptr(DistCsr *d);  // halo segment of the exchange begun last (peer-write: alternates between two slots)

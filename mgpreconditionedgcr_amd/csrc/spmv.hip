@@ -1248,7 +1248,7 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
         int64_t ib = 0, ie = 0;
         dist_info(dist, &xh, &ib, &ie);
         n_own = (int32_t)A.nrow;
-        MGCR_TRY(dist_halo_begin(dist, x));
+        MGCR_TRY(dist_halo_begin(dist, x, ie > ib && g_spmv_part == 0));
         xh = dist_halo_ptr(dist);
         MGCR_TRY(ell_rows<SHIFT>(A, ib, ie - ib, x, xh, n_own, y, k, w));
         MGCR_TRY(dist_halo_end(dist));

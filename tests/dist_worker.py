@@ -301,7 +301,13 @@ def main():
             mg.init(0)
             A = DistSparse(comm, N, r0, lp, lc, lv)
             xf = Field((r1 - r0,), x[r0:r1])
+            s0 = mg.stat("halo_split_exchanges")
             y = A(xf).to_numpy()
+            n_split = mg.stat("halo_split_exchanges") - s0
+            prev = mg.set_option("halo_split", 0)     # the same apply with the exchange completed before any row
+            y_unsplit = A(xf).to_numpy()
+            n_unsplit = mg.stat("halo_split_exchanges") - s0 - n_split
+            mg.set_option("halo_split", prev)
             b = Field((r1 - r0,), problems.rhs_grid(N, 1)[r0:r1])
             xs = Field((r1 - r0,)).set_zero()
             gcr = GCR(A, GCR_Param(0, 4, 25, 1e-30, False, check_every=5))
@@ -311,7 +317,7 @@ def main():
             g2.solve(b, xt)
             results[kind] = dict(y=y, r0=r0, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations,
                                  hist_trunc=g2.last_history, x_trunc=xt.to_numpy(), format=A.storage_format()[0],
-                                 allreduce=comm.allreduce_kind, halo=A.halo_kind)
+                                 allreduce=comm.allreduce_kind, halo=A.halo_kind, n_split=n_split, n_unsplit=n_unsplit, y_unsplit=y_unsplit)
             if kind == "poisson":
                 import ctypes
                 us = ctypes.c_double()

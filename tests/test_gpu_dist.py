@@ -47,6 +47,15 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
         assert all(res[r][kind]["allreduce"] == want for r in range(world)), [res[r][kind]["allreduce"] for r in range(world)]
         want_h = "host" if os.environ.get("MGCR_PEER_HALO") == "0" or want == "host" else "peer-write"
         assert all(res[r][kind]["halo"] == want_h for r in range(world)), [res[r][kind]["halo"] for r in range(world)]
+        # the stand-alone apply of a peer-write rank runs SPLIT by default — boundary rows stored and published, the rows that need
+        # no halo multiplied, then the wait for the neighbours and the boundary rows — with the bits of the unsplit apply
+        for r in range(world):
+            assert np.array_equal(res[r][kind]["y"], res[r][kind]["y_unsplit"]) and res[r][kind]["n_unsplit"] == 0
+            if want_h == "peer-write" and kind == "poisson48":     # (row blocks of several planes: rows that touch no halo column exist on every rank)
+                assert res[r][kind]["n_split"] == 1, (kind, r, res[r][kind]["n_split"])
+            assert res[r][kind]["n_split"] in (0, 1)
+        if want_h == "peer-write" and kind == "poisson":
+            assert sum(res[r][kind]["n_split"] for r in range(world)) >= 1
         if kind == "poisson":
             print("all-reduce of 11 doubles, %d ranks on one GPU, %s: %.1f us" % (world, want, res[0][kind]["allreduce_us"]))
         x = problems.rhs_grid(N, 5)
