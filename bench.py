@@ -964,6 +964,19 @@ def wl_bcsr(args):
 
 
 def wl_irregular_spmv(args):
+    """Two matrices of the same skewed row-length distribution: "scattered" (columns within +-2^17 rows: every gathered entry is its
+    own L2 request — the gather-bound regime, profiles/r03_gather_lab.txt) and "banded" (columns within +-900 rows, as after a
+    bandwidth-reducing ordering: the slab kernel stages x in an LDS window).  MGCR_BENCH_IRREGULAR_WINDOW=<w> measures one window only."""
+    if os.environ.get("MGCR_BENCH_IRREGULAR_WINDOW"):
+        return irregular_spmv_one(int(os.environ["MGCR_BENCH_IRREGULAR_WINDOW"]))
+    sc = irregular_spmv_one(1 << 17)
+    bd = irregular_spmv_one(900)
+    out = {"workload": sc["workload"], "scattered_columns": sc, "banded_columns": bd,
+           "roofline": dict(sc["roofline"], note="the scattered matrix (the harder case); banded: frac %.3f" % bd["roofline"]["frac"])}
+    return out
+
+
+def irregular_spmv_one(window):
     """north_star's layout for GENERAL matrices measured at HBM scale: an irregular scalar CSR of ~2 GB —
     80 % of the rows 5-9 entries, 20 % 10-64, a handful of rows ~2000 — stored as ELL slab + CSR tail.  The two kernels of the
     hybrid are timed separately (mgcr_set_option("spmv_part")) and together, cold (a 512 MiB copy sweeps the caches between
@@ -976,7 +989,6 @@ def wl_irregular_spmv(args):
     N = int(os.environ.get("MGCR_BENCH_IRREGULAR_ROWS", 8 * 1024 * 1024))
     rng = np.random.default_rng(12)
     t0 = time.perf_counter()
-    window = int(os.environ.get("MGCR_BENCH_IRREGULAR_WINDOW", 1 << 17))
     rowptr, col, val = problems.skewed_csr(N, rng, window=window, long_rows=64)
     gen_s = time.perf_counter() - t0
     nnz = int(rowptr[-1])
@@ -1006,10 +1018,10 @@ def wl_irregular_spmv(args):
         for l in range(rowptr[r], rowptr[r + 1]):
             acc += val[l] * xh[col[l]]
         worst = max(worst, abs(acc - yh[r]) / max(abs(acc), 1.0))
-    out = {"workload": "SpMV alone, irregular scalar CSR (80 % of rows 5-9 entries, 20 % 10-64, 64 rows ~2000; columns within +-2^17 of the row), "
+    out = {"workload": "SpMV alone, irregular scalar CSR (80 % of rows 5-9 entries, 20 % 10-64, 64 rows ~2000; columns within +-window of the row), "
                        "ELL slab + CSR tail, complex fp64 (north_star's general-matrix layout; configs[4] 'irregular nnz/row')",
            "rows": N, "nnz": nnz, "column_window": window, "generate_seconds": gen_s, "build_seconds": build_s, "matrix_storage": storage_name(fmt, npat),
-           "ell_width": W, "lanes_per_row": lay["lanes"], "ell_entries": ell_nnz, "ell_padding_fraction": 1.0 - ell_nnz / float(npad * W),
+           "ell_width": W, "lanes_per_row": lay["lanes"], "x_window_in_lds": lay["x_window"], "ell_entries": ell_nnz, "ell_padding_fraction": 1.0 - ell_nnz / float(npad * W),
            "tail_rows": tail_rows, "tail_entries": tail_nnz, "matrix_GB_stored": stored["matrix_bytes"] / 1e9,
            "check_parts_sum_to_whole_bitwise": parts_equal, "check_sampled_rows_max_rel_err": worst}
     del rowptr, col, val
@@ -1024,7 +1036,8 @@ def wl_irregular_spmv(args):
                     "frac_hbm_peak": nbytes / cold["median"] / 1e6 / HBM_PEAK_GBS, "ms_back_to_back": warm, "GBps_back_to_back": nbytes / warm / 1e6}
     out["algorithmic_bytes_survey_formula"] = spmv_algorithmic_bytes(nnz, N, N)
     out["GBps_survey_formula"] = out["algorithmic_bytes_survey_formula"] / out["whole"]["ms_cold_caches"] / 1e6
-    tr, note = pmc_traffic_workload("irregular_spmv")
+    del A, xf, yf, y1
+    tr, note = pmc_traffic_workload("irregular_spmv_w%d" % window)
     out["roofline"] = {"kernel": "ell_spmv_rowthread + csr_tail_kernel (whole apply)", "bound": "hbm", "achieved": out["whole"]["GBps"], "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": out["whole"]["frac_hbm_peak"], "traffic": tr, "traffic_note": note,
                        "bytes_per_launch": b_ell + b_tail}

@@ -111,9 +111,11 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  * entries are summed in CSR order by one thread (products staged in LDS) and added to the row's ELL sum — unless there are
  * more than *tail_chunk_cap of them, which one wave sums (64 lanes striding, tree); *reach = max |column - row| when the
  * operator has a row-pattern dictionary, else 0 (it decides the row -> workgroup map of the GCR kernels that embed the
- * apply).  Any pointer may be NULL.  tests/test_gpu_bitwise.py feeds these to the CPU oracle's model of the device's
+ * apply); *x_window = H > 0 when the stand-alone apply stages x[tile - H, tile + 1024 + H) in LDS (banded irregular matrices:
+ * >= 90 % of the slab's columns within H rows of their row; no influence on the bits).  Any pointer may be NULL.  tests/test_gpu_bitwise.py feeds these to the CPU oracle's model of the device's
  * summation order. */
-int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap);
+int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap,
+                       int32_t *x_window);
 /* Sparse::dagger / mod_*_at (src/Operator.h:296-328,84-86) change a Sparse IN PLACE while a DiracOp, GCR or MG may hold a
  * pointer to it (src/Operator.h:117): this replaces the matrix behind an existing handle, so that every operator that
  * borrowed the handle (mgcr_dirac_create, mgcr_gcr_create) applies the new matrix.  On failure the old matrix stays.

@@ -188,9 +188,9 @@ class Operator:
 
     def ell_layout(self):
         """dict(ell_width, lanes, tail_rows, reach, tail_chunk_cap): how a Sparse's rows are dealt to threads (include/mgcr.h)."""
-        w, l, t, r, cap = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
-        check(_lib.lib().mgcr_op_ell_layout(self.h, C.byref(w), C.byref(l), C.byref(t), C.byref(r), C.byref(cap)))
-        return dict(ell_width=w.value, lanes=l.value, tail_rows=t.value, reach=r.value, tail_chunk_cap=cap.value)
+        w, l, t, r, cap, win = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        check(_lib.lib().mgcr_op_ell_layout(self.h, C.byref(w), C.byref(l), C.byref(t), C.byref(r), C.byref(cap), C.byref(win)))
+        return dict(ell_width=w.value, lanes=l.value, tail_rows=t.value, reach=r.value, tail_chunk_cap=cap.value, x_window=win.value)
 
     def storage_format(self):
         """(format, n_patterns): 0 ELL slab, 1 row-pattern dictionary (columns + values), 2 (columns only)."""

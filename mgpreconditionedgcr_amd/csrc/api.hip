@@ -148,7 +148,8 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns) {
     return MGCR_OK;
 }
 
-int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap) {
+int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap,
+                       int32_t *x_window) {
     MGCR_CHECK(op, MGCR_ERR_INVALID, "null operator");
     const Op *o = op->kind == OP_DIRAC ? op->base : op;
     MGCR_CHECK(o->kind == OP_CSR, MGCR_ERR_UNSUPPORTED, "mgcr_op_ell_layout: not a Sparse");
@@ -157,6 +158,7 @@ int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t
     if (tail_rows) *tail_rows = o->csr.n_tail_rows;
     if (reach) *reach = o->csr.reach;
     if (tail_chunk_cap) *tail_chunk_cap = TAIL_CAP;
+    if (x_window) *x_window = o->csr.win_h;
     return MGCR_OK;
 }
 

@@ -113,6 +113,10 @@ struct CsrDev {
     int32_t sten_halo = 0;        // largest |offset| among them (0: no window)
     uint32_t sten_near_f = 0;     // the same for the fused GCR step kernels, whose window spans RED_THREADS rows: within RED_THREADS / 2
     int32_t sten_halo_f = 0;
+    // Banded irregular matrices (spmv.hip ell_window_try): when at least 90 % of the slab's columns lie within win_h rows of their
+    // row, the stand-alone apply stages x[r0 - win_h, r0 + 1024 + win_h) of each 1024-row tile in LDS and serves those gathers
+    // from there (0: no window)
+    int32_t win_h = 0;
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]

@@ -517,6 +517,54 @@ static int sten_try(CsrDev &A) {
     return MGCR_OK;
 }
 
+// How local are the slab's columns?  (count of slots within 1024 / 4096 rows of their row)
+__global__ void __launch_bounds__(256) ell_band_count_kernel(int64_t nrow, int64_t npad, int32_t W, const int32_t *__restrict__ col,
+                                                             unsigned long long *__restrict__ cnt) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long c1 = 0, c4 = 0;
+    if (row < nrow)
+        for (int32_t w = 0; w < W; w++) {
+            const int64_t d = (int64_t)col[(int64_t)w * npad + row] - row;
+            const int64_t a = d < 0 ? -d : d;
+            c1 += a <= 1024;
+            c4 += a <= 4096;
+        }
+    // wave totals, then one atomic per wave and counter
+    for (int off = 32; off >= 1; off >>= 1) {
+        c1 += __shfl_down(c1, off, 64);
+        c4 += __shfl_down(c4, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(cnt, c1);
+        atomicAdd(cnt + 1, c4);
+    }
+}
+constexpr int ELL_WIN_ROWS = 1024;   // rows per workgroup of the window kernel
+static bool ell_window_enabled() {
+    static const bool on = !(getenv("MGCR_ELL_WINDOW") && atoi(getenv("MGCR_ELL_WINDOW")) == 0);
+    return on;
+}
+// Banded irregular matrices (FEM / graph matrices in a bandwidth-reducing order): the gathers of x, one L2 request of 128 B per
+// 16-byte entry, are what bounds the slab kernel (profiles/r03_gather_lab.txt); with >= 90 % of the columns within H rows of the
+// row the window kernel reads x[tile - H, tile + 1024 + H) once, coalesced, into LDS and gathers from there.
+static int ell_window_try(CsrDev &A) {
+    A.win_h = 0;
+    if (!ell_window_enabled()) return MGCR_OK;
+    unsigned long long *d_cnt = nullptr, h_cnt[2] = {0, 0};
+    MGCR_HIP(hipMalloc((void **)&d_cnt, 2 * sizeof(unsigned long long)));
+    MGCR_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), ctx().stream));
+    hipLaunchKernelGGL(ell_band_count_kernel, dim3((unsigned)((A.nrow + 255) / 256)), dim3(256), 0, ctx().stream, A.nrow, A.npad, A.W,
+                       (const int32_t *)A.ell_col, d_cnt);
+    MGCR_HIP(hipGetLastError());
+    MGCR_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx().stream));
+    MGCR_HIP(hipStreamSynchronize(ctx().stream));
+    hipFree(d_cnt);
+    const double slots = (double)A.nrow * A.W;
+    if ((double)h_cnt[0] >= 0.9 * slots) A.win_h = 1024;
+    else if ((double)h_cnt[1] >= 0.9 * slots) A.win_h = 4096;
+    return MGCR_OK;
+}
+
 // device CSR (already resident) + host row pointers -> CsrDev
 static bool real_storage_enabled() {
     static const bool on = !(getenv("MGCR_REAL_STORAGE") && atoi(getenv("MGCR_REAL_STORAGE")) == 0);
@@ -619,6 +667,7 @@ static int ell_from_device_csr(int64_t nrow, int64_t ncol, const int64_t *h_rowp
         MGCR_TRY(pat_try<false>(A, &ok));
         if (ok) { hipFree(A.ell_col); A.ell_col = nullptr; }
     }
+    if (slab && A.L == 1 && A.pat_mode == 0 && A.nrow == A.ncol && A.nrow >= ELL_WIN_ROWS && A.W >= 2) MGCR_TRY(ell_window_try(A));
     // Real matrices (every imaginary part exactly 0, e.g. Poisson): keep the slab's values as fp64
     // reals, 12 B instead of 20 B per stored entry.  v*(c+di) with v real is (vc, vd): the same numbers
     // the complex product (vc - 0*d, vd + 0*c) gives for finite x.
@@ -724,6 +773,49 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
         }
     }
     if (!stopped) y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
+}
+
+// ELL slab, one thread per row, x window in LDS (banded irregular matrices: CsrDev::win_h).  A workgroup owns 1024 consecutive
+// rows; x[r0 - H, r0 + 1024 + H) is read once, coalesced, into LDS and every column inside it is served from there — the few
+// outside take the global gather.  Same products, added in the same (CSR) order as ell_spmv_rowthread: same bits.
+template <bool SHIFT, bool REALV, int H>
+__global__ void __launch_bounds__(ELL_WIN_ROWS) ell_spmv_window(int64_t nrow, int64_t npad, int32_t W, int64_t ntiles, const void *__restrict__ val,
+                                                                const int32_t *__restrict__ col, const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                                cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
+    cplx *win = reinterpret_cast<cplx *>(win_smem);
+    const int64_t tile = ntiles >= 64 ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t r0 = tile * ELL_WIN_ROWS, base = r0 - H;
+    constexpr int WLEN = ELL_WIN_ROWS + 2 * H;
+    const int64_t row = r0 + threadIdx.x;
+    // the row's first columns are requested together with the window (they do not depend on it)
+    int32_t j0 = 0, j1 = 0;
+    if (row < nrow) {
+        j0 = ldcol<true>(col + row);
+        if (W > 1) j1 = ldcol<true>(col + npad + row);
+    }
+    for (int t = threadIdx.x; t < WLEN; t += ELL_WIN_ROWS) {
+        int64_t g = base + t;
+        g = g < 0 ? 0 : g >= nrow ? nrow - 1 : g;
+        win[t] = x[g];
+    }
+    const bool stopped = stop_flag(skip, skip_it);
+    __syncthreads();
+    if (row >= nrow || stopped) return;
+    cplx sum = make_double2(0., 0.);
+    auto xat = [&](int32_t j) -> cplx {
+        const int64_t off = (int64_t)j - base;
+        return (off >= 0 && off < WLEN) ? win[off] : x[j];
+    };
+    sum = cadd(sum, vmul<REALV, true>(val, row, xat(j0)));
+    if (W > 1) sum = cadd(sum, vmul<REALV, true>(val, npad + row, xat(j1)));
+#pragma unroll 4
+    for (int32_t c = 2; c < W; c++) {
+        const int32_t j = ldcol<true>(col + (int64_t)c * npad + row);
+        sum = cadd(sum, vmul<REALV, true>(val, (int64_t)c * npad + row, xat(j)));
+    }
+    y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
 }
 
 // Row-pattern dictionary SpMV (L = 1): one thread per row; the row's 2-byte id selects the table row
@@ -1176,6 +1268,27 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
 #undef PT_X
 #undef PT_RV
 #undef PT
+        MGCR_HIP(hipGetLastError());
+        return MGCR_OK;
+    }
+    if (A.L == 1 && A.win_h && !xh && row_begin == 0 && row_count == A.nrow && !A.pat_mode) {
+        const int64_t ntiles = (A.nrow + ELL_WIN_ROWS - 1) / ELL_WIN_ROWS;
+        const unsigned grid = (unsigned)(ntiles >= 64 ? ((ntiles + 7) / 8) * 8 : ntiles);
+        const void *vals = A.ell_val_re ? (const void *)A.ell_val_re : (const void *)A.ell_val;
+        const size_t lds = sizeof(cplx) * (size_t)(ELL_WIN_ROWS + 2 * A.win_h);
+#define WK(RV, HH)                                                                                                                    \
+    do {                                                                                                                              \
+        static bool big_lds = false;                                                                                                  \
+        if (!big_lds) {                                                                                                               \
+            MGCR_HIP(hipFuncSetAttribute((const void *)ell_spmv_window<SHIFT, RV, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            big_lds = true;                                                                                                           \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((ell_spmv_window<SHIFT, RV, HH>), dim3(grid), dim3(ELL_WIN_ROWS), lds, c.stream, A.nrow, A.npad, A.W, ntiles, vals, \
+                           (const int32_t *)A.ell_col, x, y, k, w, g_skip.p, g_skip.it);                                              \
+    } while (0)
+        if (A.win_h == 1024) { if (A.ell_val_re) WK(true, 1024); else WK(false, 1024); }
+        else { if (A.ell_val_re) WK(true, 4096); else WK(false, 4096); }
+#undef WK
         MGCR_HIP(hipGetLastError());
         return MGCR_OK;
     }

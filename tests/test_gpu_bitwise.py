@@ -361,3 +361,40 @@ def test_irregular_spmv_bit_for_bit(nrow, ncol, kw):
         tails = np.diff(rowptr) - lay["ell_width"]
         seq = tails <= 0
         assert np.array_equal(y[seq], Ao(x)[seq])      # no tail: the reference's bits
+
+
+@pytest.mark.parametrize("window,want_h", [(300, 1024), (3000, 4096), (30000, 0)])
+def test_banded_irregular_spmv_window_bit_for_bit(window, want_h):
+    """Banded irregular matrices (>= 90 % of the slab's columns within 1024 / 4096 rows of their row) are multiplied by the kernel
+    that stages x in an LDS window (spmv.hip ell_spmv_window): same products in the same order as the slab kernel — the oracle's
+    bits with the layout's association, DiracOp epilogue included, and the bits of the kernel without the window."""
+    rng = np.random.default_rng(window)
+    N = 70000
+    rowptr, col, val = problems.skewed_csr(N, rng, window=window, long_rows=3, long_len=2500)
+    x = problems.rhs_grid(N, 3)
+    A = Sparse(N, N, rowptr, col, val)
+    lay = A.ell_layout()
+    assert lay["x_window"] == want_h and lay["tail_rows"] > 0
+    Ao = orc.csr(N, N, rowptr, col, val)
+    y = A(Field((N,), x)).to_numpy()
+    k = 0.3 - 0.2j
+    yd = DiracOp(A, k)(Field((N,), x)).to_numpy()
+    with device_model(A, N, False):
+        assert np.array_equal(y, Ao(x))
+        assert np.array_equal(yd, orc.dirac(Ao, k)(x))
+    if want_h:
+        os.environ["MGCR_ELL_WINDOW"] = "0"      # (read once per process: only a child process sees it)
+        import subprocess
+        import sys
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import mgpreconditionedgcr_amd as mg; from mgpreconditionedgcr_amd import problems, Sparse, Field;"
+                "rng = np.random.default_rng(%d); rp, c, v = problems.skewed_csr(%d, rng, window=%d, long_rows=3, long_len=2500);"
+                "A = Sparse(%d, %d, rp, c, v); assert A.ell_layout()['x_window'] == 0;"
+                "np.save(sys.argv[1], A(Field((%d,), problems.rhs_grid(%d, 3))).to_numpy())" % (ROOT, window, N, window, N, N, N, N))
+        out = os.path.join(ROOT, "gpurun_out", "y_nowindow_%d.npy" % window)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        try:
+            p = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, timeout=300)
+        finally:
+            del os.environ["MGCR_ELL_WINDOW"]
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert np.array_equal(y, np.load(out))
