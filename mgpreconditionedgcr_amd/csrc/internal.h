@@ -117,6 +117,9 @@ struct CsrDev {
     // row, the stand-alone apply stages x[r0 - win_h, r0 + 1024 + win_h) of each 1024-row tile in LDS and serves those gathers
     // from there (0: no window)
     int32_t win_h = 0;
+    // ... and the tile's TAIL entries are multiplied in the same launch from the same window (spmv.hip ell_spmv_window<.., TAIL>):
+    int32_t *win_tile_tail = nullptr;   // [ntiles + 1] first tail row (index into tail_rows) whose row is >= tile * 1024
+    int32_t *win_row_tail = nullptr;    // [nrow] the row's index into tail_rows; -1: no tail, or a tail longer than a chunk (csr_tail_kernel's)
     int64_t n_tail_rows = 0, tail_nnz = 0;
     int32_t *tail_rows = nullptr;   // [n_tail_rows]
     int32_t *tail_ptr = nullptr;    // [n_tail_rows+1]

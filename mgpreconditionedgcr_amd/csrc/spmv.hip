@@ -102,7 +102,7 @@ void csr_free(CsrDev *c) {
     hipFree(c->ell_val); hipFree(c->ell_val_re); hipFree(c->ell_col);
     hipFree(c->pat_id); hipFree(c->pat_off); hipFree(c->pat_re); hipFree(c->pat_im); hipFree(c->sten_planes);
     hipFree(c->tail_rows); hipFree(c->tail_ptr); hipFree(c->tail_col); hipFree(c->tail_val);
-    hipFree(c->tail_chunk); hipFree(c->tail_long);
+    hipFree(c->tail_chunk); hipFree(c->tail_long); hipFree(c->win_tile_tail); hipFree(c->win_row_tail);
     *c = CsrDev();
 }
 
@@ -668,6 +668,20 @@ static int ell_from_device_csr(int64_t nrow, int64_t ncol, const int64_t *h_rowp
         if (ok) { hipFree(A.ell_col); A.ell_col = nullptr; }
     }
     if (slab && A.L == 1 && A.pat_mode == 0 && A.nrow == A.ncol && A.nrow >= ELL_WIN_ROWS && A.W >= 2) MGCR_TRY(ell_window_try(A));
+    if (A.win_h && A.n_tail_rows) {
+        // per tile: its first tail row; per row: its index into the tail-row list (-1: none, or longer than a chunk)
+        const int64_t ntiles = (A.nrow + ELL_WIN_ROWS - 1) / ELL_WIN_ROWS;
+        std::vector<int32_t> tile_tail((size_t)ntiles + 1, (int32_t)trows.size()), row_tail((size_t)A.nrow, -1);
+        for (int32_t t = (int32_t)trows.size() - 1; t >= 0; t--) {
+            tile_tail[(size_t)(trows[(size_t)t] / ELL_WIN_ROWS)] = t;
+            if (tptr[(size_t)t + 1] - tptr[(size_t)t] <= TAIL_CAP) row_tail[(size_t)trows[(size_t)t]] = t;
+        }
+        for (int64_t q = ntiles - 1; q >= 0; q--)   // tiles without tail rows: the next tile's first
+            if (tile_tail[(size_t)q] > tile_tail[(size_t)q + 1]) tile_tail[(size_t)q] = tile_tail[(size_t)q + 1];
+        MGCR_TRY(dev_upload(&A.win_tile_tail, tile_tail.data(), tile_tail.size()));
+        MGCR_TRY(dev_upload(&A.win_row_tail, row_tail.data(), row_tail.size()));
+        MGCR_HIP(hipStreamSynchronize(c.stream));
+    }
     // Real matrices (every imaginary part exactly 0, e.g. Poisson): keep the slab's values as fp64
     // reals, 12 B instead of 20 B per stored entry.  v*(c+di) with v real is (vc, vd): the same numbers
     // the complex product (vc - 0*d, vd + 0*c) gives for finite x.
@@ -778,22 +792,40 @@ __global__ void __launch_bounds__(256) ell_spmv_rowthread(int64_t row_begin, int
 // ELL slab, one thread per row, x window in LDS (banded irregular matrices: CsrDev::win_h).  A workgroup owns 1024 consecutive
 // rows; x[r0 - H, r0 + 1024 + H) is read once, coalesced, into LDS and every column inside it is served from there — the few
 // outside take the global gather.  Same products, added in the same (CSR) order as ell_spmv_rowthread: same bits.
-template <bool SHIFT, bool REALV, int H>
+// TAIL: the CSR tail of the tile's rows in the SAME launch.  The tail entries of consecutive rows are one contiguous piece of the
+// tail arrays: the workgroup streams it 1024 entries at a time (coalesced), gathers x from the window it already holds, stages the
+// products in LDS, and every thread adds the products of ITS row in CSR order onto a tail sum; y = (ELL sum) + (tail sum) is
+// written once — csr_tail_chunk_kernel's arithmetic and order (same bits) without the second launch, the second gather of x from
+// memory and the read-modify-write of y.  Rows whose tail is longer than a chunk (TAIL_CAP) are left to csr_tail_kernel.
+constexpr int WIN_TAIL_PER = 2;                           // tail entries per thread and trip
+constexpr int WIN_TAIL_CH = WIN_TAIL_PER * ELL_WIN_ROWS;   // tail entries staged per trip (32 KB of products)
+template <bool SHIFT, bool REALV, int H, bool TAIL>
 __global__ void __launch_bounds__(ELL_WIN_ROWS) ell_spmv_window(int64_t nrow, int64_t npad, int32_t W, int64_t ntiles, const void *__restrict__ val,
                                                                 const int32_t *__restrict__ col, const cplx *__restrict__ x, cplx *__restrict__ y,
-                                                                cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it) {
+                                                                cplx k, const cplx *__restrict__ w, const int *__restrict__ skip, int skip_it,
+                                                                const int32_t *__restrict__ tile_tail, const int32_t *__restrict__ row_tail,
+                                                                const int32_t *__restrict__ tail_ptr, const int32_t *__restrict__ tail_col,
+                                                                const cplx *__restrict__ tail_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
     cplx *win = reinterpret_cast<cplx *>(win_smem);
+    constexpr int WLEN = ELL_WIN_ROWS + 2 * H;
+    cplx *prod = win + WLEN;   // [WIN_TAIL_CH] (TAIL only)
     const int64_t tile = ntiles >= 64 ? xcd_tile(ntiles) : (int64_t)blockIdx.x;
     if (tile >= ntiles) return;
     const int64_t r0 = tile * ELL_WIN_ROWS, base = r0 - H;
-    constexpr int WLEN = ELL_WIN_ROWS + 2 * H;
     const int64_t row = r0 + threadIdx.x;
+    const bool live = row < nrow;
     // the row's first columns are requested together with the window (they do not depend on it)
     int32_t j0 = 0, j1 = 0;
-    if (row < nrow) {
+    if (live) {
         j0 = ldcol<true>(col + row);
         if (W > 1) j1 = ldcol<true>(col + npad + row);
+    }
+    int32_t t0 = 0, t1 = 0, ti = -1;
+    if (TAIL) {
+        t0 = tile_tail[tile];
+        t1 = tile_tail[tile + 1];
+        if (live) ti = row_tail[row];
     }
     for (int t = threadIdx.x; t < WLEN; t += ELL_WIN_ROWS) {
         int64_t g = base + t;
@@ -802,20 +834,76 @@ __global__ void __launch_bounds__(ELL_WIN_ROWS) ell_spmv_window(int64_t nrow, in
     }
     const bool stopped = stop_flag(skip, skip_it);
     __syncthreads();
-    if (row >= nrow || stopped) return;
-    cplx sum = make_double2(0., 0.);
+    if (stopped) return;   // (uniform)
     auto xat = [&](int32_t j) -> cplx {
         const int64_t off = (int64_t)j - base;
         return (off >= 0 && off < WLEN) ? win[off] : x[j];
     };
-    sum = cadd(sum, vmul<REALV, true>(val, row, xat(j0)));
-    if (W > 1) sum = cadd(sum, vmul<REALV, true>(val, npad + row, xat(j1)));
+    cplx sum = make_double2(0., 0.);
+    if (live) {
+        sum = cadd(sum, vmul<REALV, true>(val, row, xat(j0)));
+        if (W > 1) sum = cadd(sum, vmul<REALV, true>(val, npad + row, xat(j1)));
 #pragma unroll 4
-    for (int32_t c = 2; c < W; c++) {
-        const int32_t j = ldcol<true>(col + (int64_t)c * npad + row);
-        sum = cadd(sum, vmul<REALV, true>(val, (int64_t)c * npad + row, xat(j)));
+        for (int32_t c = 2; c < W; c++) {
+            const int32_t j = ldcol<true>(col + (int64_t)c * npad + row);
+            sum = cadd(sum, vmul<REALV, true>(val, (int64_t)c * npad + row, xat(j)));
+        }
     }
-    y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
+    if (!TAIL) {
+        if (live) y[row] = SHIFT ? csub((w ? w : x)[row], cmul(k, sum)) : sum;
+        return;
+    }
+    const int32_t e0 = tail_ptr[t0], e1 = tail_ptr[t1];
+    int32_t rb = 0, re = 0;
+    if (ti >= 0) { rb = tail_ptr[ti]; re = tail_ptr[ti + 1]; }
+    cplx tsum = make_double2(0., 0.);
+    // the next trip's columns and values are requested before this trip's products are formed and summed: their latency hides
+    // behind the LDS phase (two workgroups per CU do not hide it by themselves)
+    int32_t jn[WIN_TAIL_PER];
+    cplx vn[WIN_TAIL_PER];
+    auto fetch = [&](int32_t cb) {
+#pragma unroll
+        for (int q = 0; q < WIN_TAIL_PER; q++) {
+            const int32_t e = cb + q * ELL_WIN_ROWS + (int32_t)threadIdx.x;
+            jn[q] = -1;
+            vn[q] = make_double2(0., 0.);
+            if (e < e1) {
+                jn[q] = tail_col[e];
+                vn[q] = make_double2(__builtin_nontemporal_load(&tail_val[e].x), __builtin_nontemporal_load(&tail_val[e].y));
+            }
+        }
+    };
+    if (e0 < e1) fetch(e0);
+    for (int32_t cb = e0; cb < e1; cb += WIN_TAIL_CH) {   // uniform trip count
+        int32_t jc[WIN_TAIL_PER];
+        cplx vc[WIN_TAIL_PER];
+#pragma unroll
+        for (int q = 0; q < WIN_TAIL_PER; q++) { jc[q] = jn[q]; vc[q] = vn[q]; }
+        if (cb + WIN_TAIL_CH < e1) fetch(cb + WIN_TAIL_CH);
+#pragma unroll
+        for (int q = 0; q < WIN_TAIL_PER; q++)
+            if (jc[q] >= 0) prod[q * ELL_WIN_ROWS + threadIdx.x] = cmul(vc[q], xat(jc[q]));
+        __syncthreads();
+        const int32_t ib = (rb > cb ? rb : cb) - cb, ie = (re < cb + WIN_TAIL_CH ? re : cb + WIN_TAIL_CH) - cb;
+        {   // this row's products of the trip, in CSR order (four independent LDS reads in flight)
+            int32_t i = ib;
+            for (; i + 4 <= ie; i += 4) {
+                const cplx p0 = prod[i], p1 = prod[i + 1], p2 = prod[i + 2], p3 = prod[i + 3];
+                tsum = cadd(cadd(cadd(cadd(tsum, p0), p1), p2), p3);
+            }
+            for (; i < ie; i++) tsum = cadd(tsum, prod[i]);
+        }
+        __syncthreads();
+    }
+    if (live) {
+        if (SHIFT) {
+            cplx v = csub((w ? w : x)[row], cmul(k, sum));
+            if (ti >= 0) v = csub(v, cmul(k, tsum));
+            y[row] = v;
+        } else {
+            y[row] = ti >= 0 ? cadd(sum, tsum) : sum;
+        }
+    }
 }
 
 // Row-pattern dictionary SpMV (L = 1): one thread per row; the row's 2-byte id selects the table row
@@ -1182,6 +1270,23 @@ __global__ void __launch_bounds__(TAIL_THREADS) csr_tail_chunk_kernel(const int4
     }
 }
 
+// measurement aid (bench.py: the ELL part and the CSR tail of a hybrid matrix timed separately): 0 = the whole apply,
+// 1 = only the ELL slab's kernel, 2 = only the tail kernel (which then adds to whatever y holds).  mgcr_set_option("spmv_part").
+static int g_spmv_part = 0;
+int set_spmv_part(int part) {
+    const int prev = g_spmv_part;
+    g_spmv_part = part < 0 || part > 2 ? 0 : part;
+    return prev;
+}
+
+// does the window kernel of A also multiply the chunk-sized tails (one launch for slab + tail)?  Not while bench.py times the
+// two parts apart (spmv_part), not for the row block of a distributed matrix (halo columns live outside x)
+static bool window_fuses_tail(const CsrDev &A) {
+    static const bool on = !(getenv("MGCR_ELL_WINDOW_TAIL") && atoi(getenv("MGCR_ELL_WINDOW_TAIL")) == 0);
+    // (H = 4096: the window alone takes 144 KB — with the products' 32 KB there is no room, and with 16 KB it measured slower than two launches)
+    return on && A.win_h == 1024 && A.win_tile_tail && A.win_row_tail && g_spmv_part == 0;
+}
+
 static SkipRef g_skip;  // consulted by apply kernels (set by the GCR driver around its operator applies)
 void set_apply_skip(SkipRef s) { g_skip = s; }
 SkipRef get_apply_skip() { return g_skip; }
@@ -1275,19 +1380,23 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
         const int64_t ntiles = (A.nrow + ELL_WIN_ROWS - 1) / ELL_WIN_ROWS;
         const unsigned grid = (unsigned)(ntiles >= 64 ? ((ntiles + 7) / 8) * 8 : ntiles);
         const void *vals = A.ell_val_re ? (const void *)A.ell_val_re : (const void *)A.ell_val;
-        const size_t lds = sizeof(cplx) * (size_t)(ELL_WIN_ROWS + 2 * A.win_h);
-#define WK(RV, HH)                                                                                                                    \
+        const bool tail = window_fuses_tail(A);
+        const size_t lds = sizeof(cplx) * (size_t)(ELL_WIN_ROWS + 2 * A.win_h + (tail ? WIN_TAIL_CH : 0));
+#define WK(RV, HH, TL)                                                                                                                \
     do {                                                                                                                              \
         static bool big_lds = false;                                                                                                  \
         if (!big_lds) {                                                                                                               \
-            MGCR_HIP(hipFuncSetAttribute((const void *)ell_spmv_window<SHIFT, RV, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            MGCR_HIP(hipFuncSetAttribute((const void *)ell_spmv_window<SHIFT, RV, HH, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             big_lds = true;                                                                                                           \
         }                                                                                                                             \
-        hipLaunchKernelGGL((ell_spmv_window<SHIFT, RV, HH>), dim3(grid), dim3(ELL_WIN_ROWS), lds, c.stream, A.nrow, A.npad, A.W, ntiles, vals, \
-                           (const int32_t *)A.ell_col, x, y, k, w, g_skip.p, g_skip.it);                                              \
+        hipLaunchKernelGGL((ell_spmv_window<SHIFT, RV, HH, TL>), dim3(grid), dim3(ELL_WIN_ROWS), lds, c.stream, A.nrow, A.npad, A.W, ntiles, vals, \
+                           (const int32_t *)A.ell_col, x, y, k, w, g_skip.p, g_skip.it, (const int32_t *)A.win_tile_tail,              \
+                           (const int32_t *)A.win_row_tail, (const int32_t *)A.tail_ptr, (const int32_t *)A.tail_col, (const cplx *)A.tail_val); \
     } while (0)
-        if (A.win_h == 1024) { if (A.ell_val_re) WK(true, 1024); else WK(false, 1024); }
-        else { if (A.ell_val_re) WK(true, 4096); else WK(false, 4096); }
+#define WK_T(RV, HH) do { if (tail) WK(RV, HH, true); else WK(RV, HH, false); } while (0)
+        if (A.win_h == 1024) { if (A.ell_val_re) WK_T(true, 1024); else WK_T(false, 1024); }
+        else { if (A.ell_val_re) WK_T(true, 4096); else WK_T(false, 4096); }
+#undef WK_T
 #undef WK
         MGCR_HIP(hipGetLastError());
         return MGCR_OK;
@@ -1341,15 +1450,6 @@ static int ell_rows(const CsrDev &A, int64_t row_begin, int64_t row_count, const
     return MGCR_OK;
 }
 
-// measurement aid (bench.py: the ELL part and the CSR tail of a hybrid matrix timed separately): 0 = the whole apply,
-// 1 = only the ELL slab's kernel, 2 = only the tail kernel (which then adds to whatever y holds).  mgcr_set_option("spmv_part").
-static int g_spmv_part = 0;
-int set_spmv_part(int part) {
-    const int prev = g_spmv_part;
-    g_spmv_part = part < 0 || part > 2 ? 0 : part;
-    return prev;
-}
-
 template <bool SHIFT>
 static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr *dist, const cplx *w) {
     Context &c = ctx();
@@ -1371,7 +1471,7 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
         MGCR_TRY(ell_rows<SHIFT>(A, 0, A.nrow, x, xh, n_own, y, k, w));
     }
     if (A.n_tail_rows && g_spmv_part != 1) {
-        if (A.n_tail_chunks) {
+        if (A.n_tail_chunks && !(window_fuses_tail(A) && !dist)) {
             hipLaunchKernelGGL((csr_tail_chunk_kernel<SHIFT>), dim3((unsigned)A.n_tail_chunks), dim3(TAIL_THREADS), 0, c.stream, (const int4 *)A.tail_chunk,
                                A.tail_rows, A.tail_ptr, A.tail_col, A.tail_val, x, xh, n_own, y, k, g_skip.p, g_skip.it);
             MGCR_HIP(hipGetLastError());
