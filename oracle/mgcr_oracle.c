@@ -73,6 +73,18 @@ void orc_set_device_model(int blocks, int64_t band, int per, int init_banded, in
     g_dev_ell_w = ell_width; g_dev_ell_l = ell_lanes < 1 ? 1 : ell_lanes; g_dev_tail_cap = tail_cap;
 }
 
+/* Several ranks (one process per GPU, rows dealt in contiguous blocks: csrc/comm.hip): every rank sums the terms of ITS rows as
+ * above (grid of red_grid(rows of the rank) workgroups over local row numbers), the rank totals are then added in rank order
+ * onto 0 (fold_pw_kernel: identical bits on every rank).  A row's entries keep their CSR order on every rank, halo columns
+ * included, whatever the block's storage (measured: tests/test_gpu_dist.py compares the distributed apply bit for bit). */
+#define DEV_MAX_RANKS 16
+static int g_dev_nranks = 1;
+static int64_t g_dev_rank_off[DEV_MAX_RANKS + 1];
+void orc_set_device_ranks(int nranks, const int64_t *row_offsets) {
+    g_dev_nranks = nranks < 1 ? 1 : nranks > DEV_MAX_RANKS ? DEV_MAX_RANKS : nranks;
+    for (int r = 0; r <= g_dev_nranks && nranks >= 1; r++) g_dev_rank_off[r] = row_offsets ? row_offsets[r] : 0;
+}
+
 static int dev_grid(int64_t n) {
     if (g_dev_blocks > 0) return g_dev_blocks;
     int64_t g = (n + DEV_THREADS - 1) / DEV_THREADS;
@@ -116,6 +128,16 @@ static double dev_sum(int64_t n, const double *term, int banded) {
     if (g == 1) return parts[0] + 0.; /* fold_partials: one partial is loaded as it is (x + 0.0) */
     return dev_block_sum(parts);
 }
+static double dev_sum_ranks(int64_t n, const double *term, int banded) {
+    if (g_dev_nranks <= 1) return dev_sum(n, term, banded);
+    double tot = 0.;
+    for (int r = 0; r < g_dev_nranks; r++) {
+        const int64_t a = g_dev_rank_off[r], b = g_dev_rank_off[r + 1];
+        tot += dev_sum(b - a, term + a, 0); /* (the banded row map is a matter of >= 2^23-row blocks: single-rank tests cover it) */
+    }
+    (void)n;
+    return tot;
+}
 static int g_dev_banded_now = 0; /* set by the GCR loop around the sums the apply-embedding kernels take */
 static cplx dot_device(int64_t n, const cplx *a, const cplx *b) {
     double *re = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1)), *im = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
@@ -124,14 +146,14 @@ static cplx dot_device(int64_t n, const cplx *a, const cplx *b) {
         re[i] = ax * bx + ay * by;   /* conj(a) * b, un-fused (reduce.h:cconj_mul) */
         im[i] = ax * by - ay * bx;
     }
-    const double sr = dev_sum(n, re, g_dev_banded_now), si = dev_sum(n, im, g_dev_banded_now);
+    const double sr = dev_sum_ranks(n, re, g_dev_banded_now), si = dev_sum_ranks(n, im, g_dev_banded_now);
     free(re); free(im);
     return sr + si * I;
 }
 static double sqnorm_device(int64_t n, const cplx *a) {
     double *t = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
     for (int64_t i = 0; i < n; i++) { const double x = creal(a[i]), y = cimag(a[i]); t[i] = x * x + y * y; }
-    const double s = dev_sum(n, t, g_dev_banded_now);
+    const double s = dev_sum_ranks(n, t, g_dev_banded_now);
     free(t);
     return s;
 }

@@ -64,6 +64,20 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
         assert np.abs(got - y).max() <= 1e-13 * np.abs(y).max()
         b = Field((N,), problems.rhs_grid(N, 1))
         Ao = orc.csr(N, N, rowptr, col, val)
+        # BIT FOR BIT against the oracle summing in the distributed device's order (tests/test_gpu_bitwise.py, here with the rank
+        # model: every rank sums its rows with its own grid, the rank totals are added in rank order — which the peer-write
+        # all-reduce guarantees; with two ranks any order gives the same bits): apply, restarted and truncated GCR histories.
+        # (Poisson kinds: every rank's block has the same ELL width and no tail; a row's entries keep their CSR order, halo columns
+        # included, also where the block is stored as a stencil view.)
+        if kind != "random" and (want == "peer-write" or world == 2):
+            from tests.dist_worker import split_rows
+            offs = np.array(split_rows(N // gran, world), np.int64) * gran
+            with orc.device_order(rank_offsets=offs):
+                assert np.array_equal(got, Ao(x)), kind
+                for tag, okw in (("", dict(restart=4, max_iter=25, tol=1e-30)), ("_trunc", dict(truncation=11, max_iter=25, tol=1e-30))):
+                    _, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(**okw), problems.rhs_grid(N, 1))
+                    for r in range(world):
+                        assert np.array_equal(res[r][kind]["hist" + tag], ho), (kind, tag, r)
         for tag, prm, okw in (("", GCR_Param(0, 4, 25, 1e-30, False), dict(restart=4, max_iter=25, tol=1e-30)),
                               ("_trunc", GCR_Param(11, 0, 25, 1e-30, False), dict(truncation=11, max_iter=25, tol=1e-30))):
             # how far the reference algorithm itself moves under re-association of its dot products
