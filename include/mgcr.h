@@ -142,6 +142,9 @@ int mgcr_csr_replace(mgcr_op_t op, int64_t nrow, int64_t ncol, const int64_t *ro
  *   "halo_split"      ($MGCR_HALO_SPLIT): the stand-alone apply of a distributed Sparse whose halo travels by peer writes stores and
  *                      publishes its boundary rows, multiplies the rows that need no halo, THEN waits for the neighbours and
  *                      multiplies the boundary rows (same bits; off: the exchange completes before any row).
+ *   "pw_tail"         ($MGCR_PW_TAIL): on a distributed operator whose scalars travel by peer writes, the kernel that produces a
+ *                      reduction's partials (apply + dot products of a stencil row block; direction build up to 8 directions) also
+ *                      folds them and sums them over the ranks in its last workgroup — no fold + exchange launch behind it (same bits).
  *   "spmv_part"       (measurement aid, default 0): 1 = a Sparse apply launches only its ELL-slab kernel, 2 = only its CSR-tail
  *                      kernel (bench.py times the two parts of the hybrid layout separately); 0 = the whole apply.
  * *previous (may be NULL) receives the old value. */
@@ -150,7 +153,8 @@ int mgcr_set_option(const char *name, int value, int *previous);
  * "step_build_launches" = steps that ran as one apply + build launch, "small_solves" = solves that ran as one launch of one
  * workgroup (csrc/gcr_small.hip), "one_launch_fallbacks" = top-level solves that were repeated on the multi-kernel path
  * because a one-launch path gave up (foreign work on the device: its grid was not co-resident), "halo_split_exchanges" =
- * peer-write halo exchanges of distributed applies that ran split (store + publish | interior rows | wait | boundary rows). */
+ * peer-write halo exchanges of distributed applies that ran split (store + publish | interior rows | wait | boundary rows),
+ * "pw_tail_folds" = reductions folded and summed over the ranks inside their producing kernel. */
 int mgcr_stat(const char *name, int64_t *value);
 
 /* Self-test of the hardware behaviour the one-launch solver paths (csrc/gcr_resident.hip, gcr_stepbuild.hip) build on: inside

@@ -186,6 +186,7 @@ int mgcr_set_option(const char *name, int value, int *previous) {
     else if (!strcmp(name, "resident_solver")) prev = set_resident_enabled(value != 0);
     else if (!strcmp(name, "step_build")) prev = set_stepbuild_enabled(value != 0);
     else if (!strcmp(name, "halo_split")) prev = set_halo_split(value != 0);
+    else if (!strcmp(name, "pw_tail")) prev = set_pw_tail_enabled(value != 0);
     else { set_error("mgcr_set_option: unknown option '%s'", name); return MGCR_ERR_INVALID; }
     if (previous) *previous = prev ? 1 : 0;
     return MGCR_OK;
@@ -198,6 +199,7 @@ int mgcr_stat(const char *name, int64_t *value) {
     else if (!strcmp(name, "small_solves")) *value = gcr_small_solve_count();
     else if (!strcmp(name, "one_launch_fallbacks")) *value = gcr_fallback_count();
     else if (!strcmp(name, "halo_split_exchanges")) *value = dist_halo_split_count();
+    else if (!strcmp(name, "pw_tail_folds")) *value = comm_pw_tail_count();
     else { set_error("mgcr_stat: unknown counter '%s'", name); return MGCR_ERR_INVALID; }
     return MGCR_OK;
 }

@@ -15,6 +15,7 @@
 
 #include "internal.h"
 #include "reduce.h"
+#include "pw_tail_dev.h"
 
 namespace mgcr {
 
@@ -93,6 +94,7 @@ struct Comm {
     uint64_t *pw_peer[PW_MAX_RANKS] = {};    // pw_peer[r]: rank r's mailbox as mapped here (own one for r == rank)
     uint32_t pw_seq = 0;                     // sequence number of the last all-reduce (never 0 on the wire)
     int *pw_err = nullptr;                   // pinned host word the kernel sets when a wait timed out
+    unsigned *pw_ticket = nullptr;           // device counter of the producer kernels' fold tails (pw_tail_dev.h)
 };
 
 // live communicators: every host synchronisation point that hands distributed results back asks each of them whether a
@@ -174,7 +176,6 @@ static int stage_reserve(Comm *c, size_t doubles) {
 struct PwPeers {
     uint64_t *mb[PW_MAX_RANKS];
 };
-constexpr int PW_MAX_SCALARS = 64;
 constexpr size_t PW_MBOX_WORDS = (size_t)2 * PW_MAX_RANKS * PW_MAX_SCALARS * 2;
 // wall_clock64 runs at 100 MHz.  Self-tests (ranks just synchronised by a set-up collective): 3 s.  Production: 20 s — the
 // ranks of one solve may arrive skewed (one of them still reading a file), but a wave must never spin anywhere near the
@@ -201,36 +202,7 @@ __global__ void __launch_bounds__(64) fold_pw_kernel(const double *__restrict__ 
     } else {
         acc = out[k];  // already folded: all-reduce in place
     }
-    acc = __shfl(acc, 0, 64);
-    const size_t slot = (size_t)(seq & 1u) * PW_MAX_RANKS;
-    double val = acc;
-    if (lane < nranks && lane != rank) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
-        uint64_t *dst = peers.mb[lane] + ((slot + (size_t)rank) * PW_MAX_SCALARS + (size_t)k) * 2;
-        __hip_atomic_store(dst, (bits & 0xffffffffull) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(dst + 1, (bits >> 32) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        uint64_t *src = peers.mb[rank] + ((slot + (size_t)lane) * PW_MAX_SCALARS + (size_t)k) * 2;
-        unsigned long long w0 = 0, w1 = 0;
-        const long long t0 = wall_clock64();
-        bool ok = false;
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-            for (;;) {
-                w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((uint32_t)(w0 >> 32) == seq && (uint32_t)(w1 >> 32) == seq) { ok = true; break; }
-                if (wall_clock64() - t0 > timeout) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        if (ok) {
-            val = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
-        } else {  // a peer never arrived: flag it (the host turns it into MGCR_ERR_COMM) and poison the result
-            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            val = __longlong_as_double(0x7ff8000000000000LL);
-        }
-    }
-    double tot = 0.;
-    for (int r = 0; r < nranks; r++) tot += __shfl(val, r, 64);  // rank order: the same bits on every rank
+    const double tot = pw_exchange_scalar(peers.mb, rank, nranks, seq, err, timeout, k, acc);   // (pw_tail_dev.h: shared with the producer kernels' tails)
     if (lane == 0) out[k] = tot;
 }
 
@@ -250,6 +222,36 @@ static int pw_launch(Comm *c, const double *pa, int na, const double *pb, int nb
 
 static int comm_allreduce_host(Comm *c, double *buf, int64_t count);
 
+// The fold + exchange of a reduction inside the kernel that produces its partials (pw_tail_dev.h)
+static int g_pw_tail = -1;
+static int64_t g_pw_tail_count = 0;
+static bool pw_tail_enabled() {
+    if (g_pw_tail < 0) g_pw_tail = !(getenv("MGCR_PW_TAIL") && atoi(getenv("MGCR_PW_TAIL")) == 0);
+    return g_pw_tail != 0;
+}
+bool set_pw_tail_enabled(bool on) {
+    const bool prev = pw_tail_enabled();
+    g_pw_tail = on ? 1 : 0;
+    return prev;
+}
+int64_t comm_pw_tail_count() { return g_pw_tail_count; }
+bool comm_pw_tail_begin(Comm *c, PwTail *t) {
+    if (!c || !c->pw_on || !pw_tail_enabled() || c->nranks < 2) return false;
+    if (!c->pw_ticket) {
+        if (hipMalloc((void **)&c->pw_ticket, sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); c->pw_ticket = nullptr; return false; }
+        if (hipMemsetAsync(c->pw_ticket, 0, sizeof(unsigned), ctx().stream) != hipSuccess) return false;
+    }
+    for (int r = 0; r < PW_MAX_RANKS; r++) t->mb[r] = c->pw_peer[r < c->nranks ? r : c->rank];
+    t->rank = c->rank;
+    t->nranks = c->nranks;
+    t->seq = pw_next_seq(c);
+    t->err = c->pw_err;
+    t->timeout = pw_timeout_run();
+    t->ticket = c->pw_ticket;
+    g_pw_tail_count++;
+    return true;
+}
+
 static void pw_release(Comm *c) {
     for (int r = 0; r < c->nranks && r < PW_MAX_RANKS; r++)
         if (r != c->rank && c->pw_peer[r]) hipIpcCloseMemHandle(c->pw_peer[r]);
@@ -258,6 +260,8 @@ static void pw_release(Comm *c) {
     c->pw_mbox = nullptr;
     if (c->pw_err) hipHostFree(c->pw_err);
     c->pw_err = nullptr;
+    if (c->pw_ticket) hipFree(c->pw_ticket);
+    c->pw_ticket = nullptr;
     c->pw_on = false;
 }
 

@@ -45,6 +45,7 @@
 #include "internal.h"
 #include "reduce.h"
 #include "gcr_dev.h"
+#include "pw_tail_dev.h"
 
 namespace mgcr {
 
@@ -513,16 +514,20 @@ __global__ void __launch_bounds__(RED_THREADS) finish_step_kernel(DevState *st, 
 //   p_k = D_k - sum_j beta_j p_j   =>   t_k = -sum_j beta_j t_j ,  T_km = -sum_{j>=m} beta_j T_jm ,  T_kk = 1.
 // (second launch bound: up to NDT = 5 the kernel fits 64 VGPRs, i.e. two 1024-thread workgroups per CU; left
 // alone the compiler takes 84 for NDT = 4 and halves the residency: 48.4 us against 42 us at 128^3)
-template <int NDT>
+// PW (multi-GPU, peer-write scalars): the last workgroup folds the <r,Ap'>, <Ap',Ap'> partials and sums them over the ranks (pw_tail_dev.h)
+template <int NDT, bool PW = false>
 __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
                                                                  int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
                                                                  int strideR, double *__restrict__ hist, int hist_cap,
                                                                  const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ r,
                                                                  const cplx *__restrict__ ar, cplx *ap_out, int64_t n,
-                                                                 double *__restrict__ partsA, LeanCoef *__restrict__ lc, int closing) {
+                                                                 double *__restrict__ partsA, LeanCoef *__restrict__ lc, int closing, PwTail pw) {
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT];
-    if (st->stop_at < st->base + it) return;
+    if (st->stop_at < st->base + it) {
+        if (PW) pw_tail(pw, (int)gridDim.x);   // a stopped solve: nothing to do, but the ranks' exchanges stay in lockstep (gcr_fused.hip step_apply_kernel)
+        return;
+    }
     double s[2 * NDT];
     fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
     if (blockIdx.x == 0) {
@@ -579,6 +584,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
     }
     const double mine = block_sum_owner<4>(v, lds);
     if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
+    if (PW) pw_tail(pw, (int)gridDim.x);
 }
 
 // LEAN, restart > 8: the x / P0 half of the cycle-closing step (the Ap half is build_lean_kernel with
@@ -638,17 +644,20 @@ __global__ void __launch_bounds__(RED_THREADS / 2) close_x_kernel(DevState *__re
 //   P0'   = dir - cp_0 P0 - sum_m cp_m D_m                   (= dir - sum_j beta_j p_j, src/GCR.h:257-266)
 //   Ap_0' = Ar - sum_j beta_j Ap_j                           with cp_m = sum_{j>=m} beta_j T_jm, cp_0 = sum_j beta_j t_j
 // written in place over slot 0, plus the <r,Ap'>, <Ap',Ap'> partials and the step's bookkeeping.
-template <int NDT, bool RDIR>
+template <int NDT, bool RDIR, bool PW = false>
 __global__ void __launch_bounds__(RED_THREADS, (NDT <= 2 ? 8 : 4)) build_close_kernel(DevState *__restrict__ st, int it, const double *__restrict__ partsB,
                                                                   int nblkB, int strideB, const double *__restrict__ partsR, int nblkR,
                                                                   int strideR, double *__restrict__ hist, int hist_cap,
                                                                   const cplx *__restrict__ den, DirPtrs d, const cplx *__restrict__ dir,
                                                                   const cplx *__restrict__ r, const cplx *__restrict__ ar, cplx *p_out,
                                                                   cplx *ap_out, int64_t n, double *__restrict__ partsA,
-                                                                  cplx *__restrict__ x, const LeanCoef *__restrict__ lc) {
+                                                                  cplx *__restrict__ x, const LeanCoef *__restrict__ lc, PwTail pw) {
     __shared__ double lds[2 * NDT * 17 > 4 * 17 ? 2 * NDT * 17 : 4 * 17];
     __shared__ cplx sbeta[NDT], scp[NDT];
-    if (st->stop_at < st->base + it) return;
+    if (st->stop_at < st->base + it) {
+        if (PW) pw_tail(pw, (int)gridDim.x);   // (see build_lean_kernel)
+        return;
+    }
     double s[2 * NDT];
     fold_partials<2 * NDT>(partsB, nblkB, strideB, s, lds);
     if (blockIdx.x == 0) {
@@ -712,6 +721,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 2 ? 8 : 4)) build_close_k
     }
     const double mine = block_sum_owner<4>(v, lds);
     if (threadIdx.x < 4) partsA[threadIdx.x * RED_MAX_BLOCKS + blockIdx.x] = mine;
+    if (PW) pw_tail(pw, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1002,12 +1012,29 @@ struct LeanArgs {
     double *partsA;
     cplx *x;
     LeanCoef *lc;
+    const PwTail *pw = nullptr;   // multi-GPU: the kernel's last workgroup folds partsA and sums it over the ranks (up to 8 directions)
 };
 
 static int launch_build_lean(const LeanArgs &a, int closing) {
 #define BL(NDT)                                                                                                               \
     KLAUNCH((build_lean_kernel<NDT>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk, a.R.stride, a.hist,      \
-            a.hist_cap, a.den, a.d, a.r, a.ar, a.ap_out, a.n, a.partsA, a.lc, closing)
+            a.hist_cap, a.den, a.d, a.r, a.ar, a.ap_out, a.n, a.partsA, a.lc, closing, PwTail{})
+#define BLP(NDT)                                                                                                              \
+    KLAUNCH((build_lean_kernel<NDT, true>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk, a.R.stride, a.hist, \
+            a.hist_cap, a.den, a.d, a.r, a.ar, a.ap_out, a.n, a.partsA, a.lc, closing, *a.pw)
+    if (a.pw) {
+        switch (a.nd) {
+            case 1: BLP(1); break;
+            case 2: BLP(2); break;
+            case 3: BLP(3); break;
+            case 4: BLP(4); break;
+            case 5: BLP(5); break;
+            case 6: BLP(6); break;
+            case 7: BLP(7); break;
+            default: BLP(8); break;
+        }
+        return MGCR_OK;
+    }
     switch (a.nd) {
         case 1: BL(1); break;
         case 2: BL(2); break;
@@ -1027,6 +1054,7 @@ static int launch_build_lean(const LeanArgs &a, int closing) {
         default: BL(16); break;
     }
 #undef BL
+#undef BLP
     return MGCR_OK;
 }
 
@@ -1054,14 +1082,22 @@ static int launch_close_x(const LeanArgs &a) {
 static int launch_build_close(const LeanArgs &a) {
 #define BC(NDT)                                                                                                               \
     do {                                                                                                                      \
-        if (a.rdir)                                                                                                           \
+        if (a.pw && a.rdir)                                                                                                   \
+            KLAUNCH((build_close_kernel<NDT, true, true>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk,     \
+                    a.R.stride, a.hist, a.hist_cap, a.den, a.d, a.dir, a.r, a.ar, a.p_out, a.ap_out, a.n, a.partsA, a.x,      \
+                    (const LeanCoef *)a.lc, *a.pw);                                                                           \
+        else if (a.pw)                                                                                                        \
+            KLAUNCH((build_close_kernel<NDT, false, true>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk,    \
+                    a.R.stride, a.hist, a.hist_cap, a.den, a.d, a.dir, a.r, a.ar, a.p_out, a.ap_out, a.n, a.partsA, a.x,      \
+                    (const LeanCoef *)a.lc, *a.pw);                                                                           \
+        else if (a.rdir)                                                                                                      \
             KLAUNCH((build_close_kernel<NDT, true>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk,           \
                     a.R.stride, a.hist, a.hist_cap, a.den, a.d, a.dir, a.r, a.ar, a.p_out, a.ap_out, a.n, a.partsA, a.x,      \
-                    (const LeanCoef *)a.lc);                                                                                  \
+                    (const LeanCoef *)a.lc, PwTail{});                                                                        \
         else                                                                                                                  \
             KLAUNCH((build_close_kernel<NDT, false>), a.g, a.st, a.it, a.B.p, a.B.nblk, a.B.stride, a.R.p, a.R.nblk,          \
                     a.R.stride, a.hist, a.hist_cap, a.den, a.d, a.dir, a.r, a.ar, a.p_out, a.ap_out, a.n, a.partsA, a.x,      \
-                    (const LeanCoef *)a.lc);                                                                                  \
+                    (const LeanCoef *)a.lc, PwTail{});                                                                        \
     } while (0)
     switch (a.nd) {
         case 1: BC(1); break;
@@ -1390,6 +1426,7 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
             cur = nxt;
             return MGCR_OK;
         }
+        bool tail_rb = false;   // the fold + exchange of |r|^2 and the beta numerators ran inside the apply kernel
         if (fuse_ok) {
             // Ar = A dir and the <Ar, Aps_j> partials of the first FND = 10 stored directions in one pass (gcr_fused.hip);
             // with more than that (restart > 10) multidot_kernel takes directions 8.. in its chunks of ND = 8 (8 and 9 twice:
@@ -1401,8 +1438,17 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
             if (xr_now)
                 MGCR_TRY(csr_step_apply_xr(b0->csr, xr_in, s->aps[cur], const_cast<cplx *>(dir), s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs,
                                            nf, s->partsB, s->partsR, s->st, it, refA.p, refA.nblk, refA.stride, s->den + cur, cur, s->lc, rmap));
-            else
-            MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist, rmap));
+            else {
+                // multi-GPU, scalars by peer writes: the apply kernel's last workgroup folds |r|^2 (the residual update's partials)
+                // and the beta numerators and sums them over the ranks — no fold + exchange launch behind it (pw_tail_dev.h)
+                PwTail pw;
+                if (multi && lim <= FND && csr_step_apply_has_pw_tail(b0->csr, b0->dist) && comm_pw_tail_begin(comm, &pw)) {
+                    pw.pa = s->partsR; pw.na = 1; pw.pb = s->partsB; pw.nb = 2 * lim; pw.out = s->dRB; pw.nblk = g;
+                    MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist, rmap, &pw));
+                    tail_rb = true;
+                } else
+                MGCR_TRY(csr_step_apply(b0->csr, dir, s->ar, s->A->kind == OP_DIRAC, s->A->k, vecs, nf, s->partsB, b0->dist, rmap));
+            }
             ch0 = lim <= FND ? nchunk : 1;
         } else {
             MGCR_TRY(op_apply_raw(s->A, dir, s->ar, n));  // src/GCR.h:242
@@ -1421,9 +1467,10 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
             MGCR_TRY(launch_multidot(g, nd, cst, it, (const cplx *)s->ar, d, ch * ND, n, s->partsB, rmap));
         }
         MGCR_TRY(mark());
+        bool tail_a = false;    // ... and that of <r,Ap'>, <Ap',Ap'> inside the build kernel
         RedRef refB = {s->partsB, g, RED_MAX_BLOCKS};
         if (multi) {  // one all-reduce for |r|^2 and all beta numerators of the step
-            MGCR_TRY(comm_fold_allreduce(comm, s->partsR, 1, s->partsB, 2 * lim, s->dRB, g));
+            if (!tail_rb) MGCR_TRY(comm_fold_allreduce(comm, s->partsR, 1, s->partsB, 2 * lim, s->dRB, g));
             refB = {s->dRB + 1, 1, 1};
         }
         if (lean) {
@@ -1433,6 +1480,12 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
             for (int j = 0; j < LND; j++) { int sl = j < lim ? j : 0; a.d.ps[j] = s->ps[sl]; a.d.aps[j] = s->aps[sl]; a.d.slot[j] = sl; }
             a.dir = dir; a.r = rcur; a.ar = s->ar; a.p_out = s->ps[0]; a.ap_out = s->aps[nxt]; a.n = n; a.partsA = s->partsA;
             a.x = x; a.lc = s->lc;
+            PwTail pwa;
+            if (multi && lim <= ND && comm_pw_tail_begin(comm, &pwa)) {   // the build kernel folds and exchanges <r,Ap'>, <Ap',Ap'> itself
+                pwa.pa = s->partsA; pwa.na = 4; pwa.pb = nullptr; pwa.nb = 0; pwa.out = s->dA; pwa.nblk = g;
+                a.pw = &pwa;
+                tail_a = true;
+            }
             if (ic_next != 0) {
                 MGCR_TRY(launch_build_lean(a, 0));              // lim == nxt
             } else if (lim <= ND) {
@@ -1458,7 +1511,7 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
             a.p_out = s->ps[nxt]; a.ap_out = s->aps[nxt]; a.n = n; a.partsA = s->partsA; a.x = x; a.alphas = s->alphas;
             MGCR_TRY(launch_build(a));
         }
-        if (multi) {
+        if (multi && !tail_a) {
             MGCR_TRY(comm_fold_allreduce(comm, s->partsA, 4, nullptr, 0, s->dA, g));
         }
         MGCR_TRY(mark());

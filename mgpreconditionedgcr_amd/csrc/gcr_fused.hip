@@ -25,6 +25,7 @@
 #include "reduce.h"
 #include "spmv_dev.h"
 #include "gcr_dev.h"
+#include "pw_tail_dev.h"
 
 namespace mgcr {
 
@@ -32,16 +33,24 @@ struct DotVecs {
     const cplx *v[FND];
 };
 
-template <int MODE, int WT, int NDT>
+// PW (row block of a distributed matrix whose scalars travel by peer writes): the launch's last workgroup also folds the partials
+// — |r|^2 of the residual update that ran before included — and sums them over the ranks (pw_tail_dev.h)
+template <int MODE, int WT, int NDT, bool PW = false>
 __global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <= 7) || MODE == 4) && NDT <= 5 ? 8 : 4)) step_apply_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                  DotVecs d, int64_t n, int nlogical, RowMap rm,
-                                                                 double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
+                                                                 double *__restrict__ parts, const int *__restrict__ skip, int skip_it, PwTail pw) {
     __shared__ double lds[2 * NDT * 17];
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
-    if (skip && skip[0] < skip[1] + skip_it) return;
+    if (!PW && skip && skip[0] < skip[1] + skip_it) return;
     // logical workgroup number: XCD x (physical b & 7) owns the band [x * per, (x + 1) * per)
     const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     if (lb >= nlogical) return;
+    if (PW && skip && skip[0] < skip[1] + skip_it) {
+        // a stopped solve's launches do nothing — but the ranks' exchanges stay in lockstep: every reduction that is launched is
+        // one exchange on every rank, whether it runs here or as a fold launch (which never skips), whatever it carries
+        pw_tail(pw, nlogical);
+        return;
+    }
     const int32_t W = WT ? WT : m.W;
     // rows of this logical workgroup's threads: RowMap (gcr_dev.h), the map multidot_kernel uses
     int64_t i, end, stride;
@@ -76,6 +85,7 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <
     }
     const double mine = block_sum_owner<2 * NDT>(v, lds);
     if (threadIdx.x < 2 * NDT) parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    if (PW) pw_tail(pw, nlogical);
 }
 
 
@@ -90,19 +100,23 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <
 // otherwise fetched about twice there —, 128^3 35.7 against 34.1: the window is used where rows reach at least 2^15 rows
 // (csr_step_apply).  EARLY (the direction streams requested together with the gathers, one memory round trip per
 // trip) spills at 64 VGPRs and loses: 42 us at 128^3; kept as a switch.
-template <int NS, bool RARE, int NDT>
+template <int NS, bool RARE, int NDT, bool PW = false>
 __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                                         DotVecs d, int64_t n, int nlogical, RowMap rm,
-                                                                                        double *__restrict__ parts, const int *__restrict__ skip, int skip_it) {
+                                                                                        double *__restrict__ parts, const int *__restrict__ skip, int skip_it, PwTail pw) {
     __shared__ double lds[2 * NDT * 17];
     extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
     constexpr unsigned NEAR = 0x3eu;
     constexpr int NC = STEN_COMMON;
     constexpr bool EARLY = false;
     static_assert(NS == 7 || (RARE && NS == 9), "7 common slots, optionally 2 rare ones behind them");
-    if (skip && skip[0] < skip[1] + skip_it) return;
+    if (!PW && skip && skip[0] < skip[1] + skip_it) return;
     const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     if (lb >= nlogical) return;
+    if (PW && skip && skip[0] < skip[1] + skip_it) {   // (see step_apply_kernel)
+        pw_tail(pw, nlogical);
+        return;
+    }
     int64_t i, end, stride;
     row_range(rm, lb, nlogical, n, &i, &end, &stride);
     const int32_t H = m.sten_halo_f;
@@ -179,6 +193,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
     }
     const double mine = block_sum_owner<2 * NDT>(v, lds);
     if (threadIdx.x < 2 * NDT) parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
+    if (PW) pw_tail(pw, nlogical);
 }
 
 
@@ -406,12 +421,12 @@ bool csr_fusable(const CsrDev &A, const DistCsr *dist) {
     return fuse_enabled() && A.L == 1 && A.n_tail_rows == 0 && A.nrow >= 1 && A.W >= 1;
 }
 
-template <int MODE, int WT>
+template <int MODE, int WT, bool PW = false>
 static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *x, cplx *y, const DotVecs &d, int64_t n,
-                      int g, double *parts, SkipRef sk, const RowMap &rm) {
+                      int g, double *parts, SkipRef sk, const RowMap &rm, const PwTail &pw = PwTail{}) {
 #define SK(NDT)                                                                                                          \
-    hipLaunchKernelGGL((step_apply_kernel<MODE, WT, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
-                       g, rm, parts, sk.p, sk.it)
+    hipLaunchKernelGGL((step_apply_kernel<MODE, WT, NDT, PW>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
+                       g, rm, parts, sk.p, sk.it, pw)
     switch (nd) {
         case 1: SK(1); break;
         case 2: SK(2); break;
@@ -427,18 +442,18 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
 #undef SK
 }
 
-template <int NS, bool RARE>
+template <int NS, bool RARE, bool PW = false>
 static void launch_tile_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *x, cplx *y, const DotVecs &d, int64_t n,
-                           int g, double *parts, SkipRef sk, const RowMap &rm) {
+                           int g, double *parts, SkipRef sk, const RowMap &rm, const PwTail &pw = PwTail{}) {
 #define SKT(NDT)                                                                                                              \
     do {                                                                                                                      \
         static bool big_lds = false;   /* up to 2 x 2048 x 16 B of window + the reduction scratch: above the 64 KiB default */ \
         if (!big_lds) {                                                                                                       \
-            hipFuncSetAttribute((const void *)step_apply_tile_kernel<NS, RARE, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            hipFuncSetAttribute((const void *)step_apply_tile_kernel<NS, RARE, NDT, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
             big_lds = true;                                                                                                   \
         }                                                                                                                     \
-        hipLaunchKernelGGL((step_apply_tile_kernel<NS, RARE, NDT>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
-                           g, rm, parts, sk.p, sk.it);                                                                        \
+        hipLaunchKernelGGL((step_apply_tile_kernel<NS, RARE, NDT, PW>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
+                           g, rm, parts, sk.p, sk.it, pw);                                                                    \
     } while (0)
     switch (nd) {
         case 1: SKT(1); break;
@@ -465,8 +480,17 @@ static bool fused_tile_enabled() {
 
 // y = A x (or x - k A x) + partials of <y, vecs_j>, j < nd <= FND, laid out like gcr.hip's partsB;
 // dist: A is this rank's row block, the halo exchange of x is enqueued first
+// pw != nullptr (the caller got it from comm_pw_tail_begin and filled in the slabs): the kernel's last workgroup folds and exchanges
+// — only where csr_step_apply_has_pw_tail(A, dist) says the instantiation exists
+bool csr_step_apply_has_pw_tail(const CsrDev &A, const DistCsr *dist) {
+    // every storage the fused kernels read (stencil view with or without rare slots, dictionary, slab).  Mixed decisions between ranks
+    // would still interoperate — a fold inside a kernel and a fold launch speak the same mailbox protocol, one sequence number per
+    // reduction either way — but there is no reason to have them
+    (void)A;
+    return dist != nullptr;
+}
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
-                   DistCsr *dist, const RowMap &rm) {
+                   DistCsr *dist, const RowMap &rm, const PwTail *pw) {
     MGCR_CHECK(x != y, MGCR_ERR_INVALID, "SpMV cannot run in place");
     MGCR_CHECK(nd >= 1 && nd <= FND, MGCR_ERR_INVALID, "csr_step_apply: 1..10 vectors");
     RowMat m = row_mat(A, shift, k);
@@ -486,7 +510,9 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
     const SkipRef sk = get_apply_skip();
 #define ST_W(MODE)                                                                              \
     do {                                                                                        \
-        if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm); \
+        if (pw && A.W == 7) launch_nd<MODE, 7, true>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm, *pw); \
+        else if (pw) launch_nd<MODE, 0, true>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);        \
+        else if (A.W == 7) launch_nd<MODE, 7>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm); \
         else launch_nd<MODE, 0>(nd, grid, lds_bytes, m, x, y, d, A.nrow, g, parts, sk, rm);          \
     } while (0)
 #define ST_S(MODE, NS) launch_nd<MODE, NS>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm)
@@ -494,10 +520,15 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         A.reach >= fused_tile_min_reach()) {
         // 3-D stencil: x staged in an LDS window per trip (step_apply_tile_kernel)
         const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
-        if (A.sten_rare) launch_tile_nd<9, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
+        if (A.sten_rare && pw) launch_tile_nd<9, true, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (A.sten_rare) launch_tile_nd<9, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
+        else if (pw) launch_tile_nd<7, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
         else launch_tile_nd<7, false>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
     } else if (csr_stencil_active(A)) {   // MODE 4: rare-tail layout (7 common + 2 rare slots)
-        if (A.sten_rare) ST_S(4, 9);
+        if (A.sten_rare && pw) launch_nd<4, 9, true>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (pw && sten_slots(A) == 7) launch_nd<3, 7, true>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (pw) launch_nd<3, 9, true>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (A.sten_rare) ST_S(4, 9);
         else if (sten_slots(A) == 7) ST_S(3, 7);
         else ST_S(3, 9);
     }

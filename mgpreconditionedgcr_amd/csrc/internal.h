@@ -206,8 +206,10 @@ int csr_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, DistC
 // SpMV fused with <y, v_j> partials (gcr_fused.hip); parts laid out like gcr.hip's partsB, red_grid(nrow) partials each
 bool csr_fusable(const CsrDev &A, const DistCsr *dist);
 struct RowMap;  // gcr_dev.h
+struct PwTail;  // pw_tail_dev.h
+bool csr_step_apply_has_pw_tail(const CsrDev &A, const DistCsr *dist);
 int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *const *vecs, int nd, double *parts,
-                   DistCsr *dist, const RowMap &rm);
+                   DistCsr *dist, const RowMap &rm, const PwTail *pw = nullptr);
 struct DevState;
 struct LeanCoef;
 bool csr_xr_fusable(const CsrDev &A, const DistCsr *dist);
@@ -238,6 +240,8 @@ SkipRef get_apply_skip();
 int dist_halo_begin(DistCsr *d, const cplx *x, bool overlap_interior = false);
 int64_t dist_halo_split_count();
 bool set_halo_split(bool on);
+bool set_pw_tail_enabled(bool on);     // comm.hip / pw_tail_dev.h: fold + cross-rank sum inside the producing kernel
+int64_t comm_pw_tail_count();
 int dist_halo_end(DistCsr *d);
 bool dist_halo_overlaps();  // MGCR_HALO_OVERLAP: exchange on the communication stream, overlapped with interior rows
 const cplx *dist_halo_ptr(DistCsr *d);  // halo segment of the exchange begun last (peer-write: alternates between two slots)

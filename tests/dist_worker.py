@@ -310,14 +310,24 @@ def main():
             mg.set_option("halo_split", prev)
             b = Field((r1 - r0,), problems.rhs_grid(N, 1)[r0:r1])
             xs = Field((r1 - r0,)).set_zero()
+            t0 = mg.stat("pw_tail_folds")
             gcr = GCR(A, GCR_Param(0, 4, 25, 1e-30, False, check_every=5))
             gcr.solve(b, xs)
+            n_tail = mg.stat("pw_tail_folds") - t0
+            # the same solve with every fold + exchange as a launch of its own
+            prev_t = mg.set_option("pw_tail", 0)
+            g0 = GCR(A, GCR_Param(0, 4, 25, 1e-30, False, check_every=5))
+            x0s = Field((r1 - r0,)).set_zero()
+            g0.solve(b, x0s)
+            mg.set_option("pw_tail", prev_t)
+            hist_notail, x_notail = g0.last_history.copy(), x0s.to_numpy()
             g2 = GCR(A, GCR_Param(11, 0, 25, 1e-30, False))
             xt = Field((r1 - r0,)).set_zero()
             g2.solve(b, xt)
             results[kind] = dict(y=y, r0=r0, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations,
                                  hist_trunc=g2.last_history, x_trunc=xt.to_numpy(), format=A.storage_format()[0],
-                                 allreduce=comm.allreduce_kind, halo=A.halo_kind, n_split=n_split, n_unsplit=n_unsplit, y_unsplit=y_unsplit)
+                                 allreduce=comm.allreduce_kind, halo=A.halo_kind, n_split=n_split, n_unsplit=n_unsplit, y_unsplit=y_unsplit,
+                                 n_tail=n_tail, hist_notail=hist_notail, x_notail=x_notail)
             if kind == "poisson":
                 import ctypes
                 us = ctypes.c_double()

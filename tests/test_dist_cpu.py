@@ -22,22 +22,43 @@ def free_port():
 
 
 def run_workers(mode, world, outdir, timeout=300):
+    """Starts `world` worker processes (tests/dist_worker.py) and collects what they saved.  The ranks meet in collectives: when one of
+    them fails, the others would wait for it until their own time limits — so the first non-zero exit ends the run at once, with THAT
+    rank's output in the assertion (a failing rank must show its cause, not a time-out of the ranks that waited for it)."""
+    import tempfile
+    import time
     port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    logs = [tempfile.TemporaryFile(mode="w+") for _ in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(r), str(world),
-                               str(port), str(outdir)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(port), str(outdir)], env=env, stdout=logs[r], stderr=subprocess.STDOUT)
              for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
+
+    def output(r):
+        logs[r].seek(0)
+        return logs[r].read()[-3000:]
+    t0 = time.time()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() - t0 > timeout:
+            failed = bad[0] if bad else -1
+            for q in procs:          # the exact processes started above
+                if q.poll() is None:
+                    q.kill()
             for q in procs:
-                q.kill()
-            raise
-        outs.append(o.decode(errors="replace"))
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+                q.wait()
+            break
+        time.sleep(0.05)
+    if failed is None:
+        bad = [r for r, p in enumerate(procs) if p.returncode != 0]
+        failed = bad[0] if bad else None
+    try:
+        assert failed is None, ("rank %d failed:\n%s" % (failed, output(failed))) if failed >= 0 else (
+            "no rank finished within %d s; rank 0 so far:\n%s" % (timeout, output(0)))
+    finally:
+        for f in logs:
+            f.close()
     return [np.load(os.path.join(str(outdir), "rank%d.npy" % r), allow_pickle=True).item() for r in range(world)]
 
 

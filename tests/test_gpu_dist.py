@@ -31,7 +31,7 @@ def test_distributed_gcr_with_transport_collectives(tmp_path, monkeypatch):
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_gcr_matches_single_process(tmp_path, world):
     mg.init()
-    res = run_workers("gcr", world, tmp_path, timeout=500)
+    res = run_workers("gcr", world, tmp_path, timeout=240)
     for kind in ("poisson", "random", "poisson48"):
         N, rowptr, col, val, gran = problem(kind)
         A = Sparse(N, N, rowptr, col, val)
@@ -56,6 +56,14 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
             assert res[r][kind]["n_split"] in (0, 1)
         if want_h == "peer-write" and kind == "poisson":
             assert sum(res[r][kind]["n_split"] for r in range(world)) >= 1
+        # peer-write scalars: the fold + cross-rank sum of a stencil row block's reductions runs in the last workgroup of the kernel that
+        # produces the partials (2 per iteration: apply + dots, build) — same history and x as with the separate fold launches
+        for r in range(world):
+            assert np.array_equal(res[r][kind]["hist"], res[r][kind]["hist_notail"]) and np.array_equal(res[r][kind]["x"], res[r][kind]["x_notail"])
+            if want == "peer-write":
+                assert res[r][kind]["n_tail"] >= (40 if kind == "poisson48" else 20), (kind, r, res[r][kind]["n_tail"])
+            else:
+                assert res[r][kind]["n_tail"] == 0
         if kind == "poisson":
             print("all-reduce of 11 doubles, %d ranks on one GPU, %s: %.1f us" % (world, want, res[0][kind]["allreduce_us"]))
         x = problems.rhs_grid(N, 5)
@@ -136,7 +144,7 @@ def test_peer_write_wait_times_out_cleanly(tmp_path, monkeypatch):
     """A rank that never joins an all-reduce: the waiting kernel gives up after its time limit (here 300 ms) and the
     call returns MGCR_ERR_COMM — no wave spins on the GPU without bound."""
     monkeypatch.setenv("MGCR_PEER_TIMEOUT_MS", "300")
-    res = run_workers("pw-timeout", 2, tmp_path, timeout=300)
+    res = run_workers("pw-timeout", 2, tmp_path, timeout=240)
     if res[0]["kind"] != "peer-write":
         pytest.skip("peer-write path not available here (%s)" % res[0]["kind"])
     assert res[0]["rc"] != 0 and "did not arrive" in res[0]["error"], res[0]
@@ -149,7 +157,7 @@ def test_peer_write_halo_timeout_is_reported_by_an_apply(tmp_path, monkeypatch):
     is enqueued, the download that hands y back returns MGCR_ERR_COMM, and the rows next to the missing halo are NaN —
     a stale or half-written receive slot can not yield plausible numbers."""
     monkeypatch.setenv("MGCR_PEER_TIMEOUT_MS", "300")
-    res = run_workers("pw-timeout-apply", 2, tmp_path, timeout=300)
+    res = run_workers("pw-timeout-apply", 2, tmp_path, timeout=240)
     if res[0]["kind"] != "peer-write":
         pytest.skip("peer-write halo path not available here (%s)" % res[0]["kind"])
     assert res[0]["rc_apply"] == 0                      # enqueueing succeeds ...
@@ -197,7 +205,7 @@ def test_distributed_mg_gcr_matches_single_process(tmp_path, world, mode):
     outer GCR — against the single-process MG-GCR of the same global problem."""
     from mgpreconditionedgcr_amd import MG, MG_Param, Mesh
     mg.init()
-    res = run_workers(mode, world, tmp_path, timeout=500)
+    res = run_workers(mode, world, tmp_path, timeout=240)
     n, planes = (8, 8) if mode == "mg" else (48, 16)
     ni = world * planes
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n, 0, ni, ni=ni)
@@ -232,7 +240,7 @@ def test_distributed_mg_on_unstructured_blocks(tmp_path, world):
     from mgpreconditionedgcr_amd import MG, MG_Param, Mesh
     from tests.dist_worker import unstructured_blocks
     mg.init()
-    res = run_workers("mg-unstructured", world, tmp_path, timeout=500)
+    res = run_workers("mg-unstructured", world, tmp_path, timeout=240)
     nb, bs, rowptr, col, val = unstructured_blocks()
     N = nb * bs
     from mgpreconditionedgcr_amd import DiracOp
@@ -267,7 +275,7 @@ def test_distributed_hierarchical_sparse(tmp_path, world):
     from mgpreconditionedgcr_amd import HierarchicalSparse, MG, MG_Param, Mesh
     from tests.dist_worker import unstructured_block_triplets
     mg.init()
-    res = run_workers("bcsr", world, tmp_path, timeout=500)
+    res = run_workers("bcsr", world, tmp_path, timeout=240)
     nb, bs, rows, cols, blocks = unstructured_block_triplets()
     N = nb * bs
     H = HierarchicalSparse(nb, nb, rows.astype(np.int32), cols.astype(np.int32), blocks)
