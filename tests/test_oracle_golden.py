@@ -230,3 +230,59 @@ def test_optimised_cpu_port_follows_the_oracle():
     _, ho = orc.opt_gcr_poisson(n, 5, 30, 2)
     _, sens, _ = orc.gcr_reorder_sensitivity(A, orc.gcr_param(restart=5, max_iter=30, tol=0.0), b)
     assert (np.abs(ho - h[:31]) <= np.maximum(1e-9 * h[:31], 8 * sens[:31]) + 1e-17).all()
+
+
+def test_device_order_model_against_a_python_restatement():
+    """oracle order 3 (the device's summation order, mgcr_oracle.c) against an independent numpy restatement of the same
+    model: per-thread sums over a thread's rows in ascending order, the wave64 tree (l, l+32), (l, l+16) ..., the 16 waves in
+    order onto 0, the workgroup partials by the same 1024-wide tree; several ranks: rank totals in rank order.  (That the MODEL is
+    the device is what tests/test_gpu_bitwise.py shows on the GPU; this keeps the C code honest without one.)"""
+    def tree1024(v):
+        v = np.concatenate([v, np.zeros(1024 - v.size)]).reshape(16, 64).copy()
+        off = 32
+        while off >= 1:
+            v[:, :off] = v[:, :off] + v[:, off:2 * off]
+            off //= 2
+        t = 0.0
+        for w in range(16):
+            t += v[w, 0]
+        return t
+
+    def dev_sum(term):
+        n = term.size
+        g = min(max((n + 1023) // 1024, 1), 512)
+        parts = np.zeros(g)
+        for b in range(g):
+            acc = np.zeros(1024)
+            for t in range(1024):
+                a = 0.0
+                for i in range(b * 1024 + t, n, g * 1024):
+                    a += term[i]
+                acc[t] = a
+            parts[b] = tree1024(acc)
+        return parts[0] + 0.0 if g == 1 else tree1024(parts)
+
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 64, 1000, 1025, 5000):
+        a = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n) + 1j * rng.standard_normal(n)
+        b = rng.standard_normal(n) + 1j * rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)
+        re = a.real * b.real + a.imag * b.imag
+        im = a.real * b.imag - a.imag * b.real
+        with orc.device_order():
+            d, s = orc.dot(a, b), orc.sqnorm(a)
+        assert d == complex(dev_sum(re), dev_sum(im)), n
+        assert s == dev_sum(a.real * a.real + a.imag * a.imag), n
+        # ... and it is a re-association of the reference's sum, nothing else
+        assert abs(d - orc.dot(a, b)) <= 1e-9 * np.abs(re).sum() + 1e-9 * np.abs(im).sum()
+    # three ranks: every rank sums its rows with its own grid, the totals are added in rank order
+    n, offs = 3000, np.array([0, 700, 1900, 3000])
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    t = a.real * a.real + a.imag * a.imag
+    with orc.device_order(rank_offsets=offs):
+        s = orc.sqnorm(a)
+    want = 0.0
+    for r in range(3):
+        want += dev_sum(t[offs[r]:offs[r + 1]])
+    assert s == want
+    # order 0 is restored on leaving the context
+    assert orc.sqnorm(a) == float(np.real(sum((np.conj(z) * z for z in a), 0j)))
