@@ -28,7 +28,7 @@ for r in rows:
     m = re.match(r"multidot_kernel<(\d+)", name)
     if m:
         b = (1 + int(m.group(1))) * V
-    m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)>", name)
+    m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)[,>]", name) or re.match(r"step_apply_tile_kernel<\d+, (?:true|false), (\d+)[,>]", name)
     if m:
         b = B_spmv + int(m.group(1)) * V            # SpMV + lim direction streams, Ar written once
     m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false), (true|false)>", name)
@@ -39,7 +39,7 @@ for r in rows:
             b = B_spmv - V + (3 * lim + 5) * V           # the step that closes a cycle: + lim p streams, x read and written, P0 written
         if m.group(2) == "true":
             b += 2 * V                                   # + the next step's residual update: r read, r' written
-    m = re.match(r"build_lean_kernel<(\d+)>", name)
+    m = re.match(r"build_lean_kernel<(\d+)[,>]", name)
     if m:
         b = (3 + int(m.group(1))) * V               # r, Ar, lim Aps read; Ap written
     m = re.match(r"build_close_kernel<(\d+)", name)
@@ -53,7 +53,7 @@ for r in rows:
         b = 3 * V
     if name.startswith("xr_update_kernel<false"):
         b = 6 * V
-    m = re.match(r"init_apply_kernel", name)
+    m = re.match(r"init_apply(_tile)?_kernel", name)
     if m:
         b = B_spmv                                   # SpMV of step 0 + its dot products (no extra streams when b is r0)
     if name.startswith(("ell_spmv_rowthread", "pat_spmv", "sten_spmv")):
