@@ -149,9 +149,11 @@ __global__ void gal_count_kernel(int64_t nagg, RowSrc src, int shift, const int3
     int64_t ap = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ap >= nagg) return;
     int32_t *mine = nbr + ap * maxnb;
-    int32_t nn = 0;
+    int32_t nn = 0, last = -1;
     bool over = false;
     auto add = [&](int32_t a) {
+        if (a == last) return;   // consecutive entries mostly fall into one aggregate (a block's columns, a stencil's neighbours): no search
+        last = a;
         int32_t lo = 0;
         while (lo < nn && mine[lo] < a) lo++;
         if (lo < nn && mine[lo] == a) return;
