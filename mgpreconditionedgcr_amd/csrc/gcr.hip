@@ -1615,7 +1615,9 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (nested) return gcr_run_once(s, rhs, x, true, hist, hist_cap, n_iter, converged);
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
     const int64_t n = s->A->dim;
-    const bool risky = one_launch_paths_enabled() && comm_live_count() == 0;   // (the paths' own conditions are narrower: a copy too many costs one pass)
+    // (the paths' own conditions are narrower — operator kind, storage, restart length — but none of them takes more than 2^21 rows:
+    // a copy too many costs one pass over x of a system that small)
+    const bool risky = one_launch_paths_enabled() && comm_live_count() == 0 && n <= ((int64_t)1 << 21);
     bool have_copy = false;
     if (risky && !x_known_zero) {
         if (s->xbak_n != n) {
