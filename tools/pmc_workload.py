@@ -17,7 +17,25 @@ from tools.pmc_traffic import load  # noqa: E402
 SPMV = ("ell_spmv_rowthread", "ell_spmv_window", "ell_spmv_lanes", "csr_tail_chunk_kernel", "csr_tail_kernel")
 
 
+def apply_bytes(kern):
+    """One apply = one dispatch of each kernel the WHOLE apply launches.  The workload also times the parts alone (spmv_part), which
+    shows up as further kernels: with a window kernel that multiplies the tail itself (template flag TAIL = true) the apply is
+    that kernel (+ the long-row tail kernel); otherwise slab kernel + chunked tail (+ long-row tail)."""
+    fused = [k for k in kern if k.startswith("ell_spmv_window") and k.rstrip(">").endswith("true")]
+    if fused:
+        names = fused + [k for k in kern if k.startswith("csr_tail_kernel")]
+    else:
+        names = [k for k in kern if not (k.startswith("ell_spmv_window") and k.rstrip(">").endswith("true"))]
+    return sum(kern[k]["hbm_bytes_per_dispatch"] for k in names)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--recompute":   # re-derive hbm_bytes_per_apply of every workload from its per-kernel entries
+        d = json.load(open(sys.argv[2]))
+        for w in (d.get("workloads") or {}).values():
+            w["hbm_bytes_per_apply"] = apply_bytes(w["kernels"])
+        json.dump(d, open(sys.argv[2], "w"), indent=1)
+        return
     name, dfetch, dwrite, out_json = sys.argv[1:5]
     fe, wr = load(dfetch, "FETCH_SIZE"), load(dwrite, "WRITE_SIZE")
     kern, total = {}, 0.0
@@ -29,6 +47,7 @@ def main():
         b = (2.0 * (sf / nf if nf else 0.0) + (sw / nw if nw else 0.0)) * 1024.0
         kern[k] = {"dispatches": max(nf, nw), "hbm_bytes_per_dispatch": b}
         total += b
+    total = apply_bytes(kern)
     rec = {"hbm_bytes_per_apply": total, "kernels": kern,
            "note": "PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc_workload.py): sum over the apply's kernels of (2 x FETCH + WRITE) x 1024 per dispatch"}
     if len(sys.argv) > 5:   # L2 request counters of the same command (one more pass)
