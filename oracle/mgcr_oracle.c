@@ -233,9 +233,13 @@ typedef struct orc_op {
     /* MG */
     orc_mg *mg;
     int owns;
+    /* order 3: this operator's own device layout (orc_op_set_layout; the levels of a multigrid hierarchy are stored differently) */
+    int has_layout, lay_w, lay_l, lay_cap;
 } orc_op;
 
 void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
+void orc_op_residual(orc_op *op, const cplx *x, const cplx *b, cplx *r);
+int64_t orc_op_nrow(const orc_op *op);
 
 /* src/Operator.h:330-346  y_row = sum_l VAL[l] * x[COL[l]], sequential per row.
  * Order 3 with a device layout set (orc_set_device_model: W, L): the row's first min(len, W) entries are summed the way
@@ -246,7 +250,8 @@ void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
  * the reference's order. */
 static void csr_row_device(const orc_op *op, int64_t row, const cplx *x, cplx *ell, cplx *tail, int *has_tail) {
     const int64_t b = op->rowptr[row], e = op->rowptr[row + 1];
-    const int W = g_dev_ell_w, L = g_dev_ell_l;
+    const int W = op->has_layout ? op->lay_w : g_dev_ell_w, L = op->has_layout ? op->lay_l : g_dev_ell_l;
+    const int tail_cap = op->has_layout ? op->lay_cap : g_dev_tail_cap;
     const int64_t ne = (e - b) < W ? (e - b) : W;
     double lr[16], li[16];
     for (int l = 0; l < L; l++) { lr[l] = 0.; li[l] = 0.; }
@@ -258,7 +263,7 @@ static void csr_row_device(const orc_op *op, int64_t row, const cplx *x, cplx *e
         for (int l = 0; l < off; l++) { lr[l] = lr[l] + lr[l + off]; li[l] = li[l] + li[l + off]; }
     *ell = lr[0] + li[0] * I;
     *has_tail = (e - b) > W;
-    if (*has_tail && (e - b) - W <= g_dev_tail_cap) { /* csr_tail_chunk_kernel: products in LDS, one thread adds them in CSR order */
+    if (*has_tail && (e - b) - W <= tail_cap) { /* csr_tail_chunk_kernel: products in LDS, one thread adds them in CSR order */
         cplx t = 0.0;
         for (int64_t j = b + W; j < e; j++) t = t + op->val[j] * x[op->col[j]];
         *tail = t;
@@ -273,9 +278,13 @@ static void csr_row_device(const orc_op *op, int64_t row, const cplx *x, cplx *e
         *tail = sr + si * I;
     }
 }
-static int csr_device_layout(void) { return g_sum_order == 3 && g_dev_ell_w >= 0 && g_dev_ell_l <= 16; }
+static int csr_device_layout_of(const orc_op *op) {
+    if (g_sum_order != 3) return 0;
+    if (op && op->has_layout) return op->lay_w >= 0 && op->lay_l <= 16;
+    return g_dev_ell_w >= 0 && g_dev_ell_l <= 16;
+}
 static void csr_apply(const orc_op *op, const cplx *x, cplx *y) {
-    if (csr_device_layout()) {
+    if (csr_device_layout_of(op)) {
         for (int64_t row = 0; row < op->nrow; row++) {
             cplx ell, tail = 0.0; int ht;
             csr_row_device(op, row, x, &ell, &tail, &ht);
@@ -292,7 +301,7 @@ static void csr_apply(const orc_op *op, const cplx *x, cplx *y) {
 
 /* src/Operator.h:569-575  f - (D f) * k */
 static void dirac_apply(const orc_op *op, const cplx *x, cplx *y) {
-    if (csr_device_layout() && op->D->kind == OP_CSR) { /* the shift sits in the SpMV epilogue of each of the two kernels */
+    if (op->D->kind == OP_CSR && csr_device_layout_of(op->D)) { /* the shift sits in the SpMV epilogue of each of the two kernels */
         for (int64_t row = 0; row < op->D->nrow; row++) {
             cplx ell, tail = 0.0; int ht;
             csr_row_device(op->D, row, x, &ell, &tail, &ht);
@@ -329,6 +338,27 @@ static void bcsr_apply(const orc_op *op, const cplx *x, cplx *y) {
         }
     }
     free(tmp);
+}
+
+/* r = b - op(x).  Order 3, Sparse with multi-lane rows / a CSR tail: the device forms it in the SpMV's epilogue
+ * (gcr.hip:op_residual_raw), i.e. (b - ell part) - tail part, not b - (ell part + tail part) */
+void orc_op_residual(orc_op *op, const cplx *x, const cplx *b, cplx *r) {
+    if (op->kind == OP_CSR && csr_device_layout_of(op) && g_dev_blocks != 1) {
+        for (int64_t row = 0; row < op->nrow; row++) {
+            cplx ell, tail = 0.0; int ht;
+            csr_row_device(op, row, x, &ell, &tail, &ht);
+            cplx v = b[row] - ell;
+            if (ht) v = v - tail;
+            r[row] = v;
+        }
+        return;
+    }
+    int64_t n = orc_op_nrow(op);
+    orc_op_apply(op, x, r);
+    for (int64_t i = 0; i < n; i++) r[i] = b[i] - r[i];
+}
+void orc_op_set_layout(orc_op *op, int ell_width, int ell_lanes, int tail_cap) {
+    op->has_layout = 1; op->lay_w = ell_width; op->lay_l = ell_lanes < 1 ? 1 : ell_lanes; op->lay_cap = tail_cap;
 }
 
 orc_op *orc_op_csr(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const cplx *val) {
@@ -422,19 +452,8 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
     cplx *r = vnew(n), *p = vnew(n), *Ap = vnew(n), *Ar = vnew(n), *t = vnew(n);
     cplx *z = NULL;
     /* r = rhs (src/GCR.h:189) — the reference ignores x0 here */
-    if (gp->use_x0 && csr_device_layout() && A->kind == OP_CSR && g_dev_blocks != 1) {
-        /* order 3, Sparse with multi-lane rows / a CSR tail: the device forms b - A x0 in the SpMV's epilogue
-         * (gcr.hip:op_residual_raw), i.e. (b - ell part) - tail part, not b - (ell part + tail part) */
-        for (int64_t row = 0; row < A->nrow; row++) {
-            cplx ell, tail = 0.0; int ht;
-            csr_row_device(A, row, x, &ell, &tail, &ht);
-            cplx v = rhs[row] - ell;
-            if (ht) v = v - tail;
-            r[row] = v;
-        }
-    } else if (gp->use_x0) {
-        orc_op_apply(A, x, t);
-        for (int64_t i = 0; i < n; i++) r[i] = rhs[i] - t[i];
+    if (gp->use_x0) {
+        orc_op_residual(A, x, rhs, r);
     } else {
         memcpy(r, rhs, sizeof(cplx) * (size_t)n);
     }

@@ -75,6 +75,7 @@ def lib():
         L.orc_set_sum_order.argtypes = [C.c_int]
         L.orc_set_device_model.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_device_ranks.argtypes = [C.c_int, _i64p]
+        L.orc_op_set_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_op_nrow.argtypes = [C.c_void_p]
         L.orc_op_nrow.restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
@@ -159,6 +160,11 @@ class Op:
     @property
     def dim(self):
         return lib().orc_op_dim(self.h)
+
+    def set_layout(self, ell_width, ell_lanes, tail_cap):
+        """This operator's own device layout for summation order 3 (the levels of a multigrid hierarchy are stored differently)."""
+        lib().orc_op_set_layout(self.h, int(ell_width), int(ell_lanes), int(tail_cap))
+        return self
 
     def __call__(self, x):
         if np.size(x) != self.dim:
