@@ -85,6 +85,27 @@ void orc_set_device_ranks(int nranks, const int64_t *row_offsets) {
     for (int r = 0; r <= g_dev_nranks && nranks >= 1; r++) g_dev_rank_off[r] = row_offsets ? row_offsets[r] : 0;
 }
 
+/* Lean restart cycles (csrc/gcr.hip header): in restart mode without the literal preconditioner hooks the device never forms the
+ * directions p_k inside a cycle.  It keeps the cycle's first direction P0 and the vectors D_1..D_k the later directions were
+ * started from (the residuals, or M r in flexible mode), the triangular table p_k = t_k P0 + sum_m T_km D_m, and the coefficients
+ * cx of the pending update x += sum_k alpha_k p_k, which is applied when a cycle closes (together with the next cycle's
+ * P0' = dir - sum_j beta_j p_j) or when the solve ends.  r, Ap and every scalar follow the classic recurrences — only x (and P0) are
+ * associated differently.  orc_set_device_lean(1, .) makes orc_gcr_solve form x that way (order 3 only), coefficient by coefficient
+ * in the kernels' order, so that x is comparable bit for bit as well.  recurrence_residual: the V-cycle restricts the residual
+ * the pre-smoother's recurrence ended with instead of b - A x (csrc/mg.hip). */
+static int g_dev_lean = 0, g_dev_recurrence_residual = 0;
+void orc_set_device_lean(int lean, int recurrence_residual) { g_dev_lean = lean; g_dev_recurrence_residual = recurrence_residual; }
+int orc_device_recurrence_residual(void) { return g_sum_order == 3 && g_dev_recurrence_residual; }
+static cplx *g_last_r = NULL;        /* the residual the last orc_gcr_solve ended with (malloc'ed; taken over by the caller) */
+cplx *orc_take_last_residual(void) { cplx *r = g_last_r; g_last_r = NULL; return r; }
+/* the device's complex multiply (reduce.h:cmul), spelled out: the coefficient arithmetic below must not depend on how the C
+ * compiler lowers `*` */
+static inline cplx cm(cplx a, cplx b) {
+    const double ax = creal(a), ay = cimag(a), bx = creal(b), by = cimag(b);
+    return (ax * bx - ay * by) + (ax * by + ay * bx) * I;
+}
+#define LEAN_MAX 16
+
 static int dev_grid(int64_t n) {
     if (g_dev_blocks > 0) return g_dev_blocks;
     int64_t g = (n + DEV_THREADS - 1) / DEV_THREADS;
@@ -477,6 +498,21 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
     memcpy(Aps[0], Ap, sizeof(cplx) * (size_t)n);
     memcpy(ps[0], p, sizeof(cplx) * (size_t)n);
 
+    /* order 3, lean restart cycles (see orc_set_device_lean) */
+    const int flex = gp->flexible && gp->right_precond;
+    int storage_dev = storage;   /* gcr.hip gcr_prepare: a restart cycle longer than the whole solve keeps max_iter + 1 slots */
+    if (gp->restart != 0 && gp->max_iter >= 1 && gp->max_iter + 1 < storage_dev) storage_dev = gp->max_iter + 1;
+    const int lean = g_sum_order == 3 && g_dev_lean && g_dev_blocks != 1 && gp->restart != 0 && storage_dev <= LEAN_MAX && !gp->left_precond &&
+                     (!gp->right_precond || flex);
+    cplx *LP[LEAN_MAX + 1];      /* LP[0] = P0, LP[m] = D_m */
+    cplx lT[LEAN_MAX][LEAN_MAX], lt[LEAN_MAX], lcx[LEAN_MAX], betas[LEAN_MAX];
+    int npend = 0;
+    for (int m = 0; m <= LEAN_MAX; m++) LP[m] = NULL;
+    if (lean) {
+        LP[0] = vnew(n);
+        memcpy(LP[0], p, sizeof(cplx) * (size_t)n);
+        for (int a = 0; a < LEAN_MAX; a++) { lt[a] = 0.0; lcx[a] = 0.0; for (int b2 = 0; b2 < LEAN_MAX; b2++) lT[a][b2] = 0.0; }
+    }
     /* order 3: step 0's sums come out of the kernel that embeds the apply when the device fuses the start */
     g_dev_banded_now = g_dev_init_banded;
     double bnorm2 = orc_sqnorm(n, rhs);
@@ -504,6 +540,15 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         den_cache[cur_slot] = den;
         cplx alpha = num / den;
         /* x = x + p*alpha ; r = r - Ap*alpha  (src/GCR.h:232-233) */
+        if (lean) {   /* gcr_dev.h lean_pending_update: x += alpha p_cur recorded in terms of P0 and D_1..D_cur */
+            const int sl = cur_slot;
+            if (sl == 0) { lcx[0] = alpha; for (int m = 1; m < LEAN_MAX; m++) lcx[m] = 0.0; }
+            else {
+                lcx[0] = lcx[0] + cm(alpha, lt[sl]);
+                for (int m = 1; m <= sl; m++) lcx[m] = lcx[m] + cm(alpha, lT[sl][m]);
+            }
+            npend = sl + 1;
+        } else
         for (int64_t i = 0; i < n; i++) x[i] = x[i] + alpha * p[i];
         for (int64_t i = 0; i < n; i++) r[i] = r[i] - alpha * Ap[i];
         const cplx *dir = r; /* the vector the new direction is built from */
@@ -529,11 +574,52 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
             if (g_sum_order == 3) bd = den_cache[i];
             else orc_dot(n, Aps[i], Aps[i], &bd);
             cplx beta = bn / bd;
+            if (lean) betas[i] = beta;
             for (int64_t j = 0; j < n; j++) p_corr[j] = p_corr[j] - beta * ps[i][j];
             for (int64_t j = 0; j < n; j++) Ap_corr[j] = Ap_corr[j] - beta * Aps[i][j];
         }
         for (int64_t i = 0; i < n; i++) p[i] = dir[i] + p_corr[i];   /* src/GCR.h:265 */
         for (int64_t i = 0; i < n; i++) Ap[i] = Ar[i] + Ap_corr[i];  /* src/GCR.h:266 */
+        if (lean && iter_count % restart == 0) {
+            /* the step that closes a cycle (gcr.hip build_close_kernel / close_x_kernel): cp_0 = sum_j beta_j t_j (t_0 = 1),
+             * cp_m = sum_{j >= m} beta_j T_jm (T_mm = 1); x += sum_j cx_j p_j; P0' = dir - sum_j cp_j p_j  (p_0 = P0, p_m = D_m) */
+            const int R = lim;
+            cplx cp[LEAN_MAX];
+            for (int m = 0; m < R; m++) {
+                cplx a = 0.0;
+                if (m == 0) for (int j = 0; j < R; j++) a = a + cm(betas[j], j == 0 ? (cplx)1.0 : lt[j]);
+                else for (int j = m; j < R; j++) a = a + cm(betas[j], j == m ? (cplx)1.0 : lT[j][m]);
+                cp[m] = a;
+            }
+            cplx *np0 = vnew(n);
+            for (int64_t i = 0; i < n; i++) {
+                cplx xv = x[i];
+                for (int j = 0; j < R; j++) xv = xv + cm(lcx[j], LP[j][i]);
+                x[i] = xv;
+                cplx pc = 0.0;
+                for (int j = 0; j < R; j++) pc = pc - cm(cp[j], LP[j][i]);
+                np0[i] = dir[i] + pc;
+            }
+            free(LP[0]);
+            LP[0] = np0;
+            npend = 0;
+        } else if (lean) {
+            /* inside a cycle (gcr.hip build_lean_kernel): row k = lim of the table, and D_k = what direction k was started from */
+            const int k = lim;
+            if (k < LEAN_MAX) {
+                cplx a = 0.0;
+                for (int j = 0; j < k; j++) a = a - cm(betas[j], j == 0 ? (cplx)1.0 : lt[j]);
+                lt[k] = a;
+                for (int m = 1; m < k; m++) {
+                    a = 0.0;
+                    for (int j = m; j < k; j++) a = a - cm(betas[j], j == m ? (cplx)1.0 : lT[j][m]);
+                    lT[k][m] = a;
+                }
+                lT[k][k] = 1.0;
+                if (!LP[k]) LP[k] = vnew(n);
+                memcpy(LP[k], dir, sizeof(cplx) * (size_t)n);
+            }
+        }
         rn2 = orc_sqnorm(n, r);
         if (hist && global_count < hist_cap) hist[global_count] = sqrt(rn2) / bnorm;
         if (gp->verbose) printf("Step %d residual norm = %.10e\n", global_count, sqrt(rn2) / bnorm);
@@ -547,6 +633,16 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         cur_slot = slot;
     } while ((rn2 / bnorm2) > gp->tol * gp->tol && global_count < gp->max_iter); /* src/GCR.h:288 */
 
+    if (lean && npend > 0)   /* the updates still pending when the solve ends (gcr.hip flush_x_kernel) */
+        for (int64_t i = 0; i < n; i++) {
+            cplx xv = x[i];
+            for (int j = 0; j < npend; j++) xv = xv + cm(lcx[j], LP[j][i]);
+            x[i] = xv;
+        }
+    for (int m = 0; m <= LEAN_MAX; m++) free(LP[m]);
+    free(g_last_r);
+    g_last_r = vnew(n);
+    memcpy(g_last_r, r, sizeof(cplx) * (size_t)n);
     if (converged) *converged = (global_count == gp->max_iter) ? 0 : 1;
     if (gp->verbose) {
         if (global_count == gp->max_iter)

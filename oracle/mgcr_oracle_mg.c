@@ -35,6 +35,8 @@ struct orc_op;
 typedef struct orc_op orc_op;
 void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
 void orc_op_residual(orc_op *op, const cplx *x, const cplx *b, cplx *r);
+int orc_device_recurrence_residual(void);
+cplx *orc_take_last_residual(void);
 orc_op *orc_op_csr(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const cplx *val);
 void orc_op_free(orc_op *op);
 int64_t orc_op_dim(const orc_op *op);
@@ -315,8 +317,13 @@ static void cycle(orc_mg *mg, int l, const cplx *b, cplx *x) {
     memset(x, 0, sizeof(cplx) * (size_t)n);
     p.use_x0 = 0;
     orc_gcr_solve(mg->A[l], &p, b, x, NULL, 0, NULL);
-    cplx *r = (cplx *)malloc(sizeof(cplx) * (size_t)n);
-    orc_op_residual(mg->A[l], x, b, r);   /* r = b - A x (order 0: apply, then subtract) */
+    cplx *r;
+    if (orc_device_recurrence_residual()) {
+        r = orc_take_last_residual();      /* order 3, device default: the residual the pre-smoother's recurrence ended with (csrc/mg.hip) */
+    } else {
+        r = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+        orc_op_residual(mg->A[l], x, b, r);   /* r = b - A x (order 0: apply, then subtract) */
+    }
     int64_t nc = mg->n[l + 1];
     cplx *bc = (cplx *)malloc(sizeof(cplx) * (size_t)nc), *xc = (cplx *)malloc(sizeof(cplx) * (size_t)nc);
     orc_mg_level_restrict(mg, l, r, bc);

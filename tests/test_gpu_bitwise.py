@@ -65,7 +65,8 @@ def device_model(A, N, took_small):
     band, per = orc.row_map(N, lay["reach"])
     lanes = lay["lanes"] > 1 or lay["tail_rows"] > 0
     return orc.device_order(blocks=0, band=band, per=per, init_banded=band > 0,
-                            ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"])
+                            ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"],
+                            lean=True)      # (restart mode: x from the lean cycles' coefficient tables, like the device)
 
 
 def solve_both(A, Ao, N, gp, po, b, x0=None, dims=None):
@@ -82,7 +83,7 @@ def solve_both(A, Ao, N, gp, po, b, x0=None, dims=None):
     return gcr, x, ref, took_small
 
 
-def assert_bitwise(tag, path, gcr, ref, golden=None):
+def assert_bitwise(tag, path, gcr, ref, golden=None, x=None):
     xo, ho, ito, co = ref
     h = gcr.last_history
     RECORD.setdefault(tag, {})[path] = {
@@ -93,6 +94,10 @@ def assert_bitwise(tag, path, gcr, ref, golden=None):
     assert gcr.last_iterations == ito, "%s: %d iterations, oracle in device order %d" % (tag, gcr.last_iterations, ito)
     assert np.array_equal(h, ho), "%s: first differing step %d" % (tag, int(np.argmax(h != ho)))
     assert gcr.last_converged == co
+    if x is not None:   # the SOLUTION too: the oracle forms x the way the path that ran does (lean cycles' tables / iteration order)
+        xg = x.to_numpy().ravel()
+        RECORD[tag][path]["x_max_abs_dev_vs_device_order"] = float(np.abs(xg - xo).max())
+        assert np.array_equal(xg, xo), "%s: x differs in %d of %d entries (max %.3e)" % (tag, int((xg != xo).sum()), xo.size, np.abs(xg - xo).max())
 
 
 @pytest.fixture(scope="module")
@@ -133,9 +138,7 @@ def test_sample_histories_bit_for_bit(sample, sample_gold, tag, k, kw, solver_pa
     # half (2): device order == the GPU
     gcr, x, ref, small = solve_both(DiracOp(D, k), Ao, 3072, GCR_Param(verb=False, **kw), po, b, dims=DIMS)
     assert small or solver_path == "multi-kernel" or tag == "g6_full" or kw.get("re", 0) > 8   # (the one-workgroup solver keeps <= 8 directions)
-    assert_bitwise(tag, solver_path if small else "multi-kernel", gcr, ref, gold)
-    if small:   # the one-workgroup solver also forms x in the reference's order
-        assert np.array_equal(x.to_numpy(), ref[0])
+    assert_bitwise(tag, solver_path if small else "multi-kernel", gcr, ref, gold, x)
 
 
 def test_sample_literal_preconditioner_hooks_bit_for_bit(sample, sample_gold):
@@ -154,7 +157,7 @@ def test_sample_literal_preconditioner_hooks_bit_for_bit(sample, sample_gold):
         gp = GCR_Param(0, 5, n_it, 1e-13, False, M if left else None, None if left else M)
         gcr, x, ref, small = solve_both(DiracOp(D, 0.15), Ao, 3072, gp, po, b, dims=DIMS)
         assert not small
-        assert_bitwise(tag, "multi-kernel", gcr, ref, gold)
+        assert_bitwise(tag, "multi-kernel", gcr, ref, gold, x)
 
 
 POISSON_CASES = [(32, dict(re=5, max_it=10, tau=1e-13), "p32"),
@@ -181,9 +184,7 @@ def test_poisson_histories_bit_for_bit(poisson_gold, n, kw, tag, solver_path):
         finally:
             mg.set_option("resident_solver", prev)
         path = "one-workgroup" if small else "resident" if took_resident else "multi-kernel"
-        assert_bitwise(tag, path, gcr, ref, gold)
-        if small:
-            assert np.array_equal(x.to_numpy(), ref[0])
+        assert_bitwise(tag, path, gcr, ref, gold, x)
 
 
 def test_poisson128_headline_bit_for_bit(poisson_gold):
@@ -207,7 +208,7 @@ def test_poisson128_headline_bit_for_bit(poisson_gold):
         finally:
             mg.set_option("step_build", prev)
         assert (launches > 0) == bool(step_build)
-        assert_bitwise("p128_20steps", "one-launch steps" if step_build else "three kernels", gcr, ref, poisson_gold["p128_hist"])
+        assert_bitwise("p128_20steps", "one-launch steps" if step_build else "three kernels", gcr, ref, poisson_gold["p128_hist"], x)
         assert np.array_equal(gcr.last_history[1:11], ref[1][1:11])
 
 
@@ -223,7 +224,7 @@ def test_poisson192_banded_row_map_bit_for_bit():
     assert orc.row_map(N, lay["reach"])[0] > 0
     Ao = orc.csr(N, ncol, rowptr, col, val)
     gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 6, 1e-13, False), orc.gcr_param(restart=5, max_iter=6, tol=1e-13), b, dims=(n, n, n))
-    assert_bitwise("p192_6steps", "multi-kernel (banded)", gcr, ref)
+    assert_bitwise("p192_6steps", "multi-kernel (banded)", gcr, ref, None, x)
 
 
 def _fuzz_system(rng):
@@ -285,8 +286,8 @@ def test_random_parameters_bit_for_bit(seed):
     assert np.array_equal(h[:m], ho[:m]), "%s: first differing step %d (%.17g against %.17g)" % (what, int(np.argmax(h[:m] != ho[:m])), h[int(np.argmax(h[:m] != ho[:m]))], ho[int(np.argmax(h[:m] != ho[:m]))])
     assert gcr.last_iterations == ref[2], what
     assert gcr.last_converged == ref[3], what
-    if small:
-        assert np.array_equal(x.to_numpy(), ref[0]), what
+    xg = x.to_numpy()
+    assert np.array_equal(xg, ref[0]), "%s: x differs in %d entries (max %.3e)" % (what, int((xg != ref[0]).sum()), np.abs(xg - ref[0]).max())
 
 
 def test_dot_and_norm_bit_for_bit(sample_gold):

@@ -460,15 +460,17 @@ def test_direct_coarsest_solve():
     assert g.last_converged and (b - D(x)).norm() / b.norm() <= 2e-10
 
 
+@pytest.mark.parametrize("config", ["default", "classic"])
 @pytest.mark.parametrize("n,levels", [(16, 1), (16, 2), (32, 2)])
-def test_vcycle_bit_for_bit_vs_oracle_in_device_order(n, levels, tmp_path):
+def test_vcycle_bit_for_bit_vs_oracle_in_device_order(n, levels, config, tmp_path):
     """The V-cycle has no reference output (MG::operator() returns uninitialised memory: parity unpinned), but what the HIP
-    cycle computes can be stated exactly: with the smoothers' x formed in iteration order (lean_cycles off) and the restricted
-    residual recomputed as b - A x (MGCR_MG_RECURRENCE_RESIDUAL=0) it is the oracle's corrected cycle BIT FOR BIT once the
-    oracle sums every level's dot products in the device's order and associates every level operator's rows as that level is
-    stored (tests/test_gpu_bitwise.py's model, per level).  The default configuration (lean cycles, recurrence residual) then
-    differs from it by rounding only: asserted at 1e-9 by test_mg_gcr_poisson_vs_oracle.  Child process: the switches are read
-    from the environment once."""
+    cycle computes can be stated exactly: it is the oracle's corrected cycle BIT FOR BIT once the oracle sums every level's dot
+    products in the device's order and associates every level operator's rows as that level is stored (tests/test_gpu_bitwise.py's
+    model, per level) — in the "classic" configuration (smoothers' x formed in iteration order: lean_cycles off; the restricted
+    residual recomputed as b - A x: MGCR_MG_RECURRENCE_RESIDUAL=0) with the oracle's plain loop, and in the DEFAULT configuration
+    with the oracle's model of the lean restart cycles (x from the coefficient tables) and of the recurrence residual.  (One-workgroup
+    solves off in both: every level then runs the multi-kernel / resident solvers the model describes.)  Child process: the switches
+    are read from the environment once."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -488,17 +490,26 @@ prm = MG_Param(Mesh((n, n, n)), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False
 M = MG(A, prm)
 b = problems.rhs_grid(N, 0)
 y = M(Field((n, n, n), b)).to_numpy()
+outer = GCR(A, GCR_Param(0, 5, 100, 1e-9, False, None, M, flexible=True))
+xs = Field((n, n, n)).set_zero()
+outer.solve(Field((n, n, n), b), xs)
 lay = []
 for l in range(levels + 1):
     d = M.level_operator(l).ell_layout() if l else A.ell_layout()
     lay.append([d["ell_width"], d["lanes"], d["tail_chunk_cap"], d["tail_rows"], M.level_info(l)["dim"]])
-np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), resident=mg.stat("resident_solves"), stepb=mg.stat("step_build_launches"))
+np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), resident=mg.stat("resident_solves"), stepb=mg.stat("step_build_launches"),
+         hist=outer.last_history, x=xs.to_numpy().ravel(), its=outer.last_iterations)
 """ % (root, n, levels, out)
-    env = dict(os.environ, MGCR_LEAN="0", MGCR_MG_RECURRENCE_RESIDUAL="0", MGCR_SMALL_SOLVE_ROWS="0")
+    env = dict(os.environ, MGCR_SMALL_SOLVE_ROWS="0")
+    if config == "classic":
+        env.update(MGCR_LEAN="0", MGCR_MG_RECURRENCE_RESIDUAL="0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     got = np.load(out)
-    assert got["small"] == 0 and got["resident"] == 0 and got["stepb"] == 0     # every nested solve ran the multi-kernel classic path
+    assert got["small"] == 0
+    if config == "classic":
+        assert got["resident"] == 0 and got["stepb"] == 0     # every nested solve ran the multi-kernel classic path
+    # (default: the coarsest solve runs as one launch where its operator's rows are stored one thread per row — 32^3, two levels)
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
     b = problems.rhs_grid(N, 0)
     Ao = orc.csr(N, ncol, rowptr, col, val)
@@ -508,6 +519,10 @@ np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), re
     for l in range(1, levels + 1):
         assert Mo.level_dim(l) == got["lay"][l][4]
         keep.append(Mo.level_op(l).set_layout(*got["lay"][l][:3]))
-    with orc.device_order():
+    with orc.device_order(lean=config == "default", recurrence_residual=config == "default"):
         yo = Mo(b)
+        # ... and the MG-preconditioned flexible GCR(5) on top of it (configs[2]'s solver): history, iteration count and x
+        xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=100, tol=1e-9, right=Mo, flexible=True), b)
     assert np.array_equal(got["y"], yo), "max rel dev %.3e" % (np.abs(got["y"] - yo).max() / np.abs(yo).max())
+    assert int(got["its"]) == ito and np.array_equal(got["hist"], ho), (int(got["its"]), ito)
+    assert np.array_equal(got["x"], xo), "x: max rel dev %.3e" % (np.abs(got["x"] - xo).max() / np.abs(xo).max())
