@@ -45,7 +45,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "irregular_spmv", "poisson128_gcr_general", "bcsr", "bcsr_mg", "sample", "latency64"]
 MG_PARITY_NOTE = ("unpinned: the reference's MG::operator() returns uninitialised memory (src/MG.h:124-129,405-430), so no reference "
-                  "output exists; the cycle is checked against the oracle's corrected cycle (tests/test_gpu_mg.py)")
+                  "output exists; the cycle is checked against the oracle's corrected cycle — bit for bit in the device's summation order, "
+                  "cycle and MG-preconditioned solve (tests/test_gpu_mg.py)")
 # transports a multi-GPU run falls back through (environment of the worker processes)
 LADDER = [("default: peer-write kernels where their self-test passes, RCCL otherwise", {}),
           ("RCCL only", {"MGCR_PEER_ALLREDUCE": "0", "MGCR_PEER_HALO": "0"}),

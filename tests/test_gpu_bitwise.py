@@ -6,7 +6,8 @@ The argument has two halves, and both are asserted here with np.array_equal:
   (1) oracle, summation order 0 (index order)  ==  the real reference        (golden vectors, tests/golden/*.npz —
       outputs of the reference's own classes compiled here, oracle/ref_harness.cpp);
   (2) oracle, summation order 3 (device order) ==  the GPU                   (every entry of the residual history,
-      the iteration count, the convergence flag; the solution x where the device forms it in the reference's order).
+      the iteration count, the convergence flag, AND the solution x — in restart mode with the oracle's model of the lean
+      cycles' coefficient tables, which associate the same linear combination differently).
 
 Order 3 (oracle/mgcr_oracle.c, "order 3") changes NOTHING in the oracle but the association of the sums: the terms
 conj(a_i) b_i are the same doubles, added per thread in ascending row order, then by the wave64 tree of csrc/reduce.h,
