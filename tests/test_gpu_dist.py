@@ -80,12 +80,13 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
         if kind != "random" and (want == "peer-write" or world == 2):
             from tests.dist_worker import split_rows
             offs = np.array(split_rows(N // gran, world), np.int64) * gran
-            with orc.device_order(rank_offsets=offs):
+            with orc.device_order(rank_offsets=offs, lean=True):
                 assert np.array_equal(got, Ao(x)), kind
                 for tag, okw in (("", dict(restart=4, max_iter=25, tol=1e-30)), ("_trunc", dict(truncation=11, max_iter=25, tol=1e-30))):
-                    _, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(**okw), problems.rhs_grid(N, 1))
+                    xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(**okw), problems.rhs_grid(N, 1))
                     for r in range(world):
                         assert np.array_equal(res[r][kind]["hist" + tag], ho), (kind, tag, r)
+                    assert np.array_equal(np.concatenate([res[r][kind]["x" + tag] for r in range(world)]), xo), (kind, tag)   # the solution too
         for tag, prm, okw in (("", GCR_Param(0, 4, 25, 1e-30, False), dict(restart=4, max_iter=25, tol=1e-30)),
                               ("_trunc", GCR_Param(11, 0, 25, 1e-30, False), dict(truncation=11, max_iter=25, tol=1e-30))):
             # how far the reference algorithm itself moves under re-association of its dot products
