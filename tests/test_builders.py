@@ -194,4 +194,16 @@ def test_legacy_dense_gcr_matches_reference(legacy_gold, tmp_path):
             assert np.abs(x - xr).max() <= 1e-7 * max(np.abs(xr).max(), np.abs(g["x0"]).max() * 1e-3), (tag, who)
         if tag == "zero":
             assert np.array_equal(x_py, g["x0"]) and np.array_equal(x_cpp, g["x0"])     # untouched
+        elif tag != "rhs0":
+            # ... and BIT FOR BIT what the oracle computes when it sums in the device's order (tests/test_gpu_bitwise.py): the dense
+            # operator as one block, truncated GCR with use_x0, tolerance sqrt(tol) / |rhs| with |rhs|^2 summed like mgcr_norm2 does
+            from oracle import oracle as orc  # checker only
+            Ao = orc.bcsr_from_triplets(1, 1, n, np.array([0], np.int32), np.array([0], np.int32), g["A"].reshape(1, n, n))
+            with orc.device_order():
+                bn2 = orc.sqnorm(g["rhs"])
+                xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(truncation=trunc, max_iter=max_iter, tol=float(np.sqrt(tol) / np.sqrt(bn2)), use_x0=True),
+                                               g["rhs"], g["x0"])
+            assert ito == norms.size and np.array_equal(norms, ho[1:] * np.sqrt(bn2)), tag
+            assert np.array_equal(x_py, xo), tag
+            assert printed[tag] == [float("%.10e" % v) for v in ho[1:] * np.sqrt(bn2)], tag     # the C++ mirror prints those doubles
     assert re.search(r"GCR did not converge after 40 steps! Residual norm = ", p.stdout)

@@ -50,6 +50,19 @@ def test_config1_history_through_the_cpp_interface(sample_matrix_path, sample_go
         assert abs(hist[k] - ref[k]) <= ((1e-9 if ref[k] >= 1e-9 else 1e-6) + 5e-11) * ref[k], (k, hist[k], ref[k])
     m = re.search(r"true relative residual of \(x - x0\): (\S+)", out)
     assert m and float(m.group(1)) < 1e-12  # x_final = x0 + A^-1 b
+    # ... and EXACTLY the lines the oracle prints when it sums its dot products in the device's order (tests/test_gpu_bitwise.py):
+    # the C++ mirror drives the same kernels, so its `Step %d residual norm = %.10e` lines are those doubles, digit for digit
+    import mgpreconditionedgcr_amd as mg
+    from mgpreconditionedgcr_amd import read_data
+    mg.init()
+    lay = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path)).ell_layout()
+    with orc.device_order(ell_width=lay["ell_width"], ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"], lean=True):
+        _, ho, ito, _ = orc.gcr_solve(orc.dirac(orc.csr(nrow, ncol, rowptr, col, val), 0.15), orc.gcr_param(restart=5, max_iter=4000, tol=1e-13),
+                                      sample_gold["gcr_rhs"])
+    printed = re.findall(r"^Step \d+ residual norm = \S+$", out, re.M)
+    assert printed == ["Step %d residual norm = %.10e" % (k, ho[k]) for k in range(ho.size)], "first differing line: %s" % next(
+        (a, "Step %d residual norm = %.10e" % (k, ho[k])) for k, a in enumerate(printed) if a != "Step %d residual norm = %.10e" % (k, ho[k]))
+    assert "GCR converged after %d steps." % ito in out
 
 
 @pytest.mark.gpu
