@@ -1615,9 +1615,11 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     if (nested) return gcr_run_once(s, rhs, x, true, hist, hist_cap, n_iter, converged);
     MGCR_CHECK(s->A, MGCR_ERR_INVALID, "GCR has no operator (call initialise / mgcr_gcr_set_operator first)");
     const int64_t n = s->A->dim;
-    // (the paths' own conditions are narrower — operator kind, storage, restart length — but none of them takes more than 2^21 rows:
-    // a copy too many costs one pass over x of a system that small)
-    const bool risky = one_launch_paths_enabled() && comm_live_count() == 0 && n <= ((int64_t)1 << 21);
+    // Which solves can meet a one-launch path at all?  The solve itself up to 2^21 rows (the paths' own conditions are narrower —
+    // operator kind, storage, restart length — but none of them takes more); at any size when a preconditioner is attached, whose
+    // nested solves (an MG cycle's coarsest level) may take one.  A copy too many costs one pass over x.
+    const bool risky = one_launch_paths_enabled() && comm_live_count() == 0 &&
+                       (n <= ((int64_t)1 << 21) || s->p.left_precond || s->p.right_precond);
     bool have_copy = false;
     if (risky && !x_known_zero) {
         if (s->xbak_n != n) {
@@ -1631,7 +1633,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
     }
     int rc = gcr_run_once(s, rhs, x, false, hist, hist_cap, n_iter, converged);
     if (rc != MGCR_INT_GAVE_UP) return rc;
-    if (!risky) {   // (cannot happen: nothing that waits on other workgroups ran) — report like a host synchronisation point would
+    if (!have_copy && !x_known_zero) {   // (cannot happen: nothing that waits on other workgroups ran) — report like a host synchronisation point would
         set_error("one-launch solver kernel gave up and no copy of x was kept");
         return MGCR_ERR_HIP;
     }

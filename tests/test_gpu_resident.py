@@ -349,3 +349,45 @@ def test_cross_xcd_coherence_of_sc1_accesses():
     assert bad.value > 0
     # the solvers' paths are untouched by the self-test
     assert mg.lib().mgcr_synchronize() == 0
+
+
+def test_nested_resident_solve_that_gives_up_is_repaired_by_the_outer_solve():
+    """The coarsest solve of a V-cycle runs as one launch; when THAT launch gives up (a workgroup told to leave), the cycle's output
+    is NaN and so is the outer solve — which the library then repeats on the multi-kernel paths: the caller's first call returns a
+    converged, finite solution (here x was zeroed: no copy needed), the same as a process that never took the one-launch paths."""
+    import subprocess
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import mgpreconditionedgcr_amd as mg
+from mgpreconditionedgcr_amd import *
+n = 32
+N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+A = Sparse(N, ncol, rowptr, col, val)
+prm = MG_Param(Mesh((n, n, n)), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)), 1, None, None,
+               null_vectors=np.ones((1, N), np.complex128))
+M = MG(A, prm)
+b = Field((n, n, n)).fill_rhs(0)
+x = Field((n, n, n)).set_zero()
+outer = GCR(A, GCR_Param(0, 5, 100, 1e-9, False, None, M, flexible=True))
+outer.solve(b, x)
+r = b - A(x)
+print("fallbacks", mg.stat("one_launch_fallbacks"), "resident", mg.stat("resident_solves"), "its", outer.last_iterations, "converged", outer.last_converged,
+      "finite", bool(np.isfinite(x.to_numpy()).all()), "true_res_ok", bool(r.norm() / b.norm() <= 2e-9))
+np.save(sys.argv[1], np.concatenate([outer.last_history, x.to_numpy().ravel().view(np.float64)]))
+'''
+    import os
+    import tempfile
+    d = tempfile.mkdtemp()
+    outs = {}
+    for tag, env_add in (("stalled", dict(MGCR_TEST_RESIDENT_STALL="3", MGCR_TEST_RESIDENT_SPIN_LIMIT="20000")), ("never", dict(MGCR_RESIDENT="0"))):
+        env = dict(os.environ, MGCR_SMALL_SOLVE_ROWS="0", **env_add)
+        f = os.path.join(d, tag + ".npy")
+        out = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=200,
+                             cwd=os.path.join(os.path.dirname(__file__), ".."))
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs[tag] = (out.stdout, np.load(f))
+    assert "fallbacks 1 " in outs["stalled"][0] and "converged True finite True true_res_ok True" in outs["stalled"][0], outs["stalled"][0]
+    assert "fallbacks 0 resident 0 " in outs["never"][0], outs["never"][0]
+    assert np.array_equal(outs["stalled"][1], outs["never"][1])     # history and x: the bits of the multi-kernel paths
