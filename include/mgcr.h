@@ -116,6 +116,10 @@ int mgcr_op_storage_format(mgcr_op_t op, int32_t *format, int32_t *n_patterns);
  * summation order. */
 int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t *tail_rows, int64_t *reach, int32_t *tail_chunk_cap,
                        int32_t *x_window);
+/* Where a lean restarted GCR on this operator forms r' = r - alpha A p: *kind = 0 in a launch of its own (xr_update_kernel), 1 inside
+ * the kernel that embeds the apply, latency regime (same sums, same bits), 2 inside the windowed apply of the bandwidth regime
+ * (csrc/gcr_fused_xr_tile.h: |r'|^2 is then summed over that kernel's banded row map — tests/test_gpu_bitwise.py tells the oracle). */
+int mgcr_op_xr_fuse_kind(mgcr_op_t op, int32_t *kind);
 /* Sparse::dagger / mod_*_at (src/Operator.h:296-328,84-86) change a Sparse IN PLACE while a DiracOp, GCR or MG may hold a
  * pointer to it (src/Operator.h:117): this replaces the matrix behind an existing handle, so that every operator that
  * borrowed the handle (mgcr_dirac_create, mgcr_gcr_create) applies the new matrix.  On failure the old matrix stays.

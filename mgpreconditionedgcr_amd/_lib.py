@@ -81,6 +81,7 @@ _SIGS = {
     "mgcr_op_apply": (C.c_int, [_vp, _vp, _vp]),
     "mgcr_op_stored_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "mgcr_op_storage_format": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mgcr_op_xr_fuse_kind": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "mgcr_op_ell_layout": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mgcr_csr_replace": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "mgcr_selftest_coherence": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),

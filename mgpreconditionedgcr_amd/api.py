@@ -192,6 +192,12 @@ class Operator:
         check(_lib.lib().mgcr_op_ell_layout(self.h, C.byref(w), C.byref(l), C.byref(t), C.byref(r), C.byref(cap), C.byref(win)))
         return dict(ell_width=w.value, lanes=l.value, tail_rows=t.value, reach=r.value, tail_chunk_cap=cap.value, x_window=win.value)
 
+    def xr_fuse_kind(self):
+        """0 / 1 / 2: where a lean GCR on this operator runs its residual update (include/mgcr.h mgcr_op_xr_fuse_kind)."""
+        k = C.c_int32()
+        check(_lib.lib().mgcr_op_xr_fuse_kind(self.h, C.byref(k)))
+        return k.value
+
     def storage_format(self):
         """(format, n_patterns): 0 ELL slab, 1 row-pattern dictionary (columns + values), 2 (columns only)."""
         f, n = C.c_int32(), C.c_int32()

@@ -162,6 +162,14 @@ int mgcr_op_ell_layout(mgcr_op_t op, int32_t *ell_width, int32_t *lanes, int64_t
     return MGCR_OK;
 }
 
+int mgcr_op_xr_fuse_kind(mgcr_op_t op, int32_t *kind) {
+    MGCR_CHECK(op && kind, MGCR_ERR_INVALID, "mgcr_op_xr_fuse_kind: null argument");
+    const Op *o = op->kind == OP_DIRAC ? op->base : op;
+    MGCR_CHECK(o->kind == OP_CSR, MGCR_ERR_UNSUPPORTED, "mgcr_op_xr_fuse_kind: not a Sparse");
+    *kind = csr_fusable(o->csr, o->dist) ? csr_xr_fuse_kind(o->csr, o->dist) : 0;
+    return MGCR_OK;
+}
+
 int mgcr_op_halo_kind(mgcr_op_t op, int32_t *kind) {
     MGCR_CHECK(op && kind, MGCR_ERR_INVALID, "mgcr_op_halo_kind: null argument");
     const Op *o = op->kind == OP_DIRAC ? op->base : op;

@@ -100,7 +100,12 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 1 || (MODE == 3 && WT <
 // otherwise fetched about twice there —, 128^3 35.7 against 34.1: the window is used where rows reach at least 2^15 rows
 // (csr_step_apply).  EARLY (the direction streams requested together with the gathers, one memory round trip per
 // trip) spills at 64 VGPRs and loses: 42 us at 128^3; kept as a switch.
-template <int NS, bool RARE, int NDT, bool PW = false>
+// CARRY (banded row map whose step IS the reach of the two far slots — a 256 x 256 x Z grid with 64 workgroups per band: the thread
+// that owns row i owned row i - n^2 one trip earlier and will own row i + n^2 one trip later): the far gathers disappear — the entry
+// requested for the NEXT trip is this trip's + n^2 neighbour, this trip's own entry is the next trip's - n^2 neighbour.  Each trip
+// then requests ONE entry per row (+ the halo) and every plane of x passes through the XCD's L2 once instead of three times.
+// Same values in the same places: same bits.
+template <int NS, bool RARE, int NDT, bool PW = false, bool CARRY = false>
 __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                                         DotVecs d, int64_t n, int nlogical, RowMap rm,
                                                                                         double *__restrict__ parts, const int *__restrict__ skip, int skip_it, PwTail pw) {
@@ -128,6 +133,11 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
 #pragma unroll
     for (int j = 0; j < 2 * NDT; j++) v[j] = 0.;
     int buf = 0;
+    cplx c_prev = make_double2(0., 0.), c_cur = c_prev;
+    if (CARRY) {
+        c_prev = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
+        c_cur = gather_x(x, m.xh, m.n_own, clampj(i));
+    }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {   // uniform trip count per workgroup
         const bool live = i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
@@ -135,9 +145,9 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         uint64_t pl[NS];
 #pragma unroll
         for (int c = 0; c < NS; c++) pl[c] = pp[c];
-        const cplx own = gather_x(x, m.xh, m.n_own, clampj(i));
-        const cplx far0 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
-        const cplx far6 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[6]));
+        const cplx far6 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[6]));   // CARRY: the next trip's own entry
+        const cplx own = CARRY ? c_cur : gather_x(x, m.xh, m.n_own, clampj(i));
+        const cplx far0 = CARRY ? c_prev : gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
         cplx halo = make_double2(0., 0.);
         int hidx = -1;
         if ((int)threadIdx.x < 2 * H) {
@@ -160,7 +170,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         for (int c = 0; c < NC; c++) {
             const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? far0 : far6);
             const bool on = (pl[c] >> lane & 1ull) != 0ull;
-            const cplx nsum = cadd(sum, sten_term<-1>(m, c, xv));
+            const cplx nsum = cadd(sum, sten_term<(CARRY ? 1 : -1)>(m, c, xv));
             sum.x = on ? nsum.x : sum.x;
             sum.y = on ? nsum.y : sum.y;
         }
@@ -170,7 +180,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
                 if (pl[c] != 0ull) {   // wave-uniform: a wave of a boundary plane
                     const cplx xr = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[c]));
                     const bool on = (pl[c] >> lane & 1ull) != 0ull;
-                    const cplx nsum = cadd(sum, sten_term<-1>(m, c, xr));
+                    const cplx nsum = cadd(sum, sten_term<(CARRY ? 1 : -1)>(m, c, xr));
                     sum.x = on ? nsum.x : sum.x;
                     sum.y = on ? nsum.y : sum.y;
                 }
@@ -190,6 +200,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
                 v[2 * j + 1] += t.y;
             }
         }
+        if (CARRY) { c_prev = own; c_cur = far6; }
     }
     const double mine = block_sum_owner<2 * NDT>(v, lds);
     if (threadIdx.x < 2 * NDT) parts[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
@@ -262,6 +273,8 @@ __global__ void __launch_bounds__(RED_THREADS, 4) step_apply_xr_kernel(RowMat m,
     if (threadIdx.x == 2 * NDT) partsR[lb] = mine;
 }
 
+#include "gcr_fused_xr_tile.h"
+
 // Step 0 of a solve whose first direction is its start residual (lean smoothers, gcr.hip alias_p0): Ap_0 = A r_0
 // AND the partial sums of <r_0,Ap_0>, <Ap_0,Ap_0>, |r_0|^2 — and |b|^2 when b is not r_0 — in ONE pass, instead
 // of the operator apply followed by init3_partials_kernel (+ norm_partials_kernel): r_0 is the row's own x entry
@@ -315,7 +328,7 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 3 && WT <= 7) || MODE =
 
 
 // init_apply_kernel with the LDS window of step_apply_tile_kernel (same conditions, same bits)
-template <int NS, bool RARE>
+template <int NS, bool RARE, bool CARRY = false>
 __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
                                                                          const cplx *__restrict__ b, int64_t n, int nlogical, RowMap rm,
                                                                          double *__restrict__ partsA, double *__restrict__ partsR,
@@ -337,6 +350,11 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
     const int lane = (int)(threadIdx.x & 63);
     double v[6] = {0., 0., 0., 0., 0., 0.};
     int buf = 0;
+    cplx c_prev = make_double2(0., 0.), c_cur = c_prev;
+    if (CARRY) {   // (step_apply_tile_kernel)
+        c_prev = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
+        c_cur = gather_x(x, m.xh, m.n_own, clampj(i));
+    }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
         const bool live = i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
@@ -344,9 +362,9 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
         uint64_t pl[NS];
 #pragma unroll
         for (int c = 0; c < NS; c++) pl[c] = pp[c];
-        const cplx own = gather_x(x, m.xh, m.n_own, clampj(i));
-        const cplx far0 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
-        const cplx far6 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[6]));
+        const cplx far6 = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[6]));   // CARRY: the next trip's own entry
+        const cplx own = CARRY ? c_cur : gather_x(x, m.xh, m.n_own, clampj(i));
+        const cplx far0 = CARRY ? c_prev : gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
         cplx halo = make_double2(0., 0.);
         int hidx = -1;
         if ((int)threadIdx.x < 2 * H) {
@@ -364,7 +382,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
         for (int c = 0; c < NC; c++) {
             const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? far0 : far6);
             const bool on = (pl[c] >> lane & 1ull) != 0ull;
-            const cplx nsum = cadd(sum, sten_term<-1>(m, c, xv));
+            const cplx nsum = cadd(sum, sten_term<(CARRY ? 1 : -1)>(m, c, xv));
             sum.x = on ? nsum.x : sum.x;
             sum.y = on ? nsum.y : sum.y;
         }
@@ -374,7 +392,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
                 if (pl[c] != 0ull) {
                     const cplx xr = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[c]));
                     const bool on = (pl[c] >> lane & 1ull) != 0ull;
-                    const cplx nsum = cadd(sum, sten_term<-1>(m, c, xr));
+                    const cplx nsum = cadd(sum, sten_term<(CARRY ? 1 : -1)>(m, c, xr));
                     sum.x = on ? nsum.x : sum.x;
                     sum.y = on ? nsum.y : sum.y;
                 }
@@ -393,6 +411,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
                 v[5] += bv.x * bv.x + bv.y * bv.y;
             }
         }
+        if (CARRY) { c_prev = own; c_cur = far6; }
     }
     const double mine = block_sum_owner<6>(v, lds);
     if (threadIdx.x < 4) partsA[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
@@ -442,17 +461,17 @@ static void launch_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, 
 #undef SK
 }
 
-template <int NS, bool RARE, bool PW = false>
+template <int NS, bool RARE, bool PW = false, bool CARRY = false>
 static void launch_tile_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *x, cplx *y, const DotVecs &d, int64_t n,
                            int g, double *parts, SkipRef sk, const RowMap &rm, const PwTail &pw = PwTail{}) {
 #define SKT(NDT)                                                                                                              \
     do {                                                                                                                      \
         static bool big_lds = false;   /* up to 2 x 2048 x 16 B of window + the reduction scratch: above the 64 KiB default */ \
         if (!big_lds) {                                                                                                       \
-            hipFuncSetAttribute((const void *)step_apply_tile_kernel<NS, RARE, NDT, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            hipFuncSetAttribute((const void *)step_apply_tile_kernel<NS, RARE, NDT, PW, CARRY>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
             big_lds = true;                                                                                                   \
         }                                                                                                                     \
-        hipLaunchKernelGGL((step_apply_tile_kernel<NS, RARE, NDT, PW>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
+        hipLaunchKernelGGL((step_apply_tile_kernel<NS, RARE, NDT, PW, CARRY>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, x, y, d, n, \
                            g, rm, parts, sk.p, sk.it, pw);                                                                    \
     } while (0)
     switch (nd) {
@@ -472,6 +491,15 @@ static void launch_tile_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat
 static int64_t fused_tile_min_reach() {
     static const int64_t r = getenv("MGCR_FUSED_TILE_REACH") ? atoll(getenv("MGCR_FUSED_TILE_REACH")) : (int64_t)1 << 15;
     return r;
+}
+// the far slots of the 7-slot view are exactly one step of the banded row map away (step_apply_tile_kernel: CARRY)
+// (the CARRY instantiations are also the ones compiled for real stencil coefficients — no per-slot real / complex decision, 14 scalar
+// registers less: what lets them keep 64 vector registers without spills)
+static bool tile_carry(const CsrDev &A, const RowMap &rm) {
+    static const bool on = !(getenv("MGCR_TILE_CARRY") && atoi(getenv("MGCR_TILE_CARRY")) == 0);
+    const int64_t step = (int64_t)rm.per * RED_THREADS;
+    return on && rm.band != 0 && A.sten_off[6] == step && A.sten_off[0] == -step && !A.sten_rare && sten_slots(A) == 7 &&
+           row_mat(A, false, cplx{0., 0.}).realv;
 }
 static bool fused_tile_enabled() {
     static const bool on = !(getenv("MGCR_FUSED_TILE") && atoi(getenv("MGCR_FUSED_TILE")) == 0);
@@ -523,6 +551,7 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         if (A.sten_rare && pw) launch_tile_nd<9, true, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
         else if (A.sten_rare) launch_tile_nd<9, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
         else if (pw) launch_tile_nd<7, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (!dist && tile_carry(A, rm)) launch_tile_nd<7, false, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
         else launch_tile_nd<7, false>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
     } else if (csr_stencil_active(A)) {   // MODE 4: rare-tail layout (7 common + 2 rare slots)
         if (A.sten_rare && pw) launch_nd<4, 9, true>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
@@ -564,8 +593,55 @@ static void launch_xr_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &
 #undef SX
 }
 
+static bool tile_regime(const CsrDev &A) {   // where csr_step_apply / csr_init_apply stage x in the LDS window
+    return csr_stencil_active(A) && A.sten_near_f == 0x3eu && A.sten_halo_f > 0 && (A.sten_rare || sten_slots(A) == 7) && fused_tile_enabled() &&
+           A.reach >= fused_tile_min_reach();
+}
+static bool xr_tile_enabled() {
+    static const bool on = !(getenv("MGCR_XR_FUSE_TILE") && atoi(getenv("MGCR_XR_FUSE_TILE")) == 0);
+    return on;
+}
+template <int NS, bool RARE>
+static void launch_xr_tile_nd(int nd, unsigned grid, size_t lds_bytes, const RowMat &m, const cplx *r_in, const cplx *ap, cplx *r_out, cplx *y,
+                              const DotVecs &d, int64_t n, int g, const RowMap &rm, double *parts, double *partsR, DevState *st,
+                              int it, const double *partsA, int nblkA, int strideA, cplx *den_slot, int slot, LeanCoef *lc) {
+#define SXT(NDT)                                                                                                                       \
+    do {                                                                                                                               \
+        static bool big_lds = false;                                                                                                   \
+        if (!big_lds) {                                                                                                                \
+            hipFuncSetAttribute((const void *)step_apply_xr_tile_kernel<NS, RARE, NDT, (NDT <= 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            big_lds = true;                                                                                                            \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((step_apply_xr_tile_kernel<NS, RARE, NDT, (NDT <= 4)>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r_in, ap, r_out, \
+                           y, d, n, g, rm, parts, partsR, st, it, partsA, nblkA, strideA, den_slot, slot, lc);                \
+    } while (0)
+    switch (nd) {
+        case 1: SXT(1); break;
+        case 2: SXT(2); break;
+        case 3: SXT(3); break;
+        case 4: SXT(4); break;
+        case 5: SXT(5); break;
+        case 6: SXT(6); break;
+        case 7: SXT(7); break;
+        case 8: SXT(8); break;
+        case 9: SXT(9); break;
+        default: SXT(10); break;
+    }
+#undef SXT
+}
+
+// 0: the residual update keeps its own launch; 1: latency regime (step_apply_xr_kernel); 2: windowed bandwidth regime
+// (step_apply_xr_tile_kernel: |r|^2 is then summed over the apply's row map)
+int csr_xr_fuse_kind(const CsrDev &A, const DistCsr *dist) {
+    if (!csr_xr_fusable(A, dist)) return 0;
+    return tile_regime(A) ? 2 : 1;
+}
 bool csr_xr_fusable(const CsrDev &A, const DistCsr *dist) {
     static const int64_t limit = getenv("MGCR_XR_FUSE_ROWS") ? atoll(getenv("MGCR_XR_FUSE_ROWS")) : ((int64_t)1 << 19);
+    if (!dist && tile_regime(A) && xr_tile_enabled() && csr_fusable(A, dist)) {
+        // the windowed form: real stencil coefficients, and the far slots one step of the banded row map away (gcr_fused_xr_tile.h)
+        return tile_carry(A, make_row_map(A.nrow, red_grid(A.nrow), A.reach));
+    }
     // the gathers double, so short rows only: 64^3 7-point, 19 iterations of GCR(10): 0.633 -> 0.608 ms; the 4x4 sample matrix
     // (39 entries per row) loses 1.6 % and stays with the separate update kernel
     return !dist && A.nrow <= limit && A.W <= 8 && csr_fusable(A, dist);
@@ -593,7 +669,12 @@ int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r
     } while (0)
 #define SXS(MODE, NS) launch_xr_nd<MODE, NS>(nd, grid, 0, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA, \
                                              den_slot, slot, lc)
-    if (csr_stencil_active(A)) {
+    if (tile_regime(A)) {
+        const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
+        MGCR_CHECK(tile_carry(A, rm) && d.v[nd - 1] == ap, MGCR_ERR_INVALID, "csr_step_apply_xr: not the windowed form's case");
+        launch_xr_tile_nd<7, false>(nd, grid, win, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,
+                                         den_slot, slot, lc);
+    } else if (csr_stencil_active(A)) {
         if (A.sten_rare) SXS(4, 9);
         else if (sten_slots(A) == 7) SXS(3, 7);
         else SXS(3, 9);
@@ -629,17 +710,19 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
     if (csr_stencil_active(A) && A.sten_near_f == 0x3eu && A.sten_halo_f > 0 && (A.sten_rare || sten_slots(A) == 7) && fused_tile_enabled() &&
         A.reach >= fused_tile_min_reach()) {
         const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
-#define IAT(NS, RARE)                                                                                                               \
+#define IAT(NS, RARE, CARRY)                                                                                                        \
     do {                                                                                                                            \
         static bool big_lds = false;                                                                                                \
         if (!big_lds) {                                                                                                             \
-            hipFuncSetAttribute((const void *)init_apply_tile_kernel<NS, RARE>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            hipFuncSetAttribute((const void *)init_apply_tile_kernel<NS, RARE, CARRY>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
             big_lds = true;                                                                                                         \
         }                                                                                                                           \
-        hipLaunchKernelGGL((init_apply_tile_kernel<NS, RARE>), dim3(grid), dim3(RED_THREADS), win, ctx().stream, m, r0, aps0, b, A.nrow, g, rm, \
+        hipLaunchKernelGGL((init_apply_tile_kernel<NS, RARE, CARRY>), dim3(grid), dim3(RED_THREADS), win, ctx().stream, m, r0, aps0, b, A.nrow, g, rm, \
                            partsA, partsR, partsN, sk.p, sk.it);                                                                    \
     } while (0)
-        if (A.sten_rare) IAT(9, true); else IAT(7, false);
+        if (A.sten_rare) IAT(9, true, false);
+        else if (!dist && tile_carry(A, rm)) IAT(7, false, true);
+        else IAT(7, false, false);
 #undef IAT
     } else if (csr_stencil_active(A)) {
 #define IAS(MODE, NS) hipLaunchKernelGGL((init_apply_kernel<MODE, NS>), dim3(grid), dim3(RED_THREADS), 0, ctx().stream, m, r0, aps0, b, A.nrow, g, \

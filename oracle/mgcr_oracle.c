@@ -95,6 +95,11 @@ void orc_set_device_ranks(int nranks, const int64_t *row_offsets) {
  * the pre-smoother's recurrence ended with instead of b - A x (csrc/mg.hip). */
 static int g_dev_lean = 0, g_dev_recurrence_residual = 0;
 void orc_set_device_lean(int lean, int recurrence_residual) { g_dev_lean = lean; g_dev_recurrence_residual = recurrence_residual; }
+/* Where the device forms r' = r - alpha Ap INSIDE the kernel that embeds the apply (csrc/gcr_fused_xr_tile.h: lean cycles on a 3-D
+ * stencil whose far neighbours are one step of the banded row map away, e.g. a 256 x 256 x Z grid), |r'|^2 is summed over THAT kernel's
+ * row map — every step but the solve's last (max_iter reached: nothing is applied after it, the plain update kernel runs). */
+static int g_dev_xr_banded = 0;
+void orc_set_device_xr_banded(int on) { g_dev_xr_banded = on; }
 int orc_device_recurrence_residual(void) { return g_sum_order == 3 && g_dev_recurrence_residual; }
 static cplx *g_last_r = NULL;        /* the residual the last orc_gcr_solve ended with (malloc'ed; taken over by the caller) */
 cplx *orc_take_last_residual(void) { cplx *r = g_last_r; g_last_r = NULL; return r; }
@@ -620,7 +625,9 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
                 memcpy(LP[k], dir, sizeof(cplx) * (size_t)n);
             }
         }
+        g_dev_banded_now = lean && g_dev_xr_banded && !flex && global_count < gp->max_iter;
         rn2 = orc_sqnorm(n, r);
+        g_dev_banded_now = 0;
         if (hist && global_count < hist_cap) hist[global_count] = sqrt(rn2) / bnorm;
         if (gp->verbose) printf("Step %d residual norm = %.10e\n", global_count, sqrt(rn2) / bnorm);
         if (iter_count % restart == 0) { /* src/GCR.h:277-283: wipe (slots are never read again before being rewritten) */

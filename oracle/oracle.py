@@ -77,6 +77,7 @@ def lib():
         L.orc_set_device_ranks.argtypes = [C.c_int, _i64p]
         L.orc_op_set_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_set_device_lean.argtypes = [C.c_int, C.c_int]
+        L.orc_set_device_xr_banded.argtypes = [C.c_int]
         L.orc_op_nrow.argtypes = [C.c_void_p]
         L.orc_op_nrow.restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
@@ -259,26 +260,31 @@ class device_order:
     (gcr_dev.h:make_row_map), needed from about 182^3 rows on (`row_map(n, reach)` below computes them)."""
 
     def __init__(self, blocks=0, band=0, per=0, init_banded=False, ell_width=-1, ell_lanes=1, tail_cap=0, rank_offsets=None, lean=False,
-                 recurrence_residual=False):
+                 recurrence_residual=False, xr_banded=False):
         """rank_offsets: first row of every rank's block (+ the total) of a distributed solve — the ranks sum their rows
         separately and add the totals in rank order.  lean: x is formed the way the device's lean restart cycles form it (restart
         mode <= 16 slots without the literal preconditioner hooks), so that x is comparable bit for bit too; recurrence_residual:
-        the oracle's V-cycle restricts the residual the pre-smoother's recurrence ended with, like the device's default."""
+        the oracle's V-cycle restricts the residual the pre-smoother's recurrence ended with, like the device's default.
+        xr_banded: the residual update runs inside the windowed apply kernel (csrc/gcr_fused_xr_tile.h; `xr_banded_for` below says
+        when), so |r|^2 of every step but a solve's last is summed over the banded map."""
         self.args = (int(blocks), int(band), int(per), int(bool(init_banded)), int(ell_width), int(ell_lanes), int(tail_cap))
         self.ranks = None if rank_offsets is None else np.ascontiguousarray(rank_offsets, np.int64)
         self.lean = (int(bool(lean)), int(bool(recurrence_residual)))
+        self.xr_banded = int(bool(xr_banded))
 
     def __enter__(self):
         lib().orc_set_device_model(*self.args)
         if self.ranks is not None:
             lib().orc_set_device_ranks(self.ranks.size - 1, self.ranks)
         lib().orc_set_device_lean(*self.lean)
+        lib().orc_set_device_xr_banded(self.xr_banded)
         lib().orc_set_sum_order(3)
         return self
 
     def __exit__(self, *exc):
         lib().orc_set_sum_order(0)
         lib().orc_set_device_lean(0, 0)
+        lib().orc_set_device_xr_banded(0)
         lib().orc_set_device_model(0, 0, 0, 0, -1, 1, 0)
         lib().orc_set_device_ranks(1, np.zeros(2, np.int64))
         return False

@@ -67,7 +67,8 @@ def device_model(A, N, took_small):
     lanes = lay["lanes"] > 1 or lay["tail_rows"] > 0
     return orc.device_order(blocks=0, band=band, per=per, init_banded=band > 0,
                             ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"],
-                            lean=True)      # (restart mode: x from the lean cycles' coefficient tables, like the device)
+                            lean=True,      # (restart mode: x from the lean cycles' coefficient tables, like the device)
+                            xr_banded=band > 0 and A.xr_fuse_kind() == 2)   # residual update inside the windowed apply kernel
 
 
 def solve_both(A, Ao, N, gp, po, b, x0=None, dims=None):
@@ -226,6 +227,27 @@ def test_poisson192_banded_row_map_bit_for_bit():
     Ao = orc.csr(N, ncol, rowptr, col, val)
     gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 6, 1e-13, False), orc.gcr_param(restart=5, max_iter=6, tol=1e-13), b, dims=(n, n, n))
     assert_bitwise("p192_6steps", "multi-kernel (banded)", gcr, ref, None, x)
+
+
+@pytest.mark.parametrize("restart,steps", [(5, 7), (10, 12), (3, 3)])
+def test_poisson_256x256_slab_carried_window_bit_for_bit(restart, steps):
+    """16 planes of a 256 x 256 grid (1 M rows): the far neighbours of a row are exactly one step of the banded row map away, so the
+    windowed kernels carry them in registers from trip to trip and the residual update runs inside the apply kernel
+    (gcr_fused.hip CARRY, gcr_fused_xr_tile.h) — the kernels of BASELINE configs[2] (256^3) at a size the oracle finishes in seconds.
+    |r|^2 of every step but the last is then summed over the banded map: the oracle's model follows (xr_banded).  The same solve with
+    the separate update kernel (MGCR_XR_FUSE_TILE=0 in a child process would be needed: tools/xr_tile_check.py) differs in those sums only."""
+    n, nz = 256, 16
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+    b = problems.rhs_grid(N, 0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    lay = A.ell_layout()
+    band, per = orc.row_map(N, lay["reach"])
+    assert band > 0 and per * 1024 == n * n and A.xr_fuse_kind() == 2
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, restart, steps, 1e-13, False), orc.gcr_param(restart=restart, max_iter=steps, tol=1e-13), b,
+                                    dims=(nz, n, n))
+    assert not small
+    assert_bitwise("p256x256x16_restart%d_%dsteps" % (restart, steps), "multi-kernel (banded, carried window)", gcr, ref, None, x)
 
 
 def _fuzz_system(rng):
