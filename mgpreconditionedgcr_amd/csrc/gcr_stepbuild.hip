@@ -79,7 +79,9 @@ __device__ __forceinline__ void sb_close_step(DevState *st, int it, double rr, d
     if (clear_pending) st->npend = 0;
 }
 
-template <int MODE, int WT, int NDT, bool XR, bool CLOSE>
+// REALC: the instantiation for real stencil coefficients (no per-slot real / complex decision, 14 scalar registers less — the
+// kernels' scalar registers spill into vector-register lanes, which a wave then reads back one v_readlane at a time)
+template <int MODE, int WT, int NDT, bool XR, bool CLOSE, bool REALC = false>
 __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArgs a) {
     __shared__ double lds[(2 * NDT > 4 ? 2 * NDT : 4) * 17];
     __shared__ double lds_pw[2 * SB_MAX_ND * 17], lds_ws[2 * SB_MAX_ND * RES_GRP];
@@ -112,7 +114,9 @@ __global__ void __launch_bounds__(RED_THREADS, 8) step_build_kernel(StepBuildArg
         int trip = 0;
         for (int64_t i = i0; i < end; i += stride, trip++) {
             const PatLds pl{nullptr, nullptr, nullptr};
-            const cplx sum = fused_row_product<MODE, WT>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return a.x[j]; });
+            cplx sum;
+            if constexpr (REALC) sum = sten_row_product_t<WT, false, 1>(a.m, i, [&](int32_t j) -> cplx { return a.x[j]; });
+            else sum = fused_row_product<MODE, WT>(a.m, i, 0, pl, [&](int32_t j) -> cplx { return a.x[j]; });
             const cplx yi = a.m.shift ? csub(a.x[i], cmul(a.m.k, sum)) : sum;
             arL[trip * RED_THREADS + (int)threadIdx.x] = yi;
             __builtin_amdgcn_sched_barrier(0);
@@ -293,9 +297,14 @@ static int64_t g_stepbuild_launches = 0;
 int64_t stepbuild_launch_count() { return g_stepbuild_launches; }
 
 // the instantiation a step with `nd` stored directions launches
-static const void *sb_kernel(int nd, bool xr, bool close) {
-#define SBK(NDT) (close ? (xr ? (const void *)step_build_kernel<3, 7, NDT, true, true> : (const void *)step_build_kernel<3, 7, NDT, false, true>) \
-                        : (xr ? (const void *)step_build_kernel<3, 7, NDT, true, false> : (const void *)step_build_kernel<3, 7, NDT, false, false>))
+static bool sb_real_enabled() {
+    static const bool on = !(getenv("MGCR_SB_REAL") && atoi(getenv("MGCR_SB_REAL")) == 0);
+    return on;
+}
+static const void *sb_kernel(int nd, bool xr, bool close, bool realc) {
+#define SBR(NDT, R) (close ? (xr ? (const void *)step_build_kernel<3, 7, NDT, true, true, R> : (const void *)step_build_kernel<3, 7, NDT, false, true, R>) \
+                           : (xr ? (const void *)step_build_kernel<3, 7, NDT, true, false, R> : (const void *)step_build_kernel<3, 7, NDT, false, false, R>))
+#define SBK(NDT) (realc ? SBR(NDT, true) : SBR(NDT, false))
     switch (nd) {
         case 1: return SBK(1);
         case 2: return SBK(2);
@@ -304,6 +313,7 @@ static const void *sb_kernel(int nd, bool xr, bool close) {
         default: return SBK(5);
     }
 #undef SBK
+#undef SBR
 }
 // Do `grid` workgroups of this instantiation, with this much dynamic LDS, fit the chip AT ONCE?  The workgroups wait for each
 // other inside the launch, so the answer has to come from the runtime (registers and LDS of the code object that was actually
@@ -344,9 +354,10 @@ bool csr_step_build_eligible(const CsrDev &A, const DistCsr *dist, int lim) {
     if (g > RES_BLK) return false;
     // every form the step may be launched in (with / without the next residual update, closing or not) must be co-resident
     const size_t lds = sb_lds_bytes(A, g);
+    const bool realc = sb_real_enabled() && row_mat(A, false, cplx{0., 0.}).realv;
     for (int xr = 0; xr < 2; xr++)
         for (int cl = 0; cl < 2; cl++)
-            if (!launch_is_coresident(sb_kernel(lim, xr != 0, cl != 0), RED_THREADS, lds, g)) return false;
+            if (!launch_is_coresident(sb_kernel(lim, xr != 0, cl != 0, realc), RED_THREADS, lds, g)) return false;
     return true;
 }
 
@@ -376,7 +387,7 @@ int csr_step_build(const CsrDev &A, const cplx *x, bool shift, cplx k, const cpl
     a.spin_limit = getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT") ? atoi(getenv("MGCR_TEST_RESIDENT_SPIN_LIMIT")) : RES_SPIN_LIMIT;
     const unsigned grid = (unsigned)g;
     const size_t lds_bytes = sb_lds_bytes(A, g);
-    const void *kernel = sb_kernel(nd, xr_out != nullptr, close_ps != nullptr);
+    const void *kernel = sb_kernel(nd, xr_out != nullptr, close_ps != nullptr, sb_real_enabled() && a.m.realv);
     MGCR_CHECK(launch_is_coresident(kernel, RED_THREADS, lds_bytes, g), MGCR_ERR_INVALID, "csr_step_build: launch would not be co-resident");
     void *kargs[1] = {(void *)&a};
     MGCR_HIP(hipLaunchKernel(kernel, dim3(grid), dim3(RED_THREADS), kargs, lds_bytes, ctx().stream));
