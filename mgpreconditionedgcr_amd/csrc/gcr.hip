@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) build_lean_ke
 #pragma unroll
         for (int j = 0; j < NDT; j++) ac = csub(ac, cmul(beta[j], aj[j]));
         const cplx an = cadd(av, ac);
-        ap_out[i] = an;
+        if (ap_out) ap_out[i] = an;   // (nullptr: only <r,Ap_k>, <Ap_k,Ap_k> are wanted — the solve's last step follows and its caller discards the residual)
         cplx t = cconj_mul(rv, an);
         v[0] += t.x; v[1] += t.y;
         cplx u = cconj_mul(an, an);
@@ -1487,6 +1487,10 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
                 tail_a = true;
             }
             if (ic_next != 0) {
+                // the next step is the solve's last and all it takes from this one are <r,Ap'>, <Ap',Ap'> (alpha_only_kernel: the caller — a
+                // post-smoother's, a coarsest solve's — discards the residual): Ap' itself is never read, so it is not written
+                static const bool skip_dead_ap = !(getenv("MGCR_SKIP_DEAD_AP") && atoi(getenv("MGCR_SKIP_DEAD_AP")) == 0);
+                if (skip_dead_ap && global + 1 == max_it && skip_tail && nested && s->discard_residual && !multi) a.ap_out = nullptr;
                 MGCR_TRY(launch_build_lean(a, 0));              // lim == nxt
             } else if (lim <= ND) {
                 MGCR_TRY(launch_build_close(a));                // lim == restart: closes the cycle
