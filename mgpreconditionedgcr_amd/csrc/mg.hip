@@ -36,7 +36,9 @@ typedef std::complex<double> hc;
 __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const int32_t *__restrict__ aptr,
                                                        const int32_t *__restrict__ amem, const cplx *__restrict__ pv,
                                                        const cplx *__restrict__ x, cplx *__restrict__ xc,
-                                                       const int *__restrict__ skip, int skip_it, ResidualSel sel) {
+                                                       const int *__restrict__ skip, int skip_it, ResidualSel sel, int pvu, cplx pvc) {
+    // pvu: every entry of the prolongator equals pvc (one constant near-null vector, aggregates of one size: MgLevel::pv_uniform) —
+    // the value is then not read from memory; same products, same bits
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
@@ -70,9 +72,12 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
         if (pairs) {
 #pragma unroll
             for (int u = 0; u < 8; u += 2) {
-                const double4 p2 = *reinterpret_cast<const double4 *>(pv + idx[u]);
+                if (pvu) { pvv[u] = pvc; pvv[u + 1] = pvc; }
+                else {
+                    const double4 p2 = *reinterpret_cast<const double4 *>(pv + idx[u]);
+                    pvv[u] = make_double2(p2.x, p2.y); pvv[u + 1] = make_double2(p2.z, p2.w);
+                }
                 const double4 x2 = *reinterpret_cast<const double4 *>(x + idx[u]);
-                pvv[u] = make_double2(p2.x, p2.y); pvv[u + 1] = make_double2(p2.z, p2.w);
                 xv[u] = make_double2(x2.x, x2.y); xv[u + 1] = make_double2(x2.z, x2.w);
                 if (ap) {
                     const double4 a2 = *reinterpret_cast<const double4 *>(ap + idx[u]);
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int64_t i = idx[u] >= 0 ? idx[u] : 0;
-                pvv[u] = pv[i * ne + k];
+                pvv[u] = pvu ? pvc : pv[i * ne + k];
                 xv[u] = x[i];
                 if (ap) xv[u] = csub(xv[u], cmul(alpha, ap[i]));   // same expression as xr_update_kernel: the same bits
             }
@@ -102,12 +107,14 @@ __global__ void __launch_bounds__(256) restrict_kernel(int64_t nc, int ne, const
 __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, const int32_t *__restrict__ agg,
                                                          const cplx *__restrict__ pv, const cplx *__restrict__ xc,
                                                          cplx *__restrict__ x, cplx damp, int add,
-                                                         const int *__restrict__ skip, int skip_it, PendingX pend) {
+                                                         const int *__restrict__ skip, int skip_it, PendingX pend, int pvu, cplx pvc) {
     if (skip && skip[0] < skip[1] + skip_it) return;  // {stop_at, base}: see gcr.hip DevState
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const cplx *c = xc + (int64_t)agg[i] * ne;
     cplx s = make_double2(0., 0.);
+    if (pvu) s = cadd(s, cmul(c[0], pvc));   // (restrict_kernel: pvu)
+    else
     for (int k = 0; k < ne; k++) s = cadd(s, cmul(c[k], pv[i * ne + k]));
     if (pend.st) {
         const int np = pend.st->npend;
@@ -131,6 +138,17 @@ __global__ void __launch_bounds__(256) expand_add_kernel(int64_t n, int ne, cons
 }
 
 
+// flag[0] = 0 as soon as an entry of pv differs (in its bits) from pv[0]
+__global__ void __launch_bounds__(256) pv_uniform_kernel(int64_t n, const cplx *__restrict__ pv, int *flag) {
+    const cplx v0 = pv[0];
+    bool same = true;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const cplx v = pv[i];
+        same = same && __double_as_longlong(v.x) == __double_as_longlong(v0.x) && __double_as_longlong(v.y) == __double_as_longlong(v0.y);
+    }
+    if (!same) flag[0] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // hierarchy
 // ------------------------------------------------------------------------------------------------
@@ -146,6 +164,8 @@ struct MgLevel {
     bool owns_A = false;
     int32_t *d_agg = nullptr, *d_aptr = nullptr, *d_amem = nullptr;
     cplx *d_pv = nullptr;
+    bool pv_uniform = false;    // ne == 1 and every entry of d_pv has the bits of pv_value: restrict / expand do not read d_pv
+    cplx pv_value = {0., 0.};
     cplx *x = nullptr, *b = nullptr, *r = nullptr;  // work vectors (x, b: levels >= 1)
     GcrState *pre = nullptr, *post = nullptr, *coarse = nullptr;
     cplx *inv = nullptr;   // coarsest level, direct solve (dense.hip): the inverse of A, n x n
@@ -221,6 +241,20 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         rc = mg_level_setup_device(L.A, ndim, dims.data(), blocked.data(), p->subblock_dim, ne, d_vecs, &L.nagg, &L.d_agg, &L.d_aptr,
                                    &L.d_amem, &L.d_pv, &Ac, l + 2 < nlev, &d_next);
         if (rc != MGCR_OK) break;
+        if (ne == 1 && L.n > 0 && !(getenv("MGCR_MG_UNIFORM_PV") && atoi(getenv("MGCR_MG_UNIFORM_PV")) == 0)) {
+            // one constant near-null vector over aggregates of one size: every entry of the prolongator is the same number — the cycle's
+            // transfer kernels then skip that stream (a vector's worth of reads each)
+            int *d_flag = nullptr, h_flag = 1;
+            rc = up<int>(&d_flag, &h_flag, 1);
+            if (rc != MGCR_OK) break;
+            hipLaunchKernelGGL(pv_uniform_kernel, dim3(2048), dim3(256), 0, ctx().stream, L.n, (const cplx *)L.d_pv, d_flag);
+            hipError_t e = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx().stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&L.pv_value, L.d_pv, sizeof(cplx), hipMemcpyDeviceToHost, ctx().stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+            hipFree(d_flag);
+            if (e != hipSuccess) { set_error("mg set-up: prolongator scan failed"); rc = MGCR_ERR_HIP; break; }
+            L.pv_uniform = h_flag != 0;
+        }
         C.A = Ac;
         C.owns_A = true;
         C.n = L.nagg * ne;
@@ -278,7 +312,8 @@ int mg_create(Op *A, const mgcr_mg_param *p, MgState **out) {
 static unsigned g256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 int mg_restrict_raw(int64_t nc, int ne, const int32_t *aptr, const int32_t *amem, const cplx *pv, const cplx *x, cplx *xc) {
-    hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, ne, aptr, amem, pv, x, xc, (const int *)nullptr, 0, ResidualSel{});
+    hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, ne, aptr, amem, pv, x, xc, (const int *)nullptr, 0, ResidualSel{}, 0,
+                       make_double2(0., 0.));
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -287,7 +322,7 @@ int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc, const ResidualSel *s
     MgLevel &L = m->lev[(size_t)l];
     int64_t nc = L.nagg * L.ne;
     hipLaunchKernelGGL(restrict_kernel, dim3(g256(nc)), dim3(256), 0, ctx().stream, nc, L.ne, L.d_aptr, L.d_amem, L.d_pv, x, xc,
-                       get_apply_skip().p, get_apply_skip().it, sel ? *sel : ResidualSel{});
+                       get_apply_skip().p, get_apply_skip().it, sel ? *sel : ResidualSel{}, L.pv_uniform ? 1 : 0, L.pv_value);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
@@ -295,7 +330,8 @@ int mg_restrict(MgState *m, int l, const cplx *x, cplx *xc, const ResidualSel *s
 int mg_expand(MgState *m, int l, const cplx *xc, cplx *x, bool add, double damping, const PendingX *pend) {
     MgLevel &L = m->lev[(size_t)l];
     hipLaunchKernelGGL(expand_add_kernel, dim3(g256(L.n)), dim3(256), 0, ctx().stream, L.n, L.ne, L.d_agg, L.d_pv, xc, x,
-                       make_double2(damping, 0.), add ? 1 : 0, get_apply_skip().p, get_apply_skip().it, pend ? *pend : PendingX{});
+                       make_double2(damping, 0.), add ? 1 : 0, get_apply_skip().p, get_apply_skip().it, pend ? *pend : PendingX{}, L.pv_uniform ? 1 : 0,
+                       L.pv_value);
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
 }
