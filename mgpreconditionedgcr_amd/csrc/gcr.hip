@@ -94,6 +94,12 @@ struct GcrState {
     int64_t xbak_n = 0;
     DevState *st = nullptr;
     double *partsA = nullptr, *partsR = nullptr, *partsN = nullptr, *partsB = nullptr;
+    // |b|^2 between the two smoothers of a V-cycle level (csrc/mg.hip): both get the same right-hand side, the kernels that embed the
+    // apply sum |b|^2 over the same rows in the same order — the post-smoother folds the partials the pre-smoother's pass left
+    // (partsN_of: the vector they belong to, nullptr = none; partsN_g: how many) instead of streaming b once more
+    GcrState *bnorm_src = nullptr;
+    const cplx *partsN_of = nullptr;
+    int partsN_g = 0;
     cplx *den = nullptr;  // cached <Aps[i],Aps[i]> per slot
     double *hist = nullptr;
     int hist_cap = 0;
@@ -113,6 +119,10 @@ struct GcrState {
 
 constexpr int64_t GRAPH_MAX_ROWS = 1 << 18;
 
+static bool bnorm_reuse_enabled() {
+    static const bool on = !(getenv("MGCR_BNORM_REUSE") && atoi(getenv("MGCR_BNORM_REUSE")) == 0);
+    return on;
+}
 static bool fuse_init_enabled() {
     static const bool on = !(getenv("MGCR_FUSE_INIT") && atoi(getenv("MGCR_FUSE_INIT")) == 0);
     return on;
@@ -1148,6 +1158,7 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
     const SkipRef outer = get_apply_skip();  // outer solver's predicate: if that solve is over, this one is a no-op too
     s->has_pending = false;
     s->defer_it = 0;
+    s->partsN_of = nullptr;   // (set again below by the path that leaves |b|^2 partials behind)
     const bool from_zero = s->x_from_zero;   // gcr_run_from_zero: x has to be zeroed here, unless the solve only ever ASSIGNS x
     s->x_from_zero = false;
 
@@ -1251,14 +1262,21 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
     MGCR_CHECK(!multi || (!p.left_precond && (!p.right_precond || flex)), MGCR_ERR_UNSUPPORTED,
                "on a distributed operator only flexible right preconditioning is available (set flexible = 1)");
     const DevState *cst = s->st;
+    const double *normN = s->partsN;
     if (fuse_start) {
         const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
         MGCR_TRY(csr_init_apply(b0->csr, rhs, s->aps[0], s->A->kind == OP_DIRAC, s->A->k, (const cplx *)nullptr, s->partsA, s->partsR,
                                 s->partsN, b0->dist, rmap));
     } else if (fuse_init) {
         const Op *b0 = s->A->kind == OP_DIRAC ? s->A->base : s->A;
+        if (!alias0 && !multi && s->bnorm_src && s->bnorm_src->partsN_of == rhs && s->bnorm_src->partsN_g == g && bnorm_reuse_enabled()) {
+            normN = s->bnorm_src->partsN;   // |b|^2: the partials of the solve that ran on this b just before
+            MGCR_TRY(csr_init_apply(b0->csr, p0, s->aps[0], s->A->kind == OP_DIRAC, s->A->k, (const cplx *)nullptr, s->partsA, s->partsR,
+                                    (double *)nullptr, b0->dist, rmap));
+        } else
         MGCR_TRY(csr_init_apply(b0->csr, p0, s->aps[0], s->A->kind == OP_DIRAC, s->A->k, alias0 ? (const cplx *)nullptr : rhs, s->partsA,
                                 s->partsR, s->partsN, b0->dist, rmap));
+        if (normN == s->partsN) { s->partsN_of = rhs; s->partsN_g = g; }
     } else if (alias0) {
         KLAUNCH(init3_partials_kernel, g, rhs, (const cplx *)s->aps[0], n, s->partsN, s->partsR, s->partsA, cst, 0);
     } else if (alias_p0) {
@@ -1277,7 +1295,7 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
         refA = {s->dA, 1, 1};
         refR = {s->dRB, 1, 1};
     } else {
-        KLAUNCH(init_kernel, 1, s->st, (const double *)s->partsN, g, RED_MAX_BLOCKS, (const double *)s->partsR, g, RED_MAX_BLOCKS, s->hist);
+        KLAUNCH(init_kernel, 1, s->st, normN, g, RED_MAX_BLOCKS, (const double *)s->partsR, g, RED_MAX_BLOCKS, s->hist);
     }
 
     const int max_it = p.max_iter > 0 ? p.max_iter : 1;  // do..while: at least one iteration
@@ -1649,6 +1667,7 @@ int gcr_run(GcrState *s, const cplx *rhs, cplx *x, bool nested, double *hist, in
 }
 
 void gcr_set_discard_residual(GcrState *s, bool on) { s->discard_residual = on; }
+void gcr_set_bnorm_source(GcrState *s, GcrState *src) { s->bnorm_src = src; }
 void gcr_set_keep_pending(GcrState *s, bool on) { s->keep_pending = on; }
 // x = sum coef_j v_j for a caller that took the pending update and then needs x after all
 int gcr_flush_pending(const PendingX &pd, cplx *x, int64_t n) {

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(RED_THREADS, ((MODE == 3 && WT <= 7) || MODE =
     // thread 4 owns |r_0|^2, thread 5 |b|^2 (when b is given)
     if (threadIdx.x == 4) {
         partsR[lb] = mine;
-        if (!b) partsN[lb] = mine;
+        if (!b && partsN) partsN[lb] = mine;   // (partsN == nullptr: the caller has |b|^2 already — gcr.hip bnorm_src)
     }
     if (threadIdx.x == 5 && b) partsN[lb] = mine;
 }
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
     if (threadIdx.x < 4) partsA[(size_t)threadIdx.x * RED_MAX_BLOCKS + lb] = mine;
     if (threadIdx.x == 4) {
         partsR[lb] = mine;
-        if (!b) partsN[lb] = mine;
+        if (!b && partsN) partsN[lb] = mine;   // (partsN == nullptr: the caller has |b|^2 already — gcr.hip bnorm_src)
     }
     if (threadIdx.x == 5 && b) partsN[lb] = mine;
 }

@@ -287,6 +287,7 @@ int gcr_state_set_x0(GcrState *s, const cplx *x0, int64_t n);
 struct ResidualSel;  // gcr_dev.h
 bool gcr_last_residual(GcrState *s, ResidualSel *out);
 void gcr_set_discard_residual(GcrState *s, bool on);
+void gcr_set_bnorm_source(GcrState *s, GcrState *src);   // the solve that ran on the same right-hand side just before (|b|^2 partials reused)
 void gcr_set_defer_residual(GcrState *s, bool on);     // the caller forms the last step's residual on the fly (ResidualSel)
 struct PendingX;  // gcr_dev.h
 void gcr_set_keep_pending(GcrState *s, bool on);

@@ -271,6 +271,7 @@ static int mg_create_device(Op *A, const mgcr_mg_param *p, MgState **out) {
         sp.use_x0 = 1;
         if (rc == MGCR_OK) rc = gcr_state_create(L.A, &sp, 1, &L.post);
         if (rc == MGCR_OK) gcr_set_discard_residual(L.post, true);   // the cycle only takes x from its post-smoother
+        if (rc == MGCR_OK) gcr_set_bnorm_source(L.post, L.pre);      // ... and its |b|^2 from the pre-smoother: same b (gcr.hip bnorm_src)
         if (rc != MGCR_OK) break;
         hipFree(d_vecs);
         d_vecs = d_next;
