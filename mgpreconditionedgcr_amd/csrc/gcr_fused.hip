@@ -609,10 +609,10 @@ static void launch_xr_tile_nd(int nd, unsigned grid, size_t lds_bytes, const Row
     do {                                                                                                                               \
         static bool big_lds = false;                                                                                                   \
         if (!big_lds) {                                                                                                                \
-            hipFuncSetAttribute((const void *)step_apply_xr_tile_kernel<NS, RARE, NDT, (NDT <= 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+            hipFuncSetAttribute((const void *)step_apply_xr_tile_kernel<NS, RARE, NDT, (NDT <= XR_TILE_APC_NDT)>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
             big_lds = true;                                                                                                            \
         }                                                                                                                              \
-        hipLaunchKernelGGL((step_apply_xr_tile_kernel<NS, RARE, NDT, (NDT <= 4)>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r_in, ap, r_out, \
+        hipLaunchKernelGGL((step_apply_xr_tile_kernel<NS, RARE, NDT, (NDT <= XR_TILE_APC_NDT)>), dim3(grid), dim3(RED_THREADS), lds_bytes, ctx().stream, m, r_in, ap, r_out, \
                            y, d, n, g, rm, parts, partsR, st, it, partsA, nblkA, strideA, den_slot, slot, lc);                \
     } while (0)
     switch (nd) {

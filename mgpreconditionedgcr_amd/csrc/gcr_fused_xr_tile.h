@@ -1,8 +1,11 @@
 // step_apply_xr_tile_kernel: part of gcr_fused.hip (included there, inside namespace mgcr, after DotVecs) — kept in a file of its own
 // so that tools/xr_tile_regs.sh can compile just this kernel when its register budget is being worked on.
 #pragma once
+#ifndef XR_TILE_APC_NDT
+#define XR_TILE_APC_NDT 5    // up to this many: the newest direction's A p stays in registers for its dot product (APC)
+#endif
 #ifndef XR_TILE_OCC8_NDT
-#define XR_TILE_OCC8_NDT 5   // up to this many direction streams: 64 registers, two workgroups per CU
+#define XR_TILE_OCC8_NDT 4   // up to this many direction streams: 64 registers, two workgroups per CU (5 spill there: 484 us at 256^3 against 410 with one workgroup per CU and 81 registers)
 #endif
 // Bandwidth regime with the LDS window AND a row map whose step is the reach of the far slots (step_apply_tile_kernel's CARRY: a
 // 256 x 256 x Z grid): the residual update INSIDE the windowed apply.  What made that lose at 128^3 — r' = r - alpha Ap formed again

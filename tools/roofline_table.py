@@ -31,7 +31,12 @@ for r in rows:
     m = re.match(r"step_apply_kernel<\d+, \d+, (\d+)[,>]", name) or re.match(r"step_apply_tile_kernel<\d+, (?:true|false), (\d+)[,>]", name)
     if m:
         b = B_spmv + int(m.group(1)) * V            # SpMV + lim direction streams, Ar written once
-    m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false), (true|false)>", name)
+    m = re.match(r"step_apply_xr_tile_kernel<\d+, (?:true|false), (\d+), (true|false)>", name)
+    if m:
+        # residual update inside the windowed apply: r and Ap read, r' and A r' written, the other lim - 1 direction streams
+        # (Ap is the newest of them: in registers when the last template flag is true, else read again — an L2 hit, not counted)
+        b = B_pat + 4 * V + (int(m.group(1)) - 1) * V
+    m = re.match(r"step_build_kernel<\d+, \d+, (\d+), (true|false), (true|false)(?:, (?:true|false))?>", name)
     if m:
         lim = int(m.group(1))
         b = B_spmv - V + (2 * lim + 2) * V               # SpMV without the write of Ar; lim streams twice, r re-read, Ap written
