@@ -10,6 +10,6 @@ import json,sys
 var,v=sys.argv[1:3]
 c=json.loads(open("gpurun_out/ab256_%s.json"%v).read().strip().splitlines()[-1])
 m=json.loads(open("gpurun_out/abmg_%s.json"%v).read().strip().splitlines()[-1])
-print(var,v,"256^3", round(c["it_per_s"],1), [round(c["phases"][k]["us_per_iteration"],1) for k in ("xr","apply_dots","build")], "| mg256 vcycle_ms", round(m.get("vcycle_ms"),4), "solve_s", m.get("solve_seconds"), "its", m.get("iterations"), flush=True)
+print(var,v,"256^3", round(c["it_per_s"],1), [round(c["phases"][k]["us_per_iteration"],1) for k in ("xr","apply_dots","build")], "| mg256 vcycle_ms", round(m.get("vcycle_ms"),4), "seconds_to_tol", m.get("seconds_to_tol"), "outer its", m.get("outer_iterations"), flush=True)
 P
 done; done
