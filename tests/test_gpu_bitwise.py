@@ -250,6 +250,44 @@ def test_poisson_256x256_slab_carried_window_bit_for_bit(restart, steps):
     assert_bitwise("p256x256x16_restart%d_%dsteps" % (restart, steps), "multi-kernel (banded, carried window)", gcr, ref, None, x)
 
 
+_VARIANT_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import mgpreconditionedgcr_amd as mg
+from mgpreconditionedgcr_amd import *
+n, nz = 256, 16
+N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+A = Sparse(N, ncol, rowptr, col, val)
+b = Field((nz, n, n), problems.rhs_grid(N, 0))
+x = Field((nz, n, n)).set_zero()
+g = GCR(A, GCR_Param(0, 5, 12, 1e-30, False))
+g.solve(b, x)
+np.save(sys.argv[1], np.concatenate([np.asarray(g.last_history), x.to_numpy().ravel().view(np.float64)]))
+print("kind", A.xr_fuse_kind())
+"""
+
+
+def test_carried_window_and_fused_update_variants_agree(tmp_path):
+    """The same 12 steps of GCR(5) on the 256 x 256 x 16 slab in three child processes: far neighbours gathered (MGCR_TILE_CARRY=0),
+    carried in registers with the update kernel separate (MGCR_XR_FUSE_TILE=0), and the default (update inside the windowed apply).
+    The first two agree in every bit; the third differs from them in |r|^2's summation order only: x identical, history to 1e-15."""
+    import subprocess
+    import sys
+    outs = {}
+    for tag, env_add in (("gathered", dict(MGCR_TILE_CARRY="0")), ("carried", dict(MGCR_XR_FUSE_TILE="0")), ("fused", {})):
+        f = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, f], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=240, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[tag] = (np.load(f), p.stdout)
+    assert "kind 0" in outs["gathered"][1] and "kind 0" in outs["carried"][1] and "kind 2" in outs["fused"][1]
+    h = 13
+    assert np.array_equal(outs["gathered"][0], outs["carried"][0])
+    assert np.array_equal(outs["carried"][0][h:], outs["fused"][0][h:])
+    a, b = outs["carried"][0][:h], outs["fused"][0][:h]
+    assert not np.array_equal(a, b) and np.max(np.abs(a - b) / a) < 1e-15
+
+
 def _fuzz_system(rng):
     kind = rng.choice(["poisson-small", "poisson-slab", "poisson-pattern", "random", "random-wide"])
     if kind in ("random", "random-wide"):
