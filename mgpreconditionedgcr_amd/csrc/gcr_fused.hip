@@ -422,6 +422,66 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
     if (threadIdx.x == 5 && b) partsN[lb] = mine;
 }
 
+// The stand-alone apply y = A x  /  y = w - k A x  (w == nullptr: w is x) in the carried-window form of the two kernels above (CARRY: a
+// 256 x 256 x Z grid, real coefficients): persistent workgroups walk their band plane by plane, every entry of x is requested once
+// (+ the halo) and the far neighbours come from the thread's own previous / next trip.  Same row arithmetic as sten_spmv_tile
+// (spmv.hip): same bits.
+template <bool SHIFT>
+__global__ void __launch_bounds__(RED_THREADS, 8) sten_apply_carry_kernel(RowMat m, const cplx *__restrict__ x, cplx *__restrict__ y,
+                                                                          const cplx *__restrict__ w, int64_t n, int nlogical, RowMap rm,
+                                                                          const int *__restrict__ skip, int skip_it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char step_smem[];
+    constexpr unsigned NEAR = 0x3eu;
+    constexpr int NC = STEN_COMMON;
+    if (skip && skip[0] < skip[1] + skip_it) return;
+    const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
+    if (lb >= nlogical) return;
+    int64_t i, end, stride;
+    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    const int32_t H = m.sten_halo_f;
+    cplx *win = reinterpret_cast<cplx *>(step_smem);
+    const int wlen = RED_THREADS + 2 * H;
+    auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
+    const int lane = (int)(threadIdx.x & 63);
+    int buf = 0;
+    cplx c_prev = x[clampj(i + m.sten_off[0])], c_cur = x[clampj(i)];
+    for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
+        const bool live = i < end;
+        const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
+        const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
+        uint64_t pl[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) pl[c] = pp[c];
+        const cplx far6 = x[clampj(i + m.sten_off[6])];   // the next trip's own entry
+        cplx wv = make_double2(0., 0.);
+        if (SHIFT && w && live) wv = ld_stream<true>(w + i);
+        cplx halo = make_double2(0., 0.);
+        int hidx = -1;
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            halo = x[clampj(t < H ? base - H + t : base + RED_THREADS + (t - H))];
+            hidx = t < H ? t : RED_THREADS + t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cplx *sx = win + buf * wlen;
+        sx[H + threadIdx.x] = c_cur;
+        if (hidx >= 0) sx[hidx] = halo;
+        __syncthreads();
+        cplx sum = make_double2(0., 0.);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? c_prev : far6);
+            const bool on = (pl[c] >> lane & 1ull) != 0ull;
+            const cplx nsum = cadd(sum, sten_term<1>(m, c, xv));
+            sum.x = on ? nsum.x : sum.x;
+            sum.y = on ? nsum.y : sum.y;
+        }
+        if (live) y[i] = SHIFT ? csub(w ? wv : c_cur, cmul(m.k, sum)) : sum;
+        c_prev = c_cur;
+        c_cur = far6;
+    }
+}
+
 static int g_fuse = -1;
 static bool fuse_enabled() {
     if (g_fuse < 0) g_fuse = !(getenv("MGCR_FUSE") && atoi(getenv("MGCR_FUSE")) == 0);
@@ -738,6 +798,28 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
 #undef IA
     MGCR_HIP(hipGetLastError());
     return MGCR_OK;
+}
+
+// y = A x / y = w - k A x in the carried-window form; false: not this kind of operator (the caller takes its own kernels)
+bool csr_apply_carry(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *w) {
+    static const bool on = !(getenv("MGCR_APPLY_CARRY") && atoi(getenv("MGCR_APPLY_CARRY")) == 0);
+    if (!on || !tile_regime(A) || A.nrow != A.ncol || A.n_tail_rows) return false;
+    const int g = red_grid(A.nrow);
+    if (g < 64 || g % 8) return false;
+    const RowMap rm = make_row_map(A.nrow, g, A.reach);
+    if (!tile_carry(A, rm)) return false;
+    const RowMat m = row_mat(A, shift, k);
+    const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
+    const SkipRef sk = get_apply_skip();
+    static bool big_lds = false;
+    if (!big_lds) {
+        (void)hipFuncSetAttribute((const void *)sten_apply_carry_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        (void)hipFuncSetAttribute((const void *)sten_apply_carry_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        big_lds = true;
+    }
+    if (shift) hipLaunchKernelGGL((sten_apply_carry_kernel<true>), dim3((unsigned)g), dim3(RED_THREADS), win, ctx().stream, m, x, y, w, A.nrow, g, rm, sk.p, sk.it);
+    else hipLaunchKernelGGL((sten_apply_carry_kernel<false>), dim3((unsigned)g), dim3(RED_THREADS), win, ctx().stream, m, x, y, (const cplx *)nullptr, A.nrow, g, rm, sk.p, sk.it);
+    return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace mgcr

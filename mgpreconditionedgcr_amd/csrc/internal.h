@@ -213,6 +213,7 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
 struct DevState;
 struct LeanCoef;
 bool csr_xr_fusable(const CsrDev &A, const DistCsr *dist);
+bool csr_apply_carry(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, const cplx *w);   // gcr_fused.hip
 int csr_xr_fuse_kind(const CsrDev &A, const DistCsr *dist);
 int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r_out, cplx *y, bool shift, cplx k, const cplx *const *vecs,
                       int nd, double *parts, double *partsR, DevState *st, int it, const double *partsA, int nblkA, int strideA,

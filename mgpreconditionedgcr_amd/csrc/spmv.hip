@@ -1468,6 +1468,8 @@ static int csr_apply_t(const CsrDev &A, const cplx *x, cplx *y, cplx k, DistCsr 
         MGCR_TRY(ell_rows<SHIFT>(A, 0, ib, x, xh, n_own, y, k, w));
         MGCR_TRY(ell_rows<SHIFT>(A, ie, A.nrow - ie, x, xh, n_own, y, k, w));
     } else if (g_spmv_part != 2) {
+        // 256 x 256 x Z grids: the carried-window form (gcr_fused.hip) — every entry of x requested once, no far gathers
+        if (g_spmv_part == 0 && csr_stencil_active(A) && csr_apply_carry(A, x, y, SHIFT, k, w)) return MGCR_OK;
         MGCR_TRY(ell_rows<SHIFT>(A, 0, A.nrow, x, xh, n_own, y, k, w));
     }
     if (A.n_tail_rows && g_spmv_part != 1) {

@@ -288,6 +288,16 @@ def test_carried_window_and_fused_update_variants_agree(tmp_path):
     assert not np.array_equal(a, b) and np.max(np.abs(a - b) / a) < 1e-15
 
 
+def test_carried_window_apply_same_bits():
+    """The stand-alone apply (A x and the shifted x - k A x) of the 256 x 256 x 16 slab with and without the carried-window kernel
+    (gcr_fused.hip sten_apply_carry_kernel; MGCR_APPLY_CARRY=0 takes spmv.hip's sten_spmv_tile): identical results."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "apply_carry_check.py")], capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "identical: True" in p.stdout, p.stdout
+
+
 def _fuzz_system(rng):
     kind = rng.choice(["poisson-small", "poisson-slab", "poisson-pattern", "random", "random-wide"])
     if kind in ("random", "random-wide"):
