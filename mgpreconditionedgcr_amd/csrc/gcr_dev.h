@@ -76,6 +76,8 @@ struct RowMap {
     int64_t band;  // rows per band (multiple of RED_THREADS); 0 = not banded
     int per;       // logical workgroups per band
     int xg;        // not banded: consecutive logical workgroups per XCD (0: one contiguous run of grid / 8 per XCD and trip)
+    int nb;        // banded: number of bands (logical workgroups per * nb .. grid - 1 have no rows)
+    int strips;    // banded: an XCD owns a strip of ceil(per / 8) neighbouring workgroups of EVERY band (else: whole bands, nb == 8)
 };
 // Logical workgroup of physical workgroup b (the hardware deals workgroups round-robin over the 8 XCDs, b & 7) for the
 // fused apply kernels (gcr_fused.hip); partial sums are indexed by the logical number, so results do not depend on it.
@@ -83,18 +85,35 @@ struct RowMap {
 // workgroups at a time — a row's far neighbours (rows +- n^2 of a 3-D grid = +- 16 workgroups at 128^3) then belong to
 // the SAME XCD when (workgroups per plane / G) is a multiple of 8, and only the +- n rows at the ends of a run of G
 // workgroups are fetched by two L2s.
+// Banded in strips (the plane-walk map below): XCD x owns workgroups [x tq, (x + 1) tq) of every band, tq = ceil(per / 8) — a strip of
+// neighbouring tiles of every plane, so that only the strip's two edges fetch their +- n neighbours from another L2; its grid / 8
+// physical workgroups are dealt band by band, and those left over take the logical numbers behind the last band (no rows: they
+// write the zero partial sums of those slots).  A bijection of [0, grid), whatever per and nb.
 __device__ __forceinline__ int logical_workgroup(const RowMap &rm, int b, int grid) {
     if (grid & 7) return b;
     const int x = b & 7, q = b >> 3;
     if (rm.xg > 0 && !rm.band) return (q / rm.xg) * (8 * rm.xg) + x * rm.xg + (q % rm.xg);
+    if (rm.band && rm.strips) {
+        const int gx = grid >> 3, tq = (rm.per + 7) >> 3;
+        const int lo = x * tq < rm.per ? x * tq : rm.per;
+        const int vt = rm.per - lo < tq ? rm.per - lo : tq;
+        const int c = rm.nb * vt;
+        if (q < c) return (q / vt) * rm.per + lo + q % vt;
+        return rm.nb * rm.per + gx * x - rm.nb * lo + (q - c);
+    }
     return x * (grid >> 3) + q;
 }
 // `reach` = how far a row's gathers go (CsrDev::reach; 0 = unknown).  Banding pays when that is a sizeable part of
 // what one XCD covers per trip of a plain grid-stride (Poisson 256^3: 65536 of 65536 rows — 1 170 against 1 130 it/s);
 // when the neighbours mostly stay inside the XCD's slice anyway (128^3: 16384 of 65536) the single sweep front of
 // the plain map is faster (9.8 k against 9.4 k it/s).
+// Plane walk (full grids of 512 workgroups, reach a multiple of 1024 rows — the plane of a 3-D grid whose planes hold a multiple of
+// 1024 sites, 32 x 1024 <= plane <= 512 x 1024): a band's `per` = reach / 1024 workgroups tile ONE plane and step from plane to
+// plane, so the thread that owns row i owns rows i +- reach one trip earlier / later — what the windowed kernels' CARRY builds on
+// (gcr_fused.hip: the far neighbours never leave the registers).  nb = floor(64 / ceil(per / 8)) bands keep every XCD within its 64
+// workgroups; with per = 64 (256 x 256 planes) this IS the 8-band map above.
 inline RowMap make_row_map(int64_t n, int g, int64_t reach) {
-    RowMap m{0, 0, 0};
+    RowMap m{0, 0, 0, 0, 0};
     if (g >= 64 && g % 8 == 0) {
         // XCDs take turns G logical workgroups at a time, G chosen so that a row's farthest neighbours (reach rows away =
         // P workgroups) belong to the same XCD: P a multiple of 8 G.  Poisson 128^3 (P = 16, G = 2), fused apply + dots:
@@ -114,7 +133,16 @@ inline RowMap make_row_map(int64_t n, int g, int64_t reach) {
     const bool wide = reach > 0 ? 2 * reach >= slice : n >= ((int64_t)1 << 23);
     if (g >= 64 && g % 8 == 0 && wide) {
         m.per = g / 8;
-        m.band = ((n + 7) / 8 + RED_THREADS - 1) / RED_THREADS * RED_THREADS;
+        m.nb = 8;
+        static const int walk_env = getenv("MGCR_PLANE_WALK") ? atoi(getenv("MGCR_PLANE_WALK")) : 1;   // 0: off, 2: strips for 64-wide bands too
+        const int64_t T = reach > 0 && reach % RED_THREADS == 0 ? reach / RED_THREADS : 0;
+        if (walk_env && g == RED_MAX_BLOCKS && T >= 32 && T <= 512 && (T != 64 || walk_env == 2)) {
+            const int gx = g / 8, tq = (int)((T + 7) / 8);
+            m.per = (int)T;
+            m.nb = gx / tq;
+            m.strips = 1;
+        }
+        m.band = ((n + m.nb - 1) / m.nb + RED_THREADS - 1) / RED_THREADS * RED_THREADS;
     }
     return m;
 }

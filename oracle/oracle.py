@@ -290,14 +290,20 @@ class device_order:
         return False
 
 
-def row_map(n, reach):
+def row_map(n, reach, plane_walk=True):
     """(band, per) of gcr_dev.h:make_row_map for a solve on n rows whose operator's rows reach `reach` rows away
-    (0: unknown): banded when 2 * reach >= rows one XCD covers per trip of the plain grid-stride."""
+    (0: unknown): banded when 2 * reach >= rows one XCD covers per trip of the plain grid-stride.  Full grids (512 workgroups) whose
+    reach is a multiple of 1024 rows — the plane of a 3-D grid — get the plane-walk form: per = reach / 1024 workgroups tile one plane,
+    floor(64 / ceil(per / 8)) bands (per = 64: the 8-band map)."""
     g = min(max((n + 1023) // 1024, 1), 512)
     slice_ = g * 1024 // 8
     wide = (2 * reach >= slice_) if reach > 0 else (n >= 1 << 23)
     if g >= 64 and g % 8 == 0 and wide:
-        return ((n + 7) // 8 + 1023) // 1024 * 1024, g // 8
+        per, nb = g // 8, 8
+        T = reach // 1024 if reach > 0 and reach % 1024 == 0 else 0
+        if plane_walk and g == 512 and 32 <= T <= 512 and T != 64:
+            per, nb = T, 64 // ((T + 7) // 8)
+        return ((n + nb - 1) // nb + 1023) // 1024 * 1024, per
     return 0, 0
 
 

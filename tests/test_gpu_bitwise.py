@@ -288,6 +288,24 @@ def test_carried_window_and_fused_update_variants_agree(tmp_path):
     assert not np.array_equal(a, b) and np.max(np.abs(a - b) / a) < 1e-15
 
 
+@pytest.mark.parametrize("n,nz", [(192, 24), (320, 10), (384, 6), (512, 4)])
+def test_plane_walk_row_map_bit_for_bit(n, nz):
+    """Grids whose planes hold a multiple of 1024 sites other than 256 x 256: the band's workgroups tile one plane and step from plane to
+    plane (gcr_dev.h make_row_map: 36, 100, 144, 256 workgroups per band; 12, 4, 3, 2 bands; the logical workgroups behind the last band
+    have no rows), so the windowed kernels carry the far neighbours and the residual update runs inside the apply here as well.  7 steps
+    of GCR(5) against the oracle's model of that map."""
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+    b = problems.rhs_grid(N, 0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    lay = A.ell_layout()
+    band, per = orc.row_map(N, lay["reach"])
+    assert per == n * n // 1024 and band > 0 and A.xr_fuse_kind() == 2
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 7, 1e-13, False), orc.gcr_param(restart=5, max_iter=7, tol=1e-13), b, dims=(nz, n, n))
+    assert not small
+    assert_bitwise("p%dx%dx%d_restart5_7steps" % (n, n, nz), "multi-kernel (plane walk, carried window)", gcr, ref, None, x)
+
+
 def test_carried_window_apply_same_bits():
     """The stand-alone apply (A x and the shifted x - k A x) of the 256 x 256 x 16 slab with and without the carried-window kernel
     (gcr_fused.hip sten_apply_carry_kernel; MGCR_APPLY_CARRY=0 takes spmv.hip's sten_spmv_tile): identical results."""
