@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         if (hidx >= 0) sx[hidx] = halo;
         __syncthreads();
         cplx sum = make_double2(0., 0.);
+        if constexpr (RARE) sum = sten_pre_sum<(CARRY ? 1 : -1)>(m, i, pl[NC], lane, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? far0 : far6);
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         if (RARE) {
 #pragma unroll
             for (int c = NC; c < NS; c++)
-                if (pl[c] != 0ull) {   // wave-uniform: a wave of a boundary plane
+                if (pl[c] != 0ull && !(c == NC && m.sten_pre)) {   // wave-uniform: a wave of a boundary plane
                     const cplx xr = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[c]));
                     const bool on = (pl[c] >> lane & 1ull) != 0ull;
                     const cplx nsum = cadd(sum, sten_term<(CARRY ? 1 : -1)>(m, c, xr));
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
         if (hidx >= 0) sx[hidx] = halo;
         __syncthreads();
         cplx sum = make_double2(0., 0.);
+        if constexpr (RARE) sum = sten_pre_sum<(CARRY ? 1 : -1)>(m, i, pl[NC], lane, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const cplx xv = (NEAR >> c & 1u) ? sx[H + (int)threadIdx.x + m.sten_off[c]] : (c == 0 ? far0 : far6);
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
         if (RARE) {
 #pragma unroll
             for (int c = NC; c < NS; c++)
-                if (pl[c] != 0ull) {
+                if (pl[c] != 0ull && !(c == NC && m.sten_pre)) {
                     const cplx xr = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[c]));
                     const bool on = (pl[c] >> lane & 1ull) != 0ull;
                     const cplx nsum = cadd(sum, sten_term<(CARRY ? 1 : -1)>(m, c, xr));
@@ -558,7 +560,9 @@ static int64_t fused_tile_min_reach() {
 static bool tile_carry(const CsrDev &A, const RowMap &rm) {
     static const bool on = !(getenv("MGCR_TILE_CARRY") && atoi(getenv("MGCR_TILE_CARRY")) == 0);
     const int64_t step = (int64_t)rm.per * RED_THREADS;
-    return on && rm.band != 0 && A.sten_off[6] == step && A.sten_off[0] == -step && !A.sten_rare && sten_slots(A) == 7 &&
+    // (7 slots, or the 7 + 2 of a distributed row block: its halo columns are rarely present slots of their own — the carried far
+    // values of a boundary plane's rows are masked like the gathered ones were)
+    return on && rm.band != 0 && A.sten_off[6] == step && A.sten_off[0] == -step && sten_slots(A) == (A.sten_rare ? 9 : 7) &&
            row_mat(A, false, cplx{0., 0.}).realv;
 }
 static bool fused_tile_enabled() {
@@ -608,10 +612,13 @@ int csr_step_apply(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k, 
         A.reach >= fused_tile_min_reach()) {
         // 3-D stencil: x staged in an LDS window per trip (step_apply_tile_kernel)
         const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
-        if (A.sten_rare && pw) launch_tile_nd<9, true, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        const bool carry = tile_carry(A, rm);
+        if (A.sten_rare && pw && carry) launch_tile_nd<9, true, true, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (A.sten_rare && pw) launch_tile_nd<9, true, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
+        else if (A.sten_rare && carry) launch_tile_nd<9, true, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
         else if (A.sten_rare) launch_tile_nd<9, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
         else if (pw) launch_tile_nd<7, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
-        else if (!dist && tile_carry(A, rm)) launch_tile_nd<7, false, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
+        else if (carry) launch_tile_nd<7, false, false, true>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
         else launch_tile_nd<7, false>(nd, grid, win, m, x, y, d, A.nrow, g, parts, sk, rm);
     } else if (csr_stencil_active(A)) {   // MODE 4: rare-tail layout (7 common + 2 rare slots)
         if (A.sten_rare && pw) launch_nd<4, 9, true>(nd, grid, 0, m, x, y, d, A.nrow, g, parts, sk, rm, *pw);
@@ -700,7 +707,7 @@ bool csr_xr_fusable(const CsrDev &A, const DistCsr *dist) {
     static const int64_t limit = getenv("MGCR_XR_FUSE_ROWS") ? atoll(getenv("MGCR_XR_FUSE_ROWS")) : ((int64_t)1 << 19);
     if (!dist && tile_regime(A) && xr_tile_enabled() && csr_fusable(A, dist)) {
         // the windowed form: real stencil coefficients, and the far slots one step of the banded row map away (gcr_fused_xr_tile.h)
-        return tile_carry(A, make_row_map(A.nrow, red_grid(A.nrow), A.reach));
+        return !A.sten_rare && tile_carry(A, make_row_map(A.nrow, red_grid(A.nrow), A.reach));
     }
     // the gathers double, so short rows only: 64^3 7-point, 19 iterations of GCR(10): 0.633 -> 0.608 ms; the 4x4 sample matrix
     // (39 entries per row) loses 1.6 % and stays with the separate update kernel
@@ -731,7 +738,7 @@ int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r
                                              den_slot, slot, lc)
     if (tile_regime(A)) {
         const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
-        MGCR_CHECK(tile_carry(A, rm) && d.v[nd - 1] == ap, MGCR_ERR_INVALID, "csr_step_apply_xr: not the windowed form's case");
+        MGCR_CHECK(!A.sten_rare && tile_carry(A, rm) && d.v[nd - 1] == ap, MGCR_ERR_INVALID, "csr_step_apply_xr: not the windowed form's case");
         launch_xr_tile_nd<7, false>(nd, grid, win, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,
                                          den_slot, slot, lc);
     } else if (csr_stencil_active(A)) {
@@ -780,8 +787,9 @@ int csr_init_apply(const CsrDev &A, const cplx *r0, cplx *aps0, bool shift, cplx
         hipLaunchKernelGGL((init_apply_tile_kernel<NS, RARE, CARRY>), dim3(grid), dim3(RED_THREADS), win, ctx().stream, m, r0, aps0, b, A.nrow, g, rm, \
                            partsA, partsR, partsN, sk.p, sk.it);                                                                    \
     } while (0)
-        if (A.sten_rare) IAT(9, true, false);
-        else if (!dist && tile_carry(A, rm)) IAT(7, false, true);
+        if (A.sten_rare && tile_carry(A, rm)) IAT(9, true, true);
+        else if (A.sten_rare) IAT(9, true, false);
+        else if (tile_carry(A, rm)) IAT(7, false, true);
         else IAT(7, false, false);
 #undef IAT
     } else if (csr_stencil_active(A)) {
@@ -808,7 +816,7 @@ bool csr_apply_carry(const CsrDev &A, const cplx *x, cplx *y, bool shift, cplx k
     const int g = red_grid(A.nrow);
     if (g < 64 || g % 8) return false;
     const RowMap rm = make_row_map(A.nrow, g, A.reach);
-    if (!tile_carry(A, rm)) return false;
+    if (A.sten_rare || !tile_carry(A, rm)) return false;
     const RowMat m = row_mat(A, shift, k);
     const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
     const SkipRef sk = get_apply_skip();

@@ -104,6 +104,7 @@ struct CsrDev {
     // 64 * wave + l has the slot).  A row's x loads then depend on nothing but the row number.
     int32_t sten_ns = 0, sten_stride = 0;   // sten_ns: slots the operator has (reporting); the arrays below are in KERNEL layout:
     int32_t sten_kernel_ns = 0;             // 7 or 9 slots (unused ones: offset 0, value 0, no presence bits)
+    int32_t sten_pre = 0;         // rare-tail layout: slot 7 is summed BEFORE the common ones (a row block's lower halo column: first in storage order)
     uint32_t sten_rare = 0;       // non-zero: rare-tail layout — slots 0..6 common, slots 7, 8 present in fewer than 1/16 of the rows and
                                   // behind every common slot in column order: loaded only by waves whose presence word is not 0
     int32_t sten_off[16] = {};

@@ -414,19 +414,38 @@ static int sten_try(CsrDev &A) {
     std::vector<uint16_t> pbits((size_t)A.npat, 0);
     std::vector<char> have((size_t)ns, 0);
     double sre[16] = {}, sim[16] = {};
+    // The slot with the largest offset may come FIRST in the rows that have it: the halo column of a row block's first plane (rows
+    // handed over in global column order — the neighbour below has the smallest global column and, as local column nloc + k, the
+    // largest offset).  Such a LEADING slot is summed before the others (kernel slot 7 of the rare layout, RowMat::sten_pre), so the
+    // row sum keeps its storage order.  lead_mode: 0 undecided, 1 leading, 2 in ascending position.
+    int lead_mode = 0;
     for (int p = 0; p < A.npat; p++) {
-        int last = -1;
+        int last = -1, count = 0;
+        bool lead_here = false;
         for (int32_t w = 0; w < A.W; w++) {
             const size_t e = (size_t)p * A.W + w;
             if (re[e] == 0. && im[e] == 0.) continue;
             const int s = (int)(std::lower_bound(S.begin(), S.end(), off[e]) - S.begin());
-            if (s <= last) return MGCR_OK;   // a repeated or descending column: not a sub-stencil in storage order
-            last = s;
+            if (count == 0 && s == ns - 1 && ns > 1) lead_here = true;      // (decided below, once the pattern is known to have more entries)
+            else {
+                if (s <= last) return MGCR_OK;   // a repeated or descending column: not a sub-stencil in storage order
+                last = s;
+                if (s == ns - 1 && ns > 1 && count > 0) {
+                    if (lead_mode == 1) return MGCR_OK;
+                    lead_mode = 2;
+                }
+            }
+            count++;
             if (!have[(size_t)s]) { have[(size_t)s] = 1; sre[s] = re[e]; sim[s] = im[e]; }
             else if (memcmp(&sre[s], &re[e], sizeof(double)) || memcmp(&sim[s], &im[e], sizeof(double))) return MGCR_OK;  // value differs between patterns
             pbits[(size_t)p] |= (uint16_t)(1u << s);
         }
+        if (lead_here && count > 1) {
+            if (lead_mode == 2) return MGCR_OK;
+            lead_mode = 1;
+        }
     }
+    const bool lead = lead_mode == 1;
     const int64_t nwaves = A.npad / 64;
     uint16_t *d_pmask = nullptr;
     unsigned long long *d_counts = nullptr;
@@ -455,15 +474,27 @@ static int sten_try(CsrDev &A) {
     // LAST one or two of the list (halo columns of a slab's first / last plane: local column nloc + slot lies behind
     // every owned column) and at most 7 common ones remain: common slots -> 0..6, rare ones -> 7, 8.  Otherwise every slot
     // is treated as common, 7 or 9 of them.
+    // A leading slot (above) always takes the rare layout: kernel slot 7, summed first; one rare slot behind the common ones may
+    // then follow as slot 8.
     int nrare = 0;
-    while (ok && nrare < 2 && nrare < ns - 1 && (int64_t)counts[(size_t)(ns - 1 - nrare)] * 16 < A.nrow) nrare++;
-    bool tail = nrare > 0 && ns - nrare <= STEN_COMMON;
-    for (int s = 0; ok && tail && s < ns - nrare; s++)
+    const int nsl = lead ? ns - 1 : ns;    // the slots in ascending position
+    while (ok && nrare < (lead ? 1 : 2) && nrare < nsl - 1 && (int64_t)counts[(size_t)(nsl - 1 - nrare)] * 16 < A.nrow) nrare++;
+    if (lead && nrare == 0 && nsl == STEN_COMMON + 1) nrare = 1;   // (the upper halo column of a block of few planes: not rare by count, but the ninth slot)
+    bool tail = (nrare > 0 || lead) && nsl - nrare <= STEN_COMMON;
+    for (int s = 0; ok && tail && !lead && s < nsl - nrare; s++)
         if ((int64_t)counts[(size_t)s] * 16 < A.nrow) tail = false;   // a rare slot among the common ones: no special treatment
+    if (lead && !tail) {   // more than 7 slots besides the leading one: no view (the dictionary kernels keep the storage order)
+        hipFree(d_pmask); hipFree(d_counts); hipFree(planes);
+        return MGCR_OK;
+    }
     const bool force = ns <= STEN_COMMON && getenv("MGCR_TEST_FORCE_RARE") && atoi(getenv("MGCR_TEST_FORCE_RARE")) != 0;
     if (force) { tail = true; nrare = 0; }   // measurement aid: a single-GPU operator through the kernels of a distributed row block
     int slot_of[16];
-    for (int s = 0; s < ns; s++) slot_of[s] = tail && s >= ns - nrare ? STEN_COMMON + (s - (ns - nrare)) : s;
+    for (int s = 0; s < ns; s++) {
+        if (lead && s == ns - 1) slot_of[s] = STEN_COMMON;                                           // summed first
+        else if (tail && s >= nsl - nrare) slot_of[s] = STEN_COMMON + (lead ? 1 : 0) + (s - (nsl - nrare));
+        else slot_of[s] = s;
+    }
     const int kernel_ns = tail ? 9 : ns <= 7 ? 7 : 9;
     const int32_t stride = kernel_ns == 7 ? 8 : 16;
     if (ok) {
@@ -484,6 +515,7 @@ static int sten_try(CsrDev &A) {
     A.sten_stride = stride;
     A.sten_planes = planes;
     A.sten_rare = tail ? 3u << STEN_COMMON : 0u;
+    A.sten_pre = lead ? 1 : 0;
     for (int k = 0; k < 16; k++) { A.sten_off[k] = 0; A.sten_re[k] = 0.; A.sten_im[k] = 0.; }
     for (int s = 0; s < ns; s++) {
         A.sten_off[slot_of[s]] = S[(size_t)s];
@@ -495,7 +527,7 @@ static int sten_try(CsrDev &A) {
     A.sten_near = 0;
     A.sten_halo = 0;
     for (int s = 0; s < ns; s++) {
-        if (tail && s >= ns - nrare) continue;
+        if (tail && slot_of[s] >= STEN_COMMON) continue;
         const int32_t a = S[(size_t)s] < 0 ? -S[(size_t)s] : S[(size_t)s];
         if (a <= STEN_TILE / 2) { A.sten_near |= 1u << slot_of[s]; A.sten_halo = std::max(A.sten_halo, a); }
     }
@@ -503,7 +535,7 @@ static int sten_try(CsrDev &A) {
     A.sten_near_f = 0;
     A.sten_halo_f = 0;
     for (int s = 0; s < ns; s++) {
-        if (tail && s >= ns - nrare) continue;
+        if (tail && slot_of[s] >= STEN_COMMON) continue;
         const int32_t a = S[(size_t)s] < 0 ? -S[(size_t)s] : S[(size_t)s];
         if (a <= RED_THREADS / 2) { A.sten_near_f |= 1u << slot_of[s]; A.sten_halo_f = std::max(A.sten_halo_f, a); }
     }
@@ -512,7 +544,8 @@ static int sten_try(CsrDev &A) {
         // how far a row's gathers reach decides the row -> workgroup map of the GCR step kernels (gcr_dev.h): the two
         // rare slots (halo columns, "nloc rows away") concern one plane each and must not count
         A.reach = 0;
-        for (int s = 0; s < ns - nrare; s++) A.reach = std::max<int64_t>(A.reach, S[(size_t)s] < 0 ? -(int64_t)S[(size_t)s] : (int64_t)S[(size_t)s]);
+        for (int s = 0; s < ns; s++)
+            if (slot_of[s] < STEN_COMMON) A.reach = std::max<int64_t>(A.reach, S[(size_t)s] < 0 ? -(int64_t)S[(size_t)s] : (int64_t)S[(size_t)s]);
     }
     return MGCR_OK;
 }
@@ -1130,6 +1163,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63);
     cplx sum = make_double2(0., 0.);
+    if constexpr (RARE) sum = sten_pre_sum<-1>(m, rloc, pl[NC], lane, [&](int32_t j) -> cplx { return gather_x(x, xh, n_own, j); });
     // (the real / complex decision once, not per slot: per slot it put a scalar fetch and a branch between every two terms)
     if (realv) {
 #pragma unroll
@@ -1154,7 +1188,7 @@ __global__ void __launch_bounds__(BLK) sten_spmv_tile(RowMat m, int64_t row_begi
     if (RARE) {
 #pragma unroll
         for (int c = NC; c < NS; c++)
-            if (pl[c] != 0ull) {   // wave-uniform: a wave of a boundary plane
+            if (pl[c] != 0ull && !(c == NC && m.sten_pre)) {   // wave-uniform: a wave of a boundary plane
                 const cplx xr = gather_x(x, xh, n_own, clampj(rloc + m.sten_off[c]));
                 const bool on = (pl[c] >> lane & 1ull) != 0ull;
                 const cplx t = m.realv ? make_double2(m.sten_re[c] * xr.x, m.sten_re[c] * xr.y) : cmul(make_double2(m.sten_re[c], m.sten_im[c]), xr);

@@ -68,6 +68,7 @@ struct RowMat {
     // MODE 3: stencil view (CsrDev::sten_*)
     int32_t sten_ns, sten_stride, sten_last;   // slots, presence words per wave, last column (clamp)
     uint32_t sten_rare, sten_near;
+    int32_t sten_pre;      // rare-tail layout: slot 7 is summed before the common slots
     int32_t sten_halo, sten_halo_f, sten_nwaves;   // sten_planes holds sten_nwaves rows + one all-zero row
     int32_t sten_off[STEN_MAX];
     double sten_re[STEN_MAX], sten_im[STEN_MAX];
@@ -82,7 +83,7 @@ inline RowMat row_mat(const CsrDev &A, bool shift, cplx k) {
     m.pid = A.pat_id; m.poff = A.pat_off; m.pre = A.pat_re; m.pim = A.pat_im;
     m.shift = shift ? 1 : 0; m.k = k;
     m.xh = nullptr; m.n_own = INT32_MAX;
-    m.sten_ns = A.sten_ns; m.sten_stride = A.sten_stride; m.sten_last = (int32_t)A.ncol - 1; m.sten_rare = A.sten_rare;
+    m.sten_ns = A.sten_ns; m.sten_stride = A.sten_stride; m.sten_last = (int32_t)A.ncol - 1; m.sten_rare = A.sten_rare; m.sten_pre = A.sten_pre;
     m.sten_near = A.sten_near; m.sten_halo = A.sten_halo; m.sten_halo_f = A.sten_halo_f; m.sten_nwaves = (int32_t)(A.npad / 64);
     for (int c = 0; c < STEN_MAX; c++) { m.sten_off[c] = A.sten_off[c]; m.sten_re[c] = A.sten_re[c]; m.sten_im[c] = A.sten_im[c]; }
     m.sten_planes = A.sten_planes;
@@ -173,6 +174,22 @@ __device__ __forceinline__ cplx sten_term(const RowMat &m, int c, cplx xv) {
     if (REALV > 0 || (REALV < 0 && m.realv)) return make_double2(m.sten_re[c] * xv.x, m.sten_re[c] * xv.y);
     return cmul(make_double2(m.sten_re[c], m.sten_im[c]), xv);
 }
+// Rare-tail layout with RowMat::sten_pre: slot STEN_COMMON (7) comes FIRST in its rows' storage order (spmv.hip sten_try) — its term
+// opens the row sum.  plw = the wave's presence word of that slot; xf(j) fetches column j.
+template <int REALV, class XF>
+__device__ __forceinline__ cplx sten_pre_sum(const RowMat &m, int64_t row, uint64_t plw, int lane, XF xf) {
+    cplx sum = make_double2(0., 0.);
+    if (m.sten_pre && plw != 0ull) {   // wave-uniform: a wave of the block's first plane
+        int32_t j = (int32_t)row + m.sten_off[STEN_COMMON];
+        j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
+        const cplx xr = xf(j);
+        const bool on = (plw >> lane & 1ull) != 0ull;
+        const cplx nsum = cadd(sum, sten_term<REALV>(m, STEN_COMMON, xr));
+        sum.x = on ? nsum.x : sum.x;
+        sum.y = on ? nsum.y : sum.y;
+    }
+    return sum;
+}
 template <int NS, bool RARE, int REALV, class XF>
 __device__ __forceinline__ cplx sten_row_product_t(const RowMat &m, int64_t row, XF xf) {
     static_assert(!RARE || NS == 9, "the rare-tail layout has 7 common + 2 rare slots");
@@ -194,6 +211,7 @@ __device__ __forceinline__ cplx sten_row_product_t(const RowMat &m, int64_t row,
     __builtin_amdgcn_sched_barrier(0);
     const int lane = (int)(threadIdx.x & 63);
     cplx sum = make_double2(0., 0.);
+    if constexpr (RARE) sum = sten_pre_sum<REALV>(m, row, pl[NC], lane, xf);
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const bool on = (pl[c] >> lane & 1ull) != 0ull;
@@ -204,7 +222,7 @@ __device__ __forceinline__ cplx sten_row_product_t(const RowMat &m, int64_t row,
     if (RARE) {
 #pragma unroll
         for (int c = NC; c < NS; c++)
-            if (pl[c] != 0ull) {   // wave-uniform
+            if (pl[c] != 0ull && !(c == NC && m.sten_pre)) {   // wave-uniform
                 int32_t j = (int32_t)row + m.sten_off[c];
                 j = j < 0 ? 0 : j > m.sten_last ? m.sten_last : j;
                 const cplx xr = xf(j);

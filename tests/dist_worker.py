@@ -127,6 +127,31 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if mode == "slab":
+        # 16 planes of a 256 x 256 grid over 2 ranks (8 planes = 512 x 1024 rows each: full grids): the row blocks take the plane-walk
+        # row map and, unless MGCR_TILE_CARRY=0, the windowed kernels that carry the far neighbours in registers (gcr_fused.hip CARRY,
+        # rare-slot layout: the halo columns); GCR(5), 12 steps, and the V-cycle-free flexible variant is left to the MG tests
+        import mgpreconditionedgcr_amd as mg
+        from mgpreconditionedgcr_amd import DistSparse, Field, GCR, GCR_Param
+        mg.init(0)
+        n, nz = 256, 16
+        N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+        per = nz // world
+        r0, r1 = rank * per * n * n, (rank + 1) * per * n * n
+        lp, lc, lv = local_block(rowptr, col, val, r0, r1)
+        A = DistSparse(comm, N, r0, lp, lc, lv)
+        bfull = problems.rhs_grid(N, 1)
+        b = Field((r1 - r0,), bfull[r0:r1])
+        y = A(b).to_numpy()
+        xs = Field((r1 - r0,)).set_zero()
+        gcr = GCR(A, GCR_Param(0, 5, 12, 1e-30, False, check_every=4))
+        gcr.solve(b, xs)
+        results["slab"] = dict(y=y, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations, format=A.storage_format()[0],
+                               layout=A.ell_layout(), allreduce=comm.allreduce_kind, halo=A.halo_kind)
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "bcsr":
         # BASELINE configs[4]'s operator as it is: a distributed HierarchicalSparse (block rows dealt to the ranks, block
         # columns anywhere), its apply, GCR on it, and MG with aggregates of two block rows whose Galerkin coarse operator

@@ -28,6 +28,37 @@ def test_distributed_gcr_with_transport_collectives(tmp_path, monkeypatch):
     test_distributed_gcr_matches_single_process(tmp_path, 2)
 
 
+def test_distributed_slab_carried_window(tmp_path, monkeypatch):
+    """Two ranks, 8 planes of a 256 x 256 grid each: the row blocks' windowed kernels carry the far neighbours from trip to trip (the halo
+    columns are rare slots of their own).  Same history, same x as with the far neighbours gathered (MGCR_TILE_CARRY=0), on every rank;
+    and the single-GPU solve within re-association."""
+    mg.init()
+    world = 2
+    (tmp_path / "carry").mkdir()
+    (tmp_path / "gather").mkdir()
+    res = run_workers("slab", world, tmp_path / "carry", timeout=240)
+    monkeypatch.setenv("MGCR_TILE_CARRY", "0")
+    ref = run_workers("slab", world, tmp_path / "gather", timeout=240)
+    monkeypatch.delenv("MGCR_TILE_CARRY")
+    for r in range(world):
+        assert res[r]["slab"]["format"] == 3 and res[r]["slab"]["layout"]["reach"] == 256 * 256
+        assert np.array_equal(res[r]["slab"]["hist"], ref[r]["slab"]["hist"]) and np.array_equal(res[r]["slab"]["hist"], res[0]["slab"]["hist"])
+        assert np.array_equal(res[r]["slab"]["x"], ref[r]["slab"]["x"]) and np.array_equal(res[r]["slab"]["y"], ref[r]["slab"]["y"])
+    n, nz = 256, 16
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+    A = Sparse(N, ncol, rowptr, col, val)
+    b = Field((N,), problems.rhs_grid(N, 1))
+    y = A(b).to_numpy()
+    assert np.array_equal(np.concatenate([res[r]["slab"]["y"] for r in range(world)]), y)
+    xs = Field((N,)).set_zero()
+    g = GCR(A, GCR_Param(0, 5, 12, 1e-30, False))
+    g.solve(b, xs)
+    h = res[0]["slab"]["hist"]
+    assert h.size == g.last_history.size and np.max(np.abs(h - g.last_history) / g.last_history) < 1e-12
+    xd = np.concatenate([res[r]["slab"]["x"] for r in range(world)])
+    assert np.abs(xd - xs.to_numpy()).max() <= 1e-11 * np.abs(xs.to_numpy()).max()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_gcr_matches_single_process(tmp_path, world):
     mg.init()
@@ -35,7 +66,9 @@ def test_distributed_gcr_matches_single_process(tmp_path, world):
     for kind in ("poisson", "random", "poisson48"):
         N, rowptr, col, val, gran = problem(kind)
         A = Sparse(N, N, rowptr, col, val)
-        assert res[0][kind]["format"] == (3 if kind == "poisson48" else 0)   # stencil view, halo columns as rarely present slots
+        # stencil view on EVERY rank: the upper halo column a rarely present slot behind the common ones, the lower one — first in its
+        # rows' storage order — a slot summed before them (spmv.hip sten_try: leading slot)
+        assert all(res[r][kind]["format"] == (3 if kind == "poisson48" else 0) for r in range(world)), [res[r][kind]["format"] for r in range(world)]
         # the per-iteration scalars went through the peer-write mailboxes (self-test passed on every rank), unless
         # the run asked for the transport's own all-reduce
         want = "host" if os.environ.get("MGCR_PEER_ALLREDUCE") == "0" else "peer-write"
