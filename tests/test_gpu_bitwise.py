@@ -229,14 +229,15 @@ def test_poisson192_banded_row_map_bit_for_bit():
     assert_bitwise("p192_6steps", "multi-kernel (banded)", gcr, ref, None, x)
 
 
-@pytest.mark.parametrize("restart,steps", [(5, 7), (10, 12), (3, 3)])
-def test_poisson_256x256_slab_carried_window_bit_for_bit(restart, steps):
+@pytest.mark.parametrize("restart,steps,nz", [(5, 7, 16), (10, 12, 16), (3, 3, 16), (5, 7, 21)])
+def test_poisson_256x256_slab_carried_window_bit_for_bit(restart, steps, nz):
     """16 planes of a 256 x 256 grid (1 M rows): the far neighbours of a row are exactly one step of the banded row map away, so the
     windowed kernels carry them in registers from trip to trip and the residual update runs inside the apply kernel
     (gcr_fused.hip CARRY, gcr_fused_xr_tile.h) — the kernels of BASELINE configs[2] (256^3) at a size the oracle finishes in seconds.
     |r|^2 of every step but the last is then summed over the banded map: the oracle's model follows (xr_banded).  The same solve with
-    the separate update kernel (MGCR_XR_FUSE_TILE=0 in a child process would be needed: tools/xr_tile_check.py) differs in those sums only."""
-    n, nz = 256, 16
+    the separate update kernel (test_carried_window_and_fused_update_variants_agree) differs in those sums only.  21 planes: bands of
+    2.625 planes — a band may start in the middle of a plane."""
+    n = 256
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
     b = problems.rhs_grid(N, 0)
     A = Sparse(N, ncol, rowptr, col, val)
@@ -247,7 +248,7 @@ def test_poisson_256x256_slab_carried_window_bit_for_bit(restart, steps):
     gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, restart, steps, 1e-13, False), orc.gcr_param(restart=restart, max_iter=steps, tol=1e-13), b,
                                     dims=(nz, n, n))
     assert not small
-    assert_bitwise("p256x256x16_restart%d_%dsteps" % (restart, steps), "multi-kernel (banded, carried window)", gcr, ref, None, x)
+    assert_bitwise("p256x256x%d_restart%d_%dsteps" % (nz, restart, steps), "multi-kernel (banded, carried window)", gcr, ref, None, x)
 
 
 _VARIANT_CHILD = r"""
