@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "ell_slab_spmv128", "irregular_spmv", "poisson128_gcr_general", "bcsr", "bcsr_mg", "sample", "latency64"]
+EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "poisson512_gcr", "ell_slab_spmv128", "irregular_spmv", "poisson128_gcr_general", "bcsr", "bcsr_mg", "sample", "latency64"]
 MG_PARITY_NOTE = ("unpinned: the reference's MG::operator() returns uninitialised memory (src/MG.h:124-129,405-430), so no reference "
                   "output exists; the cycle is checked against the oracle's corrected cycle — bit for bit in the device's summation order, "
                   "cycle and MG-preconditioned solve (tests/test_gpu_mg.py)")
@@ -436,8 +436,15 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
     last iteration (the timed solves run to max_iter) has no apply and no build launch at all (finish_step_kernel): it counts
     with its residual update only — rounds 1 and 2 booked an apply and a build for it that never ran (4-8 % too many bytes in the
     whole-iteration figure at --steps 20, 5 % in the dominant phase's).
+    fused == 5 (csrc/gcr_fused_xr_tile.h, the windowed regime; step_apply_xr_kernel in the latency regime): the residual update runs
+    inside the apply + dots kernel — r and Ap read, r' and A r' written, the other lim - 1 direction streams read (Ap IS the newest of
+    them): matrix + (3 + lim) V booked under `apply`, no xr launch; the build stays a launch of its own.  The solve's last iteration
+    still updates with xr_update_kernel (3 V).
     exact for the iterations that were timed: iteration k of a cycle orthogonalises against lim = k stored directions."""
     lims = [((k - 1) % R) + 1 for k in range(1, max(n_it, 1) + 1)]
+    xr_in_apply = fused == 5
+    if xr_in_apply:
+        fused = 1
     one = fused >= 2
     nl = len(lims)
 
@@ -456,6 +463,8 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
             if l == R:   # closing step in one launch: apply (without the write of A r) + build_close (without its read)
                 return matrix_bytes + 16 * ncol + (3 * R + 5) * V + nxt
             return matrix_bytes + 16 * ncol + (2 * l + 2) * V + nxt
+        if xr_in_apply:
+            return matrix_bytes + (3 + l) * V
         return matrix_bytes + 16 * ncol + 16 * N + l * V + (0 if fused else V) + (V if l > 8 else 0)
 
     def build_bytes(idx):
@@ -463,7 +472,7 @@ def gcr_phase_model(n_it, R, V, matrix_bytes, ncol, N, fused):
         if one_launch(idx) or idx == nl - 1:
             return 0
         return (2 * R + 6) * V if l == R else (3 + l) * V
-    b_xr = [0 if update_prefetched(i) else 3.0 * V for i in range(nl)]
+    b_xr = [0 if update_prefetched(i) or (xr_in_apply and i < nl - 1) else 3.0 * V for i in range(nl)]
     b_apply = [apply_bytes(i) for i in range(nl)]
     b_build = [build_bytes(i) for i in range(nl)]
     return [sum(b_xr) / nl, sum(b_apply) / nl, sum(b_build) / nl], sum(lims) / float(nl)
@@ -644,8 +653,9 @@ def run_headline(args, with_cpu=True):
     V = 16 * N
     R = args.restart
     b_phase, mean_lim = gcr_phase_model(n_it.value, R, V, stored["matrix_bytes"], ncol, N, fused.value)
-    names = ["xr_update_kernel (alpha, residual ring, |r|^2)",
-             "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value == 1 else "SpMV + multidot_kernel",
+    names = ["xr_update_kernel (alpha, residual ring, |r|^2)" if fused.value != 5 else "(no launch but the solve's last update: the residual update runs inside the apply kernel)",
+             "step_apply_kernel (SpMV + beta dot products, one kernel)" if fused.value == 1 else
+             "step_apply_xr*_kernel (residual update + SpMV + beta dot products, one kernel)" if fused.value == 5 else "SpMV + multidot_kernel",
              "build_lean_kernel<1..%d> / build_close_kernel<%d> (direction build + x update)" % (R - 1, R)]
     if fused.value >= 2:
         names[0] = "xr_update_kernel (alpha, residual ring, |r|^2)" + (
@@ -799,11 +809,21 @@ def timed_solve(mg, gcr, rhs, x, x0=None):
 def wl_poisson256_gcr(args):
     """configs[1]'s solver at 256^3 — the working set (12 vectors of 268 MB) is far beyond the 256 MiB Infinity Cache, so
     this is the honest HBM point of the GCR iteration."""
+    return poisson_gcr_workload(256, 50, "3D 7-point Poisson 256^3, unpreconditioned GCR restart 5, complex fp64 (configs[1]'s solver at configs[2]'s size)")
+
+
+def wl_poisson512_gcr(args):
+    """configs[3]'s grid — 512^3, 134 M rows, 2.1 GB per vector — on ONE MI355X (the reference partitions it over 8 devices; 288 GB of HBM
+    hold the solver's ~14 vectors several times over): the plane-walk row map's largest plane (256 workgroups per band, 2 bands)."""
+    return poisson_gcr_workload(512, 25, "3D 7-point Poisson 512^3 (configs[3]'s grid) on ONE GPU, unpreconditioned GCR restart 5, complex fp64")
+
+
+def poisson_gcr_workload(n, iters, title):
     import ctypes
     import mgpreconditionedgcr_amd as mg
     from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, Sparse, problems
     mg.init(0)
-    n, R, iters = 256, 5, 50
+    R = 5
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
     nnz = int(rowptr[-1])
     A = Sparse(N, ncol, rowptr, col, val)
@@ -830,8 +850,8 @@ def wl_poisson256_gcr(args):
     spmv_bytes = stored["matrix_bytes"] + 2 * V
     cold_read = cold_apply_read_sweep(mg, A, rhs, y, 10, Field, spmv_bytes)
     b_survey = spmv_algorithmic_bytes(nnz, N, ncol) + (13 + 3 * mean_lim) * V
-    return {"workload": "3D 7-point Poisson 256^3, unpreconditioned GCR restart 5, complex fp64 (configs[1]'s solver at configs[2]'s size)",
-            "rows": N, "nnz": nnz, "matrix_storage": storage_name(fmt, npat), "iterations_per_solve": iters,
+    return {"workload": title,
+            "rows": N, "nnz": nnz, "residual_update": "inside the windowed apply kernel (phases.xr: no launch)" if fu.value == 5 else "xr_update_kernel", "matrix_storage": storage_name(fmt, npat), "iterations_per_solve": iters,
             "it_per_s": iters / st["median"], "ms_per_iteration": ms, "timing_seconds": st,
             "phases": {keys[k]: {"us_per_iteration": ph_us[k], "bytes_per_launch": b_phase[k], "GBps": b_phase[k] / ph_us[k] / 1e3} for k in range(3)},
             "iteration": {"bytes_moved_model": sum(b_phase), "GBps": sum(b_phase) / ms / 1e6, "frac_hbm_peak": sum(b_phase) / ms / 1e6 / HBM_PEAK_GBS,
@@ -1420,7 +1440,7 @@ def wl_dist_bcsr(args):
 DIST_WORKLOADS = {"dist_mg": wl_dist_mg, "dist_bcsr": wl_dist_bcsr}
 DIST_EXTRA_TIMEOUT_S = 240
 
-WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
+WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "poisson512_gcr": wl_poisson512_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
              "sample": wl_sample, "latency64": wl_latency64, "irregular_spmv": wl_irregular_spmv, "poisson128_gcr_general": wl_poisson128_gcr_general,
              "bcsr_mg": wl_bcsr_mg}
 

@@ -64,7 +64,7 @@ bool set_lean_enabled(bool on) {
 // 0 = alpha/r update (+ preconditioner), 1 = operator apply + beta dot products, 2 = direction build
 static double g_prof_phase_ms[3] = {0., 0., 0.};
 static int g_prof_iters = 0;
-static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip); 3: + the next step's residual update; 4: the step that closes a cycle as well
+static int g_prof_fused = 0;   // 0: apply and dots separate; 1: one kernel; 2: + the direction build in that launch (gcr_stepbuild.hip); 3: + the next step's residual update; 4: the step that closes a cycle as well; 5: apply + dots in one kernel that also forms the residual update (gcr_fused.hip step_apply_xr*_kernel), build separate
 void gcr_last_profile(double *phase_ms_total, int *n_iter, int *fused) {
     for (int k = 0; k < 3; k++) phase_ms_total[k] = g_prof_phase_ms[k];
     *n_iter = g_prof_iters;
@@ -1616,7 +1616,7 @@ static int gcr_run_once(GcrState *s, const cplx *rhs, cplx *x, bool nested, doub
                 g_prof_phase_ms[k] += ms;
             }
         g_prof_iters = (int)(prof_events.size() / 4);
-        g_prof_fused = prof_step_build_close ? 4 : prof_step_build_xr ? 3 : prof_step_build ? 2 : fuse_ok ? 1 : 0;
+        g_prof_fused = prof_step_build_close ? 4 : prof_step_build_xr ? 3 : prof_step_build ? 2 : (fuse_ok && xr_fuse) ? 5 : fuse_ok ? 1 : 0;
         for (hipEvent_t e : prof_events) hipEventDestroy(e);
     }
     const int frc = gcr_finish(s, hist, hist_cap, n_iter, converged);

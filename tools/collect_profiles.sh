@@ -17,6 +17,8 @@ rocprofv3 --kernel-trace -d $out/kt -o kt -- python3 $B > $out/kt.log 2>&1 && py
  && rocprofv3 --kernel-trace -d $out/vc -o vc -- python3 tools/vcycle_prof.py > $out/vc.log 2>&1 && python tools/vcycle_breakdown.py $out/vc/vc_results.db > $out/${tag}_vcycle_breakdown.md && echo "vcycle done" \
  && rocprofv3 --kernel-trace -d $out/p256 -o p -- python3 bench.py --workload poisson256_gcr > $out/p256.log 2>&1 && python tools/rocpd_stats.py $out/p256/p_results.db > $out/${tag}_poisson256_kernel_stats.csv \
  && python tools/roofline_table.py $out/${tag}_poisson256_kernel_stats.csv 256 > $out/${tag}_poisson256_roofline_table.md && echo "poisson256 done" \
+ && rocprofv3 --kernel-trace -d $out/p512 -o p -- python3 bench.py --workload poisson512_gcr > $out/p512.log 2>&1 && python tools/rocpd_stats.py $out/p512/p_results.db > $out/${tag}_poisson512_kernel_stats.csv \
+ && python tools/roofline_table.py $out/${tag}_poisson512_kernel_stats.csv 512 > $out/${tag}_poisson512_roofline_table.md && echo "poisson512 done" \
  && rocprofv3 --kernel-trace -d $out/ell -o e -- python3 bench.py --workload ell_slab_spmv128 > $out/ell.log 2>&1 && python tools/rocpd_stats.py $out/ell/e_results.db > $out/${tag}_ell_slab_kernel_stats.csv && echo "ell done" \
  && python bench.py --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/bench.err && echo "bench done" \
  && rocprofv3 --kernel-trace -d $out/gen -o g -- python3 bench.py --workload poisson128_gcr_general > $out/gen.log 2>&1 && python tools/rocpd_stats.py $out/gen/g_results.db > $out/${tag}_poisson128_general_kernel_stats.csv && echo "general storage done" \
