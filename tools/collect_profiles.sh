@@ -40,5 +40,5 @@ done
 unset MGCR_BENCH_IRREGULAR_WINDOW
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
 timeout -k 10 120 tools/build/gather_lab > $out/${tag}_gather_lab.txt 2>&1 && echo "gather lab done"
-rm -rf $out/kt $out/vc $out/p256 $out/ell $out/pmc_fetch $out/pmc_write $out/gen $out/bmg
+rm -rf $out/kt $out/vc $out/p256 $out/p512 $out/ell $out/pmc_fetch $out/pmc_write $out/gen $out/bmg
 ls -la $out
