@@ -30,6 +30,22 @@ def poisson3d_csr(n, i0=0, i1=None, ni=None):
     return r.size, ni * n * n, rowptr, cols[mask], vals[mask].astype(np.complex128)
 
 
+def poisson3d_box_csr(nz, ny, nx):
+    """The same operator on an nz x ny x nx box (rows r = (i*ny + j)*nx + k): planes of ny * nx sites, lines of nx."""
+    i, j, k = np.meshgrid(np.arange(nz, dtype=np.int64), np.arange(ny, dtype=np.int64), np.arange(nx, dtype=np.int64), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    r = (i * ny + j) * nx + k
+    cand = [(i > 0, r - ny * nx, -1.0), (j > 0, r - nx, -1.0), (k > 0, r - 1, -1.0),
+            (np.ones_like(r, bool), r, 6.0),
+            (k < nx - 1, r + 1, -1.0), (j < ny - 1, r + nx, -1.0), (i < nz - 1, r + ny * nx, -1.0)]
+    mask = np.stack([c[0] for c in cand], axis=1)
+    cols = np.stack([c[1] for c in cand], axis=1)
+    vals = np.broadcast_to(np.array([c[2] for c in cand]), mask.shape)
+    rowptr = np.zeros(r.size + 1, np.int64)
+    np.cumsum(mask.sum(axis=1), out=rowptr[1:])
+    return r.size, nz * ny * nx, rowptr, cols[mask], vals[mask].astype(np.complex128)
+
+
 def rhs_grid(n, seed=0, offset=0):
     """numpy twin of mgcr_vec_fill_rhs: splitmix64 values on the 0.001 grid of init_rand."""
     def sm(x):

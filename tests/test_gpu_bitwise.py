@@ -289,6 +289,22 @@ def test_carried_window_and_fused_update_variants_agree(tmp_path):
     assert not np.array_equal(a, b) and np.max(np.abs(a - b) / a) < 1e-15
 
 
+@pytest.mark.parametrize("nz,ny,nx", [(32, 128, 256), (20, 256, 128), (6, 256, 512)])
+def test_plane_walk_row_map_on_boxes_bit_for_bit(nz, ny, nx):
+    """Planes that are not square: 128 x 256 (32 workgroups per band, 16 bands: two whole bands per XCD would also do — strips are what
+    runs), 256 x 128 (the +- n neighbours 128 rows away), 256 x 512 (128 workgroups per band, 4 bands; window halo 512)."""
+    N, ncol, rowptr, col, val = problems.poisson3d_box_csr(nz, ny, nx)
+    b = problems.rhs_grid(N, 0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    lay = A.ell_layout()
+    band, per = orc.row_map(N, lay["reach"])
+    assert lay["reach"] == ny * nx and per == ny * nx // 1024 and band > 0 and A.xr_fuse_kind() == 2
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 7, 1e-13, False), orc.gcr_param(restart=5, max_iter=7, tol=1e-13), b, dims=(nz, ny, nx))
+    assert not small
+    assert_bitwise("p%dx%dx%d_restart5_7steps" % (nz, ny, nx), "multi-kernel (plane walk, carried window)", gcr, ref, None, x)
+
+
 @pytest.mark.parametrize("n,nz", [(192, 24), (320, 10), (384, 6), (512, 4)])
 def test_plane_walk_row_map_bit_for_bit(n, nz):
     """Grids whose planes hold a multiple of 1024 sites other than 256 x 256: the band's workgroups tile one plane and step from plane to
