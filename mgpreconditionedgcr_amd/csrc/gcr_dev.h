@@ -78,6 +78,8 @@ struct RowMap {
     int xg;        // not banded: consecutive logical workgroups per XCD (0: one contiguous run of grid / 8 per XCD and trip)
     int nb;        // banded: number of bands (logical workgroups per * nb .. grid - 1 have no rows)
     int strips;    // banded: an XCD owns a strip of ceil(per / 8) neighbouring workgroups of EVERY band (else: whole bands, nb == 8)
+    int64_t plane; // != 0: ragged plane walk — planes of `plane` rows (a multiple of 64, not of 1024): a band's per = ceil(plane / 1024)
+                   // workgroups tile one plane (the last tile is short: its threads beyond the plane's end have no rows) and step by `plane`
 };
 // Logical workgroup of physical workgroup b (the hardware deals workgroups round-robin over the 8 XCDs, b & 7) for the
 // fused apply kernels (gcr_fused.hip); partial sums are indexed by the logical number, so results do not depend on it.
@@ -113,7 +115,7 @@ __device__ __forceinline__ int logical_workgroup(const RowMap &rm, int b, int gr
 // (gcr_fused.hip: the far neighbours never leave the registers).  nb = floor(64 / ceil(per / 8)) bands keep every XCD within its 64
 // workgroups; with per = 64 (256 x 256 planes) this IS the 8-band map above.
 inline RowMap make_row_map(int64_t n, int g, int64_t reach) {
-    RowMap m{0, 0, 0, 0, 0};
+    RowMap m{0, 0, 0, 0, 0, 0};
     if (g >= 64 && g % 8 == 0) {
         // XCDs take turns G logical workgroups at a time, G chosen so that a row's farthest neighbours (reach rows away =
         // P workgroups) belong to the same XCD: P a multiple of 8 G.  Poisson 128^3 (P = 16, G = 2), fused apply + dots:
@@ -143,17 +145,38 @@ inline RowMap make_row_map(int64_t n, int g, int64_t reach) {
             m.strips = 1;
         }
         m.band = ((n + m.nb - 1) / m.nb + RED_THREADS - 1) / RED_THREADS * RED_THREADS;
+        // ... and for planes that are a multiple of 64 rows only (n = 200, 264, 328 ...; a wave's 64 rows must not straddle two planes' tiles:
+        // the presence words of the stencil view are per aligned wave): the same walk with a short last tile per plane, whole planes per band
+        const int64_t Tr = (reach + RED_THREADS - 1) / RED_THREADS;
+        if (walk_env && g == RED_MAX_BLOCKS && T == 0 && reach > 0 && reach % 64 == 0 && Tr >= 32 && Tr <= 512) {
+            const int gx = g / 8, tq = (int)((Tr + 7) / 8);
+            m.per = (int)Tr;
+            m.nb = gx / tq;
+            m.strips = 1;
+            m.plane = reach;
+            const int64_t nplanes = (n + reach - 1) / reach;
+            m.band = (nplanes + m.nb - 1) / m.nb * reach;
+        }
     }
     return m;
 }
 // first row, one-past-last row and step of logical workgroup lb's thread
-__device__ __forceinline__ void row_range(const RowMap &m, int lb, int nlogical, int64_t n, int64_t *first, int64_t *end, int64_t *step) {
+// valid (the windowed kernels, which walk the tiles with a uniform trip count): false for a thread of a short tile that lies beyond the
+// plane's end — `first` is then still the row the thread's window entry belongs to; without `valid` such a thread gets an empty range
+__device__ __forceinline__ void row_range(const RowMap &m, int lb, int nlogical, int64_t n, int64_t *first, int64_t *end, int64_t *step,
+                                          bool *valid = nullptr) {
+    if (valid) *valid = true;
     if (m.band) {
         const int64_t xb = lb / m.per;
-        *first = xb * m.band + (int64_t)(lb % m.per) * RED_THREADS + threadIdx.x;
+        const int64_t in_plane = (int64_t)(lb % m.per) * RED_THREADS + threadIdx.x;
+        *first = xb * m.band + in_plane;
         const int64_t e = (xb + 1) * m.band;
         *end = e < n ? e : n;
-        *step = (int64_t)m.per * RED_THREADS;
+        *step = m.plane ? m.plane : (int64_t)m.per * RED_THREADS;
+        if (m.plane && in_plane >= m.plane) {
+            if (valid) *valid = false;
+            else *first = *end;
+        }
     } else {
         *first = (int64_t)lb * RED_THREADS + threadIdx.x;
         *end = n;

@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         return;
     }
     int64_t i, end, stride;
-    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    bool row_ok;   // (false: a thread of a plane's short last tile beyond the plane's end — it fills its window entry, nothing else)
+    row_range(rm, lb, nlogical, n, &i, &end, &stride, &row_ok);
     const int32_t H = m.sten_halo_f;
     cplx *win = reinterpret_cast<cplx *>(step_smem);   // 2 x [H + RED_THREADS + H]
     const int wlen = RED_THREADS + 2 * H;
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         c_cur = gather_x(x, m.xh, m.n_own, clampj(i));
     }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {   // uniform trip count per workgroup
-        const bool live = i < end;
+        const bool live = row_ok && i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
         const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
         uint64_t pl[NS];
@@ -343,7 +344,8 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
     const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     if (lb >= nlogical) return;
     int64_t i, end, stride;
-    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    bool row_ok;   // (false: a thread of a plane's short last tile beyond the plane's end — it fills its window entry, nothing else)
+    row_range(rm, lb, nlogical, n, &i, &end, &stride, &row_ok);
     const int32_t H = m.sten_halo_f;
     cplx *win = reinterpret_cast<cplx *>(step_smem);
     const int wlen = RED_THREADS + 2 * H;
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
         c_cur = gather_x(x, m.xh, m.n_own, clampj(i));
     }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
-        const bool live = i < end;
+        const bool live = row_ok && i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
         const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
         uint64_t pl[NS];
@@ -439,7 +441,8 @@ __global__ void __launch_bounds__(RED_THREADS, 8) sten_apply_carry_kernel(RowMat
     const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     if (lb >= nlogical) return;
     int64_t i, end, stride;
-    row_range(rm, lb, nlogical, n, &i, &end, &stride);
+    bool row_ok;   // (false: a thread of a plane's short last tile beyond the plane's end — it fills its window entry, nothing else)
+    row_range(rm, lb, nlogical, n, &i, &end, &stride, &row_ok);
     const int32_t H = m.sten_halo_f;
     cplx *win = reinterpret_cast<cplx *>(step_smem);
     const int wlen = RED_THREADS + 2 * H;
@@ -448,7 +451,7 @@ __global__ void __launch_bounds__(RED_THREADS, 8) sten_apply_carry_kernel(RowMat
     int buf = 0;
     cplx c_prev = x[clampj(i + m.sten_off[0])], c_cur = x[clampj(i)];
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
-        const bool live = i < end;
+        const bool live = row_ok && i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
         const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
         uint64_t pl[NC];
@@ -559,7 +562,7 @@ static int64_t fused_tile_min_reach() {
 // registers less: what lets them keep 64 vector registers without spills)
 static bool tile_carry(const CsrDev &A, const RowMap &rm) {
     static const bool on = !(getenv("MGCR_TILE_CARRY") && atoi(getenv("MGCR_TILE_CARRY")) == 0);
-    const int64_t step = (int64_t)rm.per * RED_THREADS;
+    const int64_t step = rm.plane ? rm.plane : (int64_t)rm.per * RED_THREADS;
     // (7 slots, or the 7 + 2 of a distributed row block: its halo columns are rarely present slots of their own — the carried far
     // values of a boundary plane's rows are masked like the gathered ones were)
     return on && rm.band != 0 && A.sten_off[6] == step && A.sten_off[0] == -step && sten_slots(A) == (A.sten_rare ? 9 : 7) &&

@@ -32,7 +32,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= XR_TILE_OCC8_NDT ? 8 : 4)
     if (st->stop_at < st->base + it) return;
     const int lb = logical_workgroup(rm, (int)blockIdx.x, (int)gridDim.x);
     int64_t i, end, stride;
-    row_range(rm, lb < nlogical ? lb : 0, nlogical, n, &i, &end, &stride);
+    bool row_ok;   // (false: a thread of a plane's short last tile beyond the plane's end — it fills its window entry, nothing else)
+    row_range(rm, lb < nlogical ? lb : 0, nlogical, n, &i, &end, &stride, &row_ok);
     const int32_t H = m.sten_halo_f;
     auto clampj = [&](int64_t j) -> int32_t { return (int32_t)(j < 0 ? 0 : j > m.sten_last ? m.sten_last : j); };
     // the first trip's operands are requested before alpha is folded from the partials (xr_update_kernel's prologue)
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= XR_TILE_OCC8_NDT ? 8 : 4)
     cplx cur_a = c_a;                                 // APC: Ap of row i
     int buf = 0;
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {   // uniform trip count per workgroup
-        const bool live = i < end;
+        const bool live = row_ok && i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
         const sten_planes_ptr pp = sten_wave_planes(m, wave < m.sten_nwaves ? wave : m.sten_nwaves);
         uint64_t pl[NS];

@@ -68,6 +68,8 @@ static int g_dev_init_banded = 0; /* step 0's sums come out of the kernel that e
 static int g_dev_ell_w = -1;      /* SpMV layout: ELL width W (rows longer than W keep a CSR tail); -1: every row sequential */
 static int g_dev_ell_l = 1;       /* lanes per row of the ELL part (1: sequential in CSR order) */
 static int g_dev_tail_cap = 0;    /* tail entries of a row: up to this many are summed in CSR order by one thread, more by a wave (lanes + tree) */
+static int64_t g_dev_plane = 0;   /* RowMap::plane: != 0, a band's workgroups tile ONE plane of this many rows (the last tile short) and step by it */
+void orc_set_device_plane(int64_t plane) { g_dev_plane = plane; }
 void orc_set_device_model(int blocks, int64_t band, int per, int init_banded, int ell_width, int ell_lanes, int tail_cap) {
     g_dev_blocks = blocks; g_dev_band = band; g_dev_per = per; g_dev_init_banded = init_banded;
     g_dev_ell_w = ell_width; g_dev_ell_l = ell_lanes < 1 ? 1 : ell_lanes; g_dev_tail_cap = tail_cap;
@@ -138,10 +140,11 @@ static double dev_sum(int64_t n, const double *term, int banded) {
         for (int t = 0; t < DEV_THREADS; t++) {
             int64_t first, end, step;
             if (use_band) {
-                const int64_t xb = b / g_dev_per;
-                first = xb * g_dev_band + (int64_t)(b % g_dev_per) * DEV_THREADS + t;
+                const int64_t xb = b / g_dev_per, in_plane = (int64_t)(b % g_dev_per) * DEV_THREADS + t;
+                first = xb * g_dev_band + in_plane;
                 end = (xb + 1) * g_dev_band; if (end > n) end = n;
-                step = (int64_t)g_dev_per * DEV_THREADS;
+                step = g_dev_plane ? g_dev_plane : (int64_t)g_dev_per * DEV_THREADS;
+                if (g_dev_plane && in_plane >= g_dev_plane) first = end;   /* a short last tile's threads beyond the plane's end */
             } else {
                 first = (int64_t)b * DEV_THREADS + t; end = n; step = (int64_t)g * DEV_THREADS;
             }

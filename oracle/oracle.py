@@ -78,6 +78,7 @@ def lib():
         L.orc_op_set_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_set_device_lean.argtypes = [C.c_int, C.c_int]
         L.orc_set_device_xr_banded.argtypes = [C.c_int]
+        L.orc_set_device_plane.argtypes = [C.c_int64]
         L.orc_op_nrow.argtypes = [C.c_void_p]
         L.orc_op_nrow.restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, _cp, _cp]
@@ -260,7 +261,7 @@ class device_order:
     (gcr_dev.h:make_row_map), needed from about 182^3 rows on (`row_map(n, reach)` below computes them)."""
 
     def __init__(self, blocks=0, band=0, per=0, init_banded=False, ell_width=-1, ell_lanes=1, tail_cap=0, rank_offsets=None, lean=False,
-                 recurrence_residual=False, xr_banded=False):
+                 recurrence_residual=False, xr_banded=False, plane=0):
         """rank_offsets: first row of every rank's block (+ the total) of a distributed solve — the ranks sum their rows
         separately and add the totals in rank order.  lean: x is formed the way the device's lean restart cycles form it (restart
         mode <= 16 slots without the literal preconditioner hooks), so that x is comparable bit for bit too; recurrence_residual:
@@ -271,6 +272,7 @@ class device_order:
         self.ranks = None if rank_offsets is None else np.ascontiguousarray(rank_offsets, np.int64)
         self.lean = (int(bool(lean)), int(bool(recurrence_residual)))
         self.xr_banded = int(bool(xr_banded))
+        self.plane = int(plane)   # RowMap::plane of the ragged plane walk (`row_map_plane`)
 
     def __enter__(self):
         lib().orc_set_device_model(*self.args)
@@ -278,6 +280,7 @@ class device_order:
             lib().orc_set_device_ranks(self.ranks.size - 1, self.ranks)
         lib().orc_set_device_lean(*self.lean)
         lib().orc_set_device_xr_banded(self.xr_banded)
+        lib().orc_set_device_plane(self.plane)
         lib().orc_set_sum_order(3)
         return self
 
@@ -285,16 +288,13 @@ class device_order:
         lib().orc_set_sum_order(0)
         lib().orc_set_device_lean(0, 0)
         lib().orc_set_device_xr_banded(0)
+        lib().orc_set_device_plane(0)
         lib().orc_set_device_model(0, 0, 0, 0, -1, 1, 0)
         lib().orc_set_device_ranks(1, np.zeros(2, np.int64))
         return False
 
 
-def row_map(n, reach, plane_walk=True):
-    """(band, per) of gcr_dev.h:make_row_map for a solve on n rows whose operator's rows reach `reach` rows away
-    (0: unknown): banded when 2 * reach >= rows one XCD covers per trip of the plain grid-stride.  Full grids (512 workgroups) whose
-    reach is a multiple of 1024 rows — the plane of a 3-D grid — get the plane-walk form: per = reach / 1024 workgroups tile one plane,
-    floor(64 / ceil(per / 8)) bands (per = 64: the 8-band map)."""
+def _row_map3(n, reach, plane_walk=True):
     g = min(max((n + 1023) // 1024, 1), 512)
     slice_ = g * 1024 // 8
     wide = (2 * reach >= slice_) if reach > 0 else (n >= 1 << 23)
@@ -303,8 +303,28 @@ def row_map(n, reach, plane_walk=True):
         T = reach // 1024 if reach > 0 and reach % 1024 == 0 else 0
         if plane_walk and g == 512 and 32 <= T <= 512 and T != 64:
             per, nb = T, 64 // ((T + 7) // 8)
-        return ((n + nb - 1) // nb + 1023) // 1024 * 1024, per
-    return 0, 0
+        band = ((n + nb - 1) // nb + 1023) // 1024 * 1024
+        Tr = (reach + 1023) // 1024
+        if plane_walk and g == 512 and T == 0 and reach > 0 and reach % 64 == 0 and 32 <= Tr <= 512:
+            per, nb = Tr, 64 // ((Tr + 7) // 8)
+            nplanes = (n + reach - 1) // reach
+            return (nplanes + nb - 1) // nb * reach, per, reach
+        return band, per, 0
+    return 0, 0, 0
+
+
+def row_map(n, reach, plane_walk=True):
+    """(band, per) of gcr_dev.h:make_row_map for a solve on n rows whose operator's rows reach `reach` rows away
+    (0: unknown): banded when 2 * reach >= rows one XCD covers per trip of the plain grid-stride.  Full grids (512 workgroups) whose
+    reach is a multiple of 1024 rows — the plane of a 3-D grid — get the plane-walk form: per = reach / 1024 workgroups tile one plane,
+    floor(64 / ceil(per / 8)) bands (per = 64: the 8-band map); a reach that is a multiple of 64 only, the ragged form (`row_map_plane`)."""
+    return _row_map3(n, reach, plane_walk)[:2]
+
+
+def row_map_plane(n, reach, plane_walk=True):
+    """RowMap::plane: != 0 when the map is the ragged plane walk (planes of `reach` rows, a multiple of 64 but not of 1024: a band's
+    ceil(reach / 1024) workgroups tile one plane, the last tile short, and step by the plane)."""
+    return _row_map3(n, reach, plane_walk)[2]
 
 
 def gcr_x_sensitivity(A, param, rhs, x0=None):

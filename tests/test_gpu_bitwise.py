@@ -68,7 +68,8 @@ def device_model(A, N, took_small):
     return orc.device_order(blocks=0, band=band, per=per, init_banded=band > 0,
                             ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"],
                             lean=True,      # (restart mode: x from the lean cycles' coefficient tables, like the device)
-                            xr_banded=band > 0 and A.xr_fuse_kind() == 2)   # residual update inside the windowed apply kernel
+                            xr_banded=band > 0 and A.xr_fuse_kind() == 2,   # residual update inside the windowed apply kernel
+                            plane=orc.row_map_plane(N, lay["reach"]))
 
 
 def solve_both(A, Ao, N, gp, po, b, x0=None, dims=None):
@@ -303,6 +304,23 @@ def test_plane_walk_row_map_on_boxes_bit_for_bit(nz, ny, nx):
     gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 7, 1e-13, False), orc.gcr_param(restart=5, max_iter=7, tol=1e-13), b, dims=(nz, ny, nx))
     assert not small
     assert_bitwise("p%dx%dx%d_restart5_7steps" % (nz, ny, nx), "multi-kernel (plane walk, carried window)", gcr, ref, None, x)
+
+
+@pytest.mark.parametrize("n,nz", [(200, 24), (264, 15), (328, 10), (400, 7)])
+def test_ragged_plane_walk_row_map_bit_for_bit(n, nz):
+    """Planes of a multiple of 64 sites that is not a multiple of 1024 (n a multiple of 8): ceil(n^2 / 1024) workgroups tile one plane —
+    the last tile is short, its threads beyond the plane's end fill their window entry and nothing else — and step by the plane; whole
+    planes per band.  Carried window and fused residual update as on the other sizes; the oracle's model follows (row_map_plane)."""
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+    b = problems.rhs_grid(N, 0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    lay = A.ell_layout()
+    band, per = orc.row_map(N, lay["reach"])
+    assert orc.row_map_plane(N, lay["reach"]) == n * n and per == (n * n + 1023) // 1024 and band % (n * n) == 0 and A.xr_fuse_kind() == 2
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 7, 1e-13, False), orc.gcr_param(restart=5, max_iter=7, tol=1e-13), b, dims=(nz, n, n))
+    assert not small
+    assert_bitwise("p%dx%dx%d_restart5_7steps" % (n, n, nz), "multi-kernel (ragged plane walk, carried window)", gcr, ref, None, x)
 
 
 @pytest.mark.parametrize("n,nz", [(192, 24), (320, 10), (384, 6), (512, 4)])
