@@ -63,8 +63,8 @@ for r in rows:
         b = B_spmv                                   # SpMV of step 0 + its dot products (no extra streams when b is r0)
     if name.startswith(("ell_spmv_rowthread", "pat_spmv", "sten_spmv")):
         b = B_spmv
-    if name.startswith("copy_kernel"):
-        b = 2 * V
+    # (copy_kernel: not listed — the run mixes copies of one vector with the 512 MiB cache sweeps of the cold-apply measurement;
+    # bench.py reports the copy of one vector on its own: spmv.copy_of_one_vector_ms)
     if b is None or int(r["Calls"]) < 4:
         continue
     gbs = b / us / 1e3
