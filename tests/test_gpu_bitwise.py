@@ -306,6 +306,29 @@ def test_plane_walk_row_map_on_boxes_bit_for_bit(nz, ny, nx):
     assert_bitwise("p%dx%dx%d_restart5_7steps" % (nz, ny, nx), "multi-kernel (plane walk, carried window)", gcr, ref, None, x)
 
 
+@pytest.mark.parametrize("nz,ny,nx", [
+    (15, 192, 192),    # fewer planes than twice the bands: bands of 1.3 planes
+    (14, 200, 200),    # ragged, 12 bands for 14 planes: 7 bands of 2 planes are used
+    (18, 100, 320),    # ragged, plane = 500 waves
+    (14, 64, 640),     # planes of 40 x 1024 rows whose +- nx neighbours are too far for the LDS window: the plane-walk map under the un-windowed kernels
+    (9, 250, 250),     # planes of 62 500 rows: not a multiple of 64 — the 8-band map stays
+    (3, 512, 512),     # 256 workgroups per band, 2 bands, 3 planes
+])
+def test_row_map_edge_shapes_bit_for_bit(nz, ny, nx):
+    """Shapes at the edges of gcr_dev.h make_row_map's cases; 6 steps of GCR(5), history and x against the oracle's model of the map
+    (oracle.row_map / row_map_plane mirror it)."""
+    N, ncol, rowptr, col, val = problems.poisson3d_box_csr(nz, ny, nx)
+    assert N >= 512 * 1024
+    b = problems.rhs_grid(N, 0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 6, 1e-13, False), orc.gcr_param(restart=5, max_iter=6, tol=1e-13), b, dims=(nz, ny, nx))
+    assert not small
+    RECORD.setdefault("row_map_edge_%dx%dx%d" % (nz, ny, nx), {})["map"] = dict(zip(("band", "per"), orc.row_map(N, A.ell_layout()["reach"])),
+                                                                                  plane=orc.row_map_plane(N, A.ell_layout()["reach"]), xr_fuse_kind=A.xr_fuse_kind())
+    assert_bitwise("row_map_edge_%dx%dx%d" % (nz, ny, nx), "multi-kernel", gcr, ref, None, x)
+
+
 @pytest.mark.parametrize("n,nz", [(200, 24), (264, 15), (328, 10), (400, 7)])
 def test_ragged_plane_walk_row_map_bit_for_bit(n, nz):
     """Planes of a multiple of 64 sites that is not a multiple of 1024 (n a multiple of 8): ceil(n^2 / 1024) workgroups tile one plane —
