@@ -127,14 +127,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    if mode == "slab":
+    if mode.startswith("slab"):
         # 16 planes of a 256 x 256 grid over 2 ranks (8 planes = 512 x 1024 rows each: full grids): the row blocks take the plane-walk
         # row map and, unless MGCR_TILE_CARRY=0, the windowed kernels that carry the far neighbours in registers (gcr_fused.hip CARRY,
         # rare-slot layout: the halo columns); GCR(5), 12 steps, and the V-cycle-free flexible variant is left to the MG tests
         import mgpreconditionedgcr_amd as mg
         from mgpreconditionedgcr_amd import DistSparse, Field, GCR, GCR_Param
         mg.init(0)
-        n, nz = 256, 16
+        n, nz = (int(v) for v in mode.split(":")[1:3]) if ":" in mode else (256, 16)   # "slab:200:28": planes of 40 000 rows (ragged plane walk)
         N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
         per = nz // world
         r0, r1 = rank * per * n * n, (rank + 1) * per * n * n

@@ -28,23 +28,23 @@ def test_distributed_gcr_with_transport_collectives(tmp_path, monkeypatch):
     test_distributed_gcr_matches_single_process(tmp_path, 2)
 
 
-def test_distributed_slab_carried_window(tmp_path, monkeypatch):
-    """Two ranks, 8 planes of a 256 x 256 grid each: the row blocks' windowed kernels carry the far neighbours from trip to trip (the halo
+@pytest.mark.parametrize("n,nz", [(256, 16), (200, 28)])
+def test_distributed_slab_carried_window(tmp_path, monkeypatch, n, nz):
+    """Two ranks, 8 planes of a 256 x 256 grid (14 of a 200 x 200 grid: the ragged plane walk) each: the row blocks' windowed kernels carry the far neighbours from trip to trip (the halo
     columns are rare slots of their own).  Same history, same x as with the far neighbours gathered (MGCR_TILE_CARRY=0), on every rank;
     and the single-GPU solve within re-association."""
     mg.init()
     world = 2
     (tmp_path / "carry").mkdir()
     (tmp_path / "gather").mkdir()
-    res = run_workers("slab", world, tmp_path / "carry", timeout=240)
+    res = run_workers("slab:%d:%d" % (n, nz), world, tmp_path / "carry", timeout=240)
     monkeypatch.setenv("MGCR_TILE_CARRY", "0")
-    ref = run_workers("slab", world, tmp_path / "gather", timeout=240)
+    ref = run_workers("slab:%d:%d" % (n, nz), world, tmp_path / "gather", timeout=240)
     monkeypatch.delenv("MGCR_TILE_CARRY")
     for r in range(world):
-        assert res[r]["slab"]["format"] == 3 and res[r]["slab"]["layout"]["reach"] == 256 * 256
+        assert res[r]["slab"]["format"] == 3 and res[r]["slab"]["layout"]["reach"] == n * n
         assert np.array_equal(res[r]["slab"]["hist"], ref[r]["slab"]["hist"]) and np.array_equal(res[r]["slab"]["hist"], res[0]["slab"]["hist"])
         assert np.array_equal(res[r]["slab"]["x"], ref[r]["slab"]["x"]) and np.array_equal(res[r]["slab"]["y"], ref[r]["slab"]["y"])
-    n, nz = 256, 16
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
     A = Sparse(N, ncol, rowptr, col, val)
     b = Field((N,), problems.rhs_grid(N, 1))
