@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "poisson512_gcr", "ell_slab_spmv128", "irregular_spmv", "poisson128_gcr_general", "bcsr", "bcsr_mg", "sample", "latency64"]
+EXTRA_WORKLOADS = ["poisson256_gcr", "mg256", "poisson512_gcr", "mg512", "ell_slab_spmv128", "irregular_spmv", "poisson128_gcr_general", "bcsr", "bcsr_mg", "sample", "latency64"]
 MG_PARITY_NOTE = ("unpinned: the reference's MG::operator() returns uninitialised memory (src/MG.h:124-129,405-430), so no reference "
                   "output exists; the cycle is checked against the oracle's corrected cycle — bit for bit in the device's summation order, "
                   "cycle and MG-preconditioned solve (tests/test_gpu_mg.py)")
@@ -867,11 +867,21 @@ def poisson_gcr_workload(n, iters, title):
 def wl_mg256(args):
     """configs[2]: Poisson 256^3, 3-level aggregation MG (2^3 aggregates, piecewise-constant P, Galerkin) as flexible right
     preconditioner of GCR restart 5; smoother 2 GCR sweeps, coarsest solve GCR tol 1e-2 / 50 iterations (src/main.cpp:841)."""
+    return mg_poisson_workload(256, 2, "3D 7-point Poisson 256^3, 3-level MG V-cycle preconditioner (2^3 aggregates), flexible GCR restart 5 to 1e-8, fp64 (configs[2])")
+
+
+def wl_mg512(args):
+    """configs[3]'s problem — 512^3, MG-preconditioned GCR — on ONE MI355X: 4 levels (512^3 .. 64^3, the coarsest solve stays the
+    one-launch resident solver of configs[2]); level 0 alone is 134 M rows, 2.1 GB per vector."""
+    return mg_poisson_workload(512, 3, "3D 7-point Poisson 512^3 (configs[3]'s problem) on ONE GPU, 4-level MG V-cycle preconditioner (2^3 aggregates), flexible GCR restart 5 to 1e-8, fp64")
+
+
+def mg_poisson_workload(n, levels, title):
     import numpy as np
     import mgpreconditionedgcr_amd as mg
     from mgpreconditionedgcr_amd import Field, GCR, GCR_Param, MG, MG_Param, Mesh, Sparse, problems
     mg.init(0)
-    n, levels, tol = 256, 2, 1e-8
+    tol = 1e-8
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
     nnz = int(rowptr[-1])
     A = Sparse(N, ncol, rowptr, col, val)
@@ -892,27 +902,34 @@ def wl_mg256(args):
         M(rhs, out=y)
         mg.lib().mgcr_synchronize()
         return time.perf_counter() - t
-    vc = stats(repeat_timed(cycle, min_total=0.2, min_reps=10))
+    vc = stats(repeat_timed(cycle, min_total=0.2, min_reps=10 if n <= 256 else 5))
     # SURVEY.md §8(d) "algorithmic bytes — V-cycle": per level nu_pre + nu_post smoother iterations B_iter(lim) =
     # B_spmv + (13 + 3 lim) V with lim = 1, 2, the residual B_spmv + 2 V, restrict V_l + V_(l+1), prolong+add V_(l+1) + 2 V_l
+    # What THIS implementation moves per level above the coarsest (V = one vector of the level, Vc of the next) —
+    # pre-smoother: A b + dots (b read, Ap0 written: 2 V), residual update + A r1 + dots (b, Ap0 read, r1, A r1 written: 4 V; as two
+    # launches where the update is not fused: 3 V + 2 V... booked at the fused count), build (A r1, r1, Ap0 read, Ap1 written: 4 V);
+    # restrict from the recurrence (r1, Ap1, member list: 2.25 V + Vc); prolong + pending x (b, r1, aggregate ids read, x written:
+    # 3.25 V + Vc; the prolongator is one number); post-smoother: b - A x (3 V), A r0 + dots (2 V: |b|^2 is the pre-smoother's), update +
+    # A r1 + dots (4 V), build without the write of Ap1 (3 V), x += (x, r0, r1 read, x written: 4 V): 31.5 V + 2 Vc.
     tot, moved, nl = 0, 0, n
     for _ in range(levels):
         Nl, nnzl = nl ** 3, 7 * nl ** 3 - 6 * nl ** 2
         Vl, Vc = 16 * Nl, 16 * (nl // 2) ** 3
         bsp = nnzl * 20 + (Nl + 1) * 4 + 2 * Vl
         tot += 2 * sum(bsp + (13 + 3 * lim) * Vl for lim in (1, 2)) + bsp + 2 * Vl + Vl + Vc + Vc + 2 * Vl
-        moved += 5 * (Nl // 8) + 44 * Vl + 2 * Vc    # what this implementation moves above the coarsest level
+        moved += 31.5 * Vl + 2 * Vc
         nl //= 2
     outer = GCR(A, GCR_Param(0, 5, 200, tol, False, None, M, flexible=True, check_every=2))
     timed_solve(mg, outer, rhs, x)
-    sv = stats(repeat_timed(lambda: timed_solve(mg, outer, rhs, x), min_total=0.3, min_reps=3, max_reps=10))
+    sv = stats(repeat_timed(lambda: timed_solve(mg, outer, rhs, x), min_total=0.3, min_reps=3, max_reps=10 if n <= 256 else 3))
     r = rhs - A(x)
-    return {"workload": "3D 7-point Poisson 256^3, 3-level MG V-cycle preconditioner (2^3 aggregates), flexible GCR restart 5 to 1e-8, fp64 (configs[2])",
+    return {"workload": title,
             "parity": MG_PARITY_NOTE, "rows": N, "nnz": nnz, "levels": [M.level_info(l) for l in range(levels + 1)],
             "mg_setup_seconds": setup_s, "vcycle_ms": vc["median"] * 1e3, "vcycle_timing_seconds": vc,
             "vcycle_bytes_survey_model_excl_coarsest": tot, "vcycle_GBps_survey": tot / vc["median"] / 1e9,
             "vcycle_bytes_moved_model_excl_coarsest": moved, "vcycle_GBps_moved_lower_bound": moved / vc["median"] / 1e9,
             "vcycle_frac_hbm_peak_moved_lower_bound": moved / vc["median"] / 1e9 / HBM_PEAK_GBS,
+            "vcycle_moved_model": "31.5 V + 2 V_coarse per level above the coarsest (round 2: 44 V); the coarsest solve (one launch, latency-bound) moves next to nothing, its time is in the denominator",
             "outer_iterations": outer.last_iterations, "converged": outer.last_converged, "seconds_to_tol": sv["median"],
             "solve_timing_seconds": sv, "tol": tol, "final_rel_residual": float(outer.last_history[-1]),
             "true_rel_residual": r.norm() / rhs.norm()}
@@ -1440,7 +1457,7 @@ def wl_dist_bcsr(args):
 DIST_WORKLOADS = {"dist_mg": wl_dist_mg, "dist_bcsr": wl_dist_bcsr}
 DIST_EXTRA_TIMEOUT_S = 240
 
-WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "poisson512_gcr": wl_poisson512_gcr, "mg256": wl_mg256, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
+WORKLOADS = {"poisson128_tol": wl_poisson128_tol, "poisson256_gcr": wl_poisson256_gcr, "poisson512_gcr": wl_poisson512_gcr, "mg256": wl_mg256, "mg512": wl_mg512, "ell_slab_spmv128": wl_ell_slab_spmv128, "bcsr": wl_bcsr,
              "sample": wl_sample, "latency64": wl_latency64, "irregular_spmv": wl_irregular_spmv, "poisson128_gcr_general": wl_poisson128_gcr_general,
              "bcsr_mg": wl_bcsr_mg}
 
