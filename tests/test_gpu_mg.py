@@ -390,6 +390,47 @@ def test_config3_full_size_mg_gcr_256():
     assert (lhs - rhs_c).norm() <= 1e-12 * rhs_c.norm()
 
 
+def test_config4_problem_at_its_size_on_one_gpu_mg_gcr_512():
+    """BASELINE configs[3]'s problem at its real size — Poisson 512^3, 134 M rows, 938 M entries, MG-preconditioned GCR — on ONE device
+    (the reference partitions it over 8; an MI355X's 288 GB hold level 0's 2.1 GB vectors many times over; the 8-GPU form of the same
+    problem is the driver's run).  4 levels (512^3 .. 64^3), otherwise the parameters of configs[2].  Size-independent properties, as for
+    256^3: convergence, monotone history, recurrence residual == true residual, projector and Galerkin identities on level 0."""
+    n, levels, tol = 512, 3, 1e-8
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n)
+    A = Sparse(N, ncol, rowptr, col, val)
+    del rowptr, col, val
+    dims = (n, n, n)
+    prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)),
+                   levels, None, None, null_vectors=np.ones((1, N), np.complex128))
+    M = MG(A, prm)
+    assert [M.level_info(l)["dim"] for l in range(4)] == [512 ** 3, 256 ** 3, 128 ** 3, 64 ** 3]
+    assert A.xr_fuse_kind() == 2                                 # plane-walk row map: 256 workgroups per band, 2 bands
+    rhs = Field(dims).fill_rhs(0)
+    x = Field(dims).set_zero()
+    outer = GCR(A, GCR_Param(0, 5, 200, tol, False, None, M, flexible=True, check_every=1))
+    outer.solve(rhs, x)
+    assert outer.last_converged and outer.last_iterations <= 40, outer.last_iterations
+    h = outer.last_history
+    assert h[-1] <= tol and (np.diff(h) < 0).all()
+    true_rel = (rhs - A(x)).norm() / rhs.norm()
+    assert true_rel <= 1.5e-8 and abs(true_rel - h[-1]) <= 1e-6 * h[-1]
+    v = Field(dims).fill_rhs(3)
+    Rv = M.restrict(v)
+    PRv = M.expand(Rv)
+    RPRv = M.restrict(PRv)
+    assert (RPRv - Rv).norm() <= 1e-13 * Rv.norm()
+    w = Field((M.level_info(1)["dim"],)).fill_rhs(4)
+    lhs = M.restrict(A(M.expand(w)))
+    rhs_c = M.level_operator(1)(w)
+    assert (lhs - rhs_c).norm() <= 1e-12 * rhs_c.norm()
+    # ... and the unpreconditioned solver's windowed kernels at this size: the same 10 steps with the far neighbours gathered are a
+    # matter of a child process (tools/gcr_size_sweep.py); here: 10 steps reduce the residual monotonically
+    g = GCR(A, GCR_Param(0, 5, 10, 1e-30, False))
+    x.set_zero()
+    g.solve(rhs, x)
+    assert (np.diff(g.last_history) < 0).all() and abs((rhs - A(x)).norm() / rhs.norm() - g.last_history[-1]) <= 1e-9 * g.last_history[-1]
+
+
 def test_arnoldi_vs_reference(sample_matrix_path):
     """Arnoldi::solve (src/MG.h:90-122) against the real reference (tests/golden/arnoldi_4x4.npz, oracle/ref_harness.cpp
     `arnoldi`): 4x4 sample, k = 0.1, GCR_Param(0,10,10,1e-8), start = the reference's init_rand(9).  Vector 0 with the
