@@ -264,6 +264,11 @@ typedef struct orc_op {
     int owns;
     /* order 3: this operator's own device layout (orc_op_set_layout; the levels of a multigrid hierarchy are stored differently) */
     int has_layout, lay_w, lay_l, lay_cap;
+    /* order 3: the row map of the solver kernels that work on THIS operator (orc_op_set_rowmap: the levels of a hierarchy have
+     * different sizes and reaches, hence different maps) — overrides orc_set_device_model's band / per / init_banded,
+     * orc_set_device_plane and orc_set_device_xr_banded for the duration of a GCR solve on it */
+    int has_rowmap, rm_per, rm_init_banded, rm_xr_banded;
+    int64_t rm_band, rm_plane;
 } orc_op;
 
 void orc_op_apply(orc_op *op, const cplx *x, cplx *y);
@@ -386,6 +391,9 @@ void orc_op_residual(orc_op *op, const cplx *x, const cplx *b, cplx *r) {
     orc_op_apply(op, x, r);
     for (int64_t i = 0; i < n; i++) r[i] = b[i] - r[i];
 }
+void orc_op_set_rowmap(orc_op *op, int64_t band, int per, int64_t plane, int init_banded, int xr_banded) {
+    op->has_rowmap = 1; op->rm_band = band; op->rm_per = per; op->rm_plane = plane; op->rm_init_banded = init_banded; op->rm_xr_banded = xr_banded;
+}
 void orc_op_set_layout(orc_op *op, int ell_width, int ell_lanes, int tail_cap) {
     op->has_layout = 1; op->lay_w = ell_width; op->lay_l = ell_lanes < 1 ? 1 : ell_lanes; op->lay_cap = tail_cap;
 }
@@ -467,8 +475,21 @@ static cplx *vnew(int64_t n) { return (cplx *)malloc(sizeof(cplx) * (size_t)n); 
  * hist[0] = step-0 entry, hist[k] = sqrt(|r|^2)/|b| printed at step k (src/GCR.h:214,271-272);
  * at most hist_cap entries are stored.  *converged = 1 unless global_count == max_iter
  * (src/GCR.h:294-298). */
+static int gcr_solve_impl(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, double *hist, int hist_cap, int *converged);
 int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, double *hist, int hist_cap,
                   int *converged) {
+    const orc_op *b0 = A->kind == OP_DIRAC && A->D ? A->D : A;
+    if (!b0->has_rowmap) return gcr_solve_impl(A, gp, rhs, x, hist, hist_cap, converged);
+    /* this operator's own row map (a level of a hierarchy): in force for this solve, nested solves set their own */
+    const int64_t band = g_dev_band, plane = g_dev_plane;
+    const int per = g_dev_per, ib = g_dev_init_banded, xb = g_dev_xr_banded;
+    g_dev_band = b0->rm_band; g_dev_per = b0->rm_per; g_dev_plane = b0->rm_plane; g_dev_init_banded = b0->rm_init_banded; g_dev_xr_banded = b0->rm_xr_banded;
+    const int rc = gcr_solve_impl(A, gp, rhs, x, hist, hist_cap, converged);
+    g_dev_band = band; g_dev_per = per; g_dev_plane = plane; g_dev_init_banded = ib; g_dev_xr_banded = xb;
+    return rc;
+}
+static int gcr_solve_impl(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, double *hist, int hist_cap,
+                          int *converged) {
     int64_t n = A->dim;
     /* mode selection, src/GCR.h:171-185 */
     int truncation, restart, storage = gp->max_iter;
@@ -522,7 +543,9 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         for (int a = 0; a < LEAN_MAX; a++) { lt[a] = 0.0; lcx[a] = 0.0; for (int b2 = 0; b2 < LEAN_MAX; b2++) lT[a][b2] = 0.0; }
     }
     /* order 3: step 0's sums come out of the kernel that embeds the apply when the device fuses the start */
-    g_dev_banded_now = g_dev_init_banded;
+    /* (only solves without preconditioner hooks start in that kernel: csrc/gcr.hip fuse_start / fuse_init) */
+    const int init_banded = g_dev_init_banded && !gp->right_precond && !gp->left_precond;
+    g_dev_banded_now = init_banded;
     double bnorm2 = orc_sqnorm(n, rhs);
     double bnorm = sqrt(bnorm2);
     if (hist && hist_cap > 0) hist[0] = sqrt(orc_sqnorm(n, r)) / bnorm;
@@ -540,7 +563,7 @@ int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, 
         iter_count++;
         /* alpha = r.dot(Ap) / Ap.dot(Ap)   (src/GCR.h:230) */
         cplx num, den;
-        g_dev_banded_now = first_step ? g_dev_init_banded : 0;
+        g_dev_banded_now = first_step ? init_banded : 0;
         orc_dot(n, r, Ap, &num);
         orc_dot(n, Ap, Ap, &den);
         g_dev_banded_now = 0;

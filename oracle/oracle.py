@@ -76,6 +76,7 @@ def lib():
         L.orc_set_device_model.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_device_ranks.argtypes = [C.c_int, _i64p]
         L.orc_op_set_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_op_set_rowmap.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int]
         L.orc_set_device_lean.argtypes = [C.c_int, C.c_int]
         L.orc_set_device_xr_banded.argtypes = [C.c_int]
         L.orc_set_device_plane.argtypes = [C.c_int64]
@@ -167,6 +168,12 @@ class Op:
     def set_layout(self, ell_width, ell_lanes, tail_cap):
         """This operator's own device layout for summation order 3 (the levels of a multigrid hierarchy are stored differently)."""
         lib().orc_op_set_layout(self.h, int(ell_width), int(ell_lanes), int(tail_cap))
+        return self
+
+    def set_rowmap(self, band, per, plane=0, init_banded=False, xr_banded=False):
+        """This operator's own row map for summation order 3 — what `device_order(band=, per=, plane=, init_banded=, xr_banded=)` sets
+        globally, for the GCR solves ON this operator only (the levels of a multigrid hierarchy)."""
+        lib().orc_op_set_rowmap(self.h, int(band), int(per), int(plane), int(bool(init_banded)), int(bool(xr_banded)))
         return self
 
     def __call__(self, x):

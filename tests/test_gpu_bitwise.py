@@ -68,7 +68,7 @@ def device_model(A, N, took_small):
     return orc.device_order(blocks=0, band=band, per=per, init_banded=band > 0,
                             ell_width=lay["ell_width"] if lanes else -1, ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"],
                             lean=True,      # (restart mode: x from the lean cycles' coefficient tables, like the device)
-                            xr_banded=band > 0 and A.xr_fuse_kind() == 2,   # residual update inside the windowed apply kernel
+                            xr_banded=band > 0 and A.xr_fuse_kind() in (1, 2),   # residual update inside the apply kernel: |r|^2 over ITS row map
                             plane=orc.row_map_plane(N, lay["reach"]))
 
 
