@@ -138,6 +138,14 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
     if (CARRY) {
         c_prev = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
         c_cur = gather_x(x, m.xh, m.n_own, clampj(i));
+        // CARRY writes a trip's window ONE TRIP AHEAD (the first one here): the next trip's halo is requested together with the next
+        // trip's own entry, i.e. while the workgroup that owns those rows requests them too — one fetch from memory for both (requested a
+        // trip later the lines had left the L2 again: PMC 1.08-1.23x the model's bytes at 256^3, 1.03-1.06x this way)
+        win[H + threadIdx.x] = c_cur;
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            win[t < H ? t : RED_THREADS + t] = gather_x(x, m.xh, m.n_own, clampj(t < H ? i - threadIdx.x - H + t : i - threadIdx.x + RED_THREADS + (t - H)));
+        }
     }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {   // uniform trip count per workgroup
         const bool live = row_ok && i < end;
@@ -153,7 +161,8 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         int hidx = -1;
         if ((int)threadIdx.x < 2 * H) {
             const int t = (int)threadIdx.x;
-            halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + RED_THREADS + (t - H)));
+            const int64_t hb = CARRY ? base + stride : base;   // CARRY: the NEXT trip's halo
+            halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? hb - H + t : hb + RED_THREADS + (t - H)));
             hidx = t < H ? t : RED_THREADS + t;
         }
         cplx b[NDT];
@@ -163,9 +172,16 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= 5 ? 8 : 4)) step_apply_ti
         }
         __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before anything is waited for
         cplx *sx = win + buf * wlen;
-        sx[H + threadIdx.x] = own;
-        if (hidx >= 0) sx[hidx] = halo;
+        if (!CARRY) {
+            sx[H + threadIdx.x] = own;
+            if (hidx >= 0) sx[hidx] = halo;
+        }
         __syncthreads();
+        if (CARRY) {   // the next trip's window, into the buffer the previous trip read (every thread is past that)
+            cplx *sn = win + (buf ^ 1) * wlen;
+            sn[H + threadIdx.x] = far6;
+            if (hidx >= 0) sn[hidx] = halo;
+        }
         cplx sum = make_double2(0., 0.);
         if constexpr (RARE) sum = sten_pre_sum<(CARRY ? 1 : -1)>(m, i, pl[NC], lane, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
 #pragma unroll
@@ -354,9 +370,14 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
     double v[6] = {0., 0., 0., 0., 0., 0.};
     int buf = 0;
     cplx c_prev = make_double2(0., 0.), c_cur = c_prev;
-    if (CARRY) {   // (step_apply_tile_kernel)
+    if (CARRY) {   // (step_apply_tile_kernel: far neighbours carried, windows written one trip ahead)
         c_prev = gather_x(x, m.xh, m.n_own, clampj(i + m.sten_off[0]));
         c_cur = gather_x(x, m.xh, m.n_own, clampj(i));
+        win[H + threadIdx.x] = c_cur;
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            win[t < H ? t : RED_THREADS + t] = gather_x(x, m.xh, m.n_own, clampj(t < H ? i - threadIdx.x - H + t : i - threadIdx.x + RED_THREADS + (t - H)));
+        }
     }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
         const bool live = row_ok && i < end;
@@ -372,14 +393,22 @@ __global__ void __launch_bounds__(RED_THREADS, 8) init_apply_tile_kernel(RowMat 
         int hidx = -1;
         if ((int)threadIdx.x < 2 * H) {
             const int t = (int)threadIdx.x;
-            halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? base - H + t : base + RED_THREADS + (t - H)));
+            const int64_t hb = CARRY ? base + stride : base;   // CARRY: the NEXT trip's halo
+            halo = gather_x(x, m.xh, m.n_own, clampj(t < H ? hb - H + t : hb + RED_THREADS + (t - H)));
             hidx = t < H ? t : RED_THREADS + t;
         }
         __builtin_amdgcn_sched_barrier(0);
         cplx *sx = win + buf * wlen;
-        sx[H + threadIdx.x] = own;
-        if (hidx >= 0) sx[hidx] = halo;
+        if (!CARRY) {
+            sx[H + threadIdx.x] = own;
+            if (hidx >= 0) sx[hidx] = halo;
+        }
         __syncthreads();
+        if (CARRY) {   // the next trip's window, into the buffer the previous trip read (every thread is past that)
+            cplx *sn = win + (buf ^ 1) * wlen;
+            sn[H + threadIdx.x] = far6;
+            if (hidx >= 0) sn[hidx] = halo;
+        }
         cplx sum = make_double2(0., 0.);
         if constexpr (RARE) sum = sten_pre_sum<(CARRY ? 1 : -1)>(m, i, pl[NC], lane, [&](int32_t j) -> cplx { return gather_x(x, m.xh, m.n_own, j); });
 #pragma unroll
@@ -450,6 +479,13 @@ __global__ void __launch_bounds__(RED_THREADS, 8) sten_apply_carry_kernel(RowMat
     const int lane = (int)(threadIdx.x & 63);
     int buf = 0;
     cplx c_prev = x[clampj(i + m.sten_off[0])], c_cur = x[clampj(i)];
+    {   // windows are written one trip ahead (step_apply_tile_kernel CARRY): the first one here
+        win[H + threadIdx.x] = c_cur;
+        if ((int)threadIdx.x < 2 * H) {
+            const int t = (int)threadIdx.x;
+            win[t < H ? t : RED_THREADS + t] = x[clampj(t < H ? i - threadIdx.x - H + t : i - threadIdx.x + RED_THREADS + (t - H))];
+        }
+    }
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {
         const bool live = row_ok && i < end;
         const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(i >> 6));
@@ -464,14 +500,17 @@ __global__ void __launch_bounds__(RED_THREADS, 8) sten_apply_carry_kernel(RowMat
         int hidx = -1;
         if ((int)threadIdx.x < 2 * H) {
             const int t = (int)threadIdx.x;
-            halo = x[clampj(t < H ? base - H + t : base + RED_THREADS + (t - H))];
+            halo = x[clampj(t < H ? base + stride - H + t : base + stride + RED_THREADS + (t - H))];   // the NEXT trip's halo
             hidx = t < H ? t : RED_THREADS + t;
         }
         __builtin_amdgcn_sched_barrier(0);
         cplx *sx = win + buf * wlen;
-        sx[H + threadIdx.x] = c_cur;
-        if (hidx >= 0) sx[hidx] = halo;
         __syncthreads();
+        {
+            cplx *sn = win + (buf ^ 1) * wlen;
+            sn[H + threadIdx.x] = far6;
+            if (hidx >= 0) sn[hidx] = halo;
+        }
         cplx sum = make_double2(0., 0.);
 #pragma unroll
         for (int c = 0; c < NC; c++) {

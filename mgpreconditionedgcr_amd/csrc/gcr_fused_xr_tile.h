@@ -5,7 +5,7 @@
 #define XR_TILE_APC_NDT 5    // up to this many: the newest direction's A p stays in registers for its dot product (APC)
 #endif
 #ifndef XR_TILE_OCC8_NDT
-#define XR_TILE_OCC8_NDT 4   // up to this many direction streams: 64 registers, two workgroups per CU (5 spill there: 484 us at 256^3 against 410 with one workgroup per CU and 81 registers)
+#define XR_TILE_OCC8_NDT 2   // up to this many direction streams: 64 registers, two workgroups per CU (more spill there — 3, 13 registers at 3, 4 streams, whose scratch traffic PMC shows as 1.2-1.3x the model bytes; one workgroup per CU with 88 registers is faster: 288 against 293 us per iteration at 256^3)
 #endif
 // Bandwidth regime with the LDS window AND a row map whose step is the reach of the far slots (step_apply_tile_kernel's CARRY: a
 // 256 x 256 x Z grid): the residual update INSIDE the windowed apply.  What made that lose at 128^3 — r' = r - alpha Ap formed again
@@ -58,6 +58,21 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= XR_TILE_OCC8_NDT ? 8 : 4)
     for (int j = 0; j < 2 * NDT + 1; j++) v[j] = 0.;
     cplx prev = upd(p_r, p_a), cur = upd(c_r, c_a);   // r' of rows i - step and i
     cplx cur_a = c_a;                                 // APC: Ap of row i
+    // The window of a trip is written ONE TRIP AHEAD (the first one here): a trip requests the next trip's own entry — its + step
+    // neighbour — and the next trip's halo together, so a halo line is asked for while the workgroup that owns it asks for it too
+    // (one fetch from memory for both; requested a trip later it had left the L2 again: PMC 1.15-1.23x the model's bytes, now 1.0x)
+    const int hidx = (int)threadIdx.x < 2 * H ? ((int)threadIdx.x < H ? (int)threadIdx.x : RED_THREADS + (int)threadIdx.x) : -1;
+    auto halo_row = [&](int64_t base) -> int32_t {
+        const int t = (int)threadIdx.x;
+        return clampj(t < H ? base - H + t : base + RED_THREADS + (t - H));
+    };
+    {
+        win[H + threadIdx.x] = cur;
+        if (hidx >= 0) {
+            const int32_t jh = halo_row(i - threadIdx.x);
+            win[hidx] = upd(r_in[jh], ap[jh]);
+        }
+    }
     int buf = 0;
     for (int64_t base = i - threadIdx.x; base < end; base += stride, i += stride, buf ^= 1) {   // uniform trip count per workgroup
         const bool live = row_ok && i < end;
@@ -69,24 +84,24 @@ __global__ void __launch_bounds__(RED_THREADS, (NDT <= XR_TILE_OCC8_NDT ? 8 : 4)
         const int32_t jn = clampj(i + stride);   // the + step neighbour now, this thread's own row next trip
         const cplx n_r = r_in[jn], n_a = ap[jn];
         cplx hr = make_double2(0., 0.), ha = hr;
-        int hidx = -1;
-        if ((int)threadIdx.x < 2 * H) {
-            const int t = (int)threadIdx.x;
-            const int32_t jh = clampj(t < H ? base - H + t : base + RED_THREADS + (t - H));
+        if (hidx >= 0) {
+            const int32_t jh = halo_row(base + stride);
             hr = r_in[jh];
             ha = ap[jh];
-            hidx = t < H ? t : RED_THREADS + t;
         }
         __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before anything is waited for
-        cplx *sx = win + buf * wlen;
-        sx[H + threadIdx.x] = cur;
         if (live) {
             r_out[i] = cur;
             v[2 * NDT] += cur.x * cur.x + cur.y * cur.y;
         }
-        if (hidx >= 0) sx[hidx] = upd(hr, ha);
+        const cplx *sx = win + buf * wlen;
+        __syncthreads();   // this trip's window (written during the previous trip) is complete; the other buffer is free
         const cplx next = upd(n_r, n_a);
-        __syncthreads();
+        {
+            cplx *sn = win + (buf ^ 1) * wlen;
+            sn[H + threadIdx.x] = next;
+            if (hidx >= 0) sn[hidx] = upd(hr, ha);
+        }
         cplx sum = make_double2(0., 0.);
 #pragma unroll
         for (int c = 0; c < NC; c++) {

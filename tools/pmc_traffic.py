@@ -40,7 +40,7 @@ def load(d, counter):
 def phase_of(name):
     if name.startswith("xr_update_kernel"):
         return "xr"
-    if name.startswith(("step_apply_kernel", "step_build_kernel", "multidot_kernel")):   # (step_build: apply + dots + build in one launch)
+    if name.startswith(("step_apply_kernel", "step_apply_tile_kernel", "step_apply_xr", "step_build_kernel", "multidot_kernel")):   # (step_build: apply + dots + build in one launch)
         return "apply_dots"
     if name.startswith(("pat_spmv", "ell_spmv", "csr_tail", "sten_spmv")):
         return "spmv"   # stand-alone applies (set-up, bench.py's replay / cold-cache loops)

@@ -10,7 +10,21 @@ import re
 import sys
 
 path = sys.argv[1]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+n = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 128
+# --pmc <fetch dir> <write dir>: two more columns — HBM-side bytes per dispatch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+# of the same command ((2 x FETCH + WRITE) x 1024: gfx950 correction, MI355X_MICROARCH.md) and their ratio to the model
+pmc = None
+if "--pmc" in sys.argv:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.pmc_traffic import load
+    k = sys.argv.index("--pmc")
+    fe, wr = load(sys.argv[k + 1], "FETCH_SIZE"), load(sys.argv[k + 2], "WRITE_SIZE")
+    pmc = {}
+    for name in set(fe) | set(wr):
+        nf, sf = fe.get(name, [0, 0.0])
+        nw, sw = wr.get(name, [0, 0.0])
+        pmc[name] = (2.0 * (sf / nf if nf else 0.0) + (sw / nw if nw else 0.0)) * 1024.0
 N = n ** 3
 nnz = 7 * N - 6 * n * n
 V = 16 * N
@@ -19,8 +33,8 @@ B_pat = ((N + 63) // 64) * 8 * 8 + 7 * 20          # stencil view: 8 presence wo
 B_spmv = B_pat + 2 * V
 R = 5
 rows = list(csv.DictReader(open(path)))
-print("| kernel | calls | avg µs | bytes / launch (model) | GB/s | of 8 TB/s |")
-print("|---|---|---|---|---|---|")
+print("| kernel | calls | avg µs | bytes / launch (model) | GB/s | of 8 TB/s |" + (" HBM-side bytes (PMC) | PMC / model |" if pmc else ""))
+print("|---|---|---|---|---|---|" + ("---|---|" if pmc else ""))
 for r in rows:
     name = r["Name"].split("(")[0].replace("void mgcr::", "").replace("mgcr::", "")
     us = float(r["AverageNs"]) / 1e3
@@ -68,4 +82,8 @@ for r in rows:
     if b is None or int(r["Calls"]) < 4:
         continue
     gbs = b / us / 1e3
-    print("| `%s` | %s | %.1f | %.1f MB | %.0f | %.2f |" % (name, r["Calls"], us, b / 1e6, gbs, gbs / 8000))
+    extra = ""
+    if pmc:
+        t = pmc.get(name)
+        extra = " %.1f MB | %.2f |" % (t / 1e6, t / b) if t else " | |"
+    print("| `%s` | %s | %.1f | %.1f MB | %.0f | %.2f |%s" % (name, r["Calls"], us, b / 1e6, gbs, gbs / 8000, extra))
