@@ -126,9 +126,22 @@ def end_process_group(p):
 
 def worker_command(argv, port, mode_env, base_env=None):
     env = dict(os.environ if base_env is None else base_env)
+    # Under torch.distributed.run the supervisor's environment says TORCHELASTIC_USE_AGENT_STORE=True: init_process_group(env://) of a
+    # process that inherits it does not open a store of its own on rank 0 but waits for the launcher agent's at MASTER_PORT — and the
+    # workers rendezvous on a FRESH port, where nobody listens: they would hang until the attempt's time limit.  The workers are not the
+    # agent's processes: they get none of its variables (and rendezvous over an explicit tcp:// address besides, worker_init_method).
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+            env.pop(k)
     env.update(mode_env)
     env.update(MGCR_BENCH_ROLE="worker", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
     return [sys.executable, os.path.abspath(__file__)] + list(argv), env
+
+
+def worker_init_method():
+    """The workers' rendezvous: rank 0 of the workers hosts the store at the port its supervisor picked — stated explicitly, so that
+    nothing inherited from a launcher's environment can redirect it."""
+    return "tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ["MASTER_PORT"])
 
 
 def last_json_line(text):
@@ -564,7 +577,7 @@ def run_headline(args, with_cpu=True):
         # control plane (barriers, id broadcast, max-reduce of the timing) over gloo; the data path
         # (halo exchange + dot-product all-reduces) is inside libmgcr_hip.so
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=worker_init_method(), rank=rank, world_size=world)
         from mgpreconditionedgcr_amd import Comm, DistSparse
         if host_transport:
             comm = Comm.host(dist)
@@ -1325,7 +1338,7 @@ def dist_context():
     host_transport = os.environ.get("MGCR_BENCH_TRANSPORT", "rccl") == "host" or one_gpu
     torch.cuda.set_device(0 if one_gpu else local_rank)
     mg.init(0 if one_gpu else local_rank)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=worker_init_method(), rank=rank, world_size=world)
     if host_transport:
         comm = Comm.host(dist)
     else:

@@ -145,3 +145,71 @@ def test_launcher_ends_the_workers_of_ranks_it_kills(tmp_path, monkeypatch):
         time.sleep(0.1)
     else:
         raise AssertionError("the worker outlived its supervisor")
+
+
+def test_worker_environment_drops_the_launcher_agents_variables():
+    """Under torch.distributed.run the rank processes (bench.py's supervisors) carry TORCHELASTIC_USE_AGENT_STORE=True: a worker that
+    inherited it would wait for the agent's store at its own fresh rendezvous port — where nobody listens — until the attempt's time
+    limit (seen on the GPU box: the default attempt of `torchrun ... bench.py --gpus 2` hung for its 420 s).  The workers get none of
+    the agent's variables and rendezvous over an explicit tcp:// address."""
+    import bench
+    base = dict(PATH="/usr/bin", RANK="1", WORLD_SIZE="2", LOCAL_RANK="1", MASTER_ADDR="10.0.0.1", MASTER_PORT="29511",
+                TORCHELASTIC_USE_AGENT_STORE="True", TORCHELASTIC_RUN_ID="none", TORCHELASTIC_RESTART_COUNT="0", GROUP_RANK="0", ROLE_RANK="1")
+    cmd, env = bench.worker_command(["--gpus", "2"], 40123, {"MGCR_PEER_ALLREDUCE": "0"}, base_env=base)
+    assert not any(k.startswith("TORCHELASTIC_") for k in env) and "GROUP_RANK" not in env and "ROLE_RANK" not in env
+    assert env["MASTER_PORT"] == "40123" and env["MASTER_ADDR"] == "127.0.0.1" and env["RANK"] == "1" and env["WORLD_SIZE"] == "2"
+    assert env["MGCR_BENCH_ROLE"] == "worker" and env["MGCR_PEER_ALLREDUCE"] == "0"
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="40123")
+        assert bench.worker_init_method() == "tcp://127.0.0.1:40123"
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_workers_rendezvous_under_torch_distributed_run(tmp_path):
+    """The same on CPU, end to end: two rank processes started by torch.distributed.run each start a child the way bench.py's
+    supervisors start their workers (worker_command: fresh port, the agent's variables dropped); the children meet over gloo with
+    bench.worker_init_method() and all-reduce a number — within seconds, not at a time limit."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import bench
+        dist.init_process_group("gloo", init_method=bench.worker_init_method(), rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+        t = torch.tensor([float(os.environ["RANK"]) + 1.0])
+        dist.all_reduce(t)
+        print("child", os.environ["RANK"], float(t[0]), flush=True)
+        dist.destroy_process_group()
+    """ % root))
+    parent = tmp_path / "parent.py"
+    parent.write_text(textwrap.dedent("""
+        import os, subprocess, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import bench
+        rank = int(os.environ["RANK"])
+        dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+        port = torch.tensor([bench.free_port() if rank == 0 else 0], dtype=torch.int64)
+        dist.broadcast(port, src=0)
+        cmd, env = bench.worker_command([], int(port[0]), {})
+        p = subprocess.run([sys.executable, %r], env=env, capture_output=True, text=True, timeout=120)
+        print("parent", rank, p.returncode, p.stdout.strip(), p.stderr[-300:] if p.returncode else "", flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(p.returncode)
+    """ % (root, str(child))))
+    port = __import__("bench").free_port()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(parent)], capture_output=True, text=True, timeout=240, cwd=root)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "child 0 3.0" in p.stdout and "child 1 3.0" in p.stdout, p.stdout
