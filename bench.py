@@ -134,6 +134,7 @@ def worker_command(argv, port, mode_env, base_env=None):
         if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
             env.pop(k)
     env.update(mode_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (hipIpc mailboxes, RCCL) — also when a launcher other than ours started the ranks
     env.update(MGCR_BENCH_ROLE="worker", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
     return [sys.executable, os.path.abspath(__file__)] + list(argv), env
 
