@@ -62,7 +62,7 @@ def run_workers(mode, world, outdir, timeout=300):
     return [np.load(os.path.join(str(outdir), "rank%d.npy" % r), allow_pickle=True).item() for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 6])
 def test_partition_plan_gloo(tmp_path, world):
     from tests.dist_worker import problem
     from mgpreconditionedgcr_amd import problems
@@ -81,4 +81,4 @@ def test_partition_plan_gloo(tmp_path, world):
                 assert res[r][kind]["n_halo"] == 36 * len(nb)     # one 6x6 plane per neighbour
                 ib, ie = res[r][kind]["interior"]
                 planes = 6 // world
-                assert (ie - ib) == 36 * (planes - len(nb))       # all but the first/last plane
+                assert (ie - ib) == 36 * max(planes - len(nb), 0)   # all but the first/last plane (6 ranks: one plane each, every row of a middle rank touches a halo column)
