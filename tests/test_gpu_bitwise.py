@@ -364,6 +364,24 @@ def test_plane_walk_row_map_bit_for_bit(n, nz):
     assert_bitwise("p%dx%dx%d_restart5_7steps" % (n, n, nz), "multi-kernel (plane walk, carried window)", gcr, ref, None, x)
 
 
+@pytest.mark.parametrize("nz,ny,nx", [(16, 256, 256), (24, 200, 200)])
+def test_shifted_operator_on_a_slab_bit_for_bit(nz, ny, nx):
+    """DiracOp = 1 - k D with a complex k on the slabs of the carried-window kernels (D = the 7-point operator: real stencil
+    coefficients, the shift is the kernels' epilogue y = r' - k (D r')): fused update + apply, stand-alone apply, 7 steps of GCR(5)."""
+    k = 0.05 + 0.02j
+    N, ncol, rowptr, col, val = problems.poisson3d_box_csr(nz, ny, nx)
+    b = problems.rhs_grid(N, 0)
+    D = Sparse(N, ncol, rowptr, col, val)
+    A = DiracOp(D, k)
+    assert A.xr_fuse_kind() == 2
+    Ao = orc.dirac(orc.csr(N, ncol, rowptr, col, val), k)
+    with device_model(A, N, False):
+        assert np.array_equal(A(Field((nz, ny, nx), b)).to_numpy().ravel(), Ao(b))
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 7, 1e-13, False), orc.gcr_param(restart=5, max_iter=7, tol=1e-13), b, dims=(nz, ny, nx))
+    assert not small
+    assert_bitwise("shifted_p%dx%dx%d_restart5_7steps" % (nz, ny, nx), "multi-kernel (carried window)", gcr, ref, None, x)
+
+
 def test_carried_window_apply_same_bits():
     """The stand-alone apply (A x and the shifted x - k A x) of the 256 x 256 x 16 slab with and without the carried-window kernel
     (gcr_fused.hip sten_apply_carry_kernel; MGCR_APPLY_CARRY=0 takes spmv.hip's sten_spmv_tile): identical results."""
