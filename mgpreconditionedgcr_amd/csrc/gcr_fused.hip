@@ -780,7 +780,10 @@ int csr_step_apply_xr(const CsrDev &A, const cplx *r_in, const cplx *ap, cplx *r
                                              den_slot, slot, lc)
     if (tile_regime(A)) {
         const size_t win = 2 * (size_t)(RED_THREADS + 2 * A.sten_halo_f) * sizeof(cplx);
-        MGCR_CHECK(!A.sten_rare && tile_carry(A, rm) && d.v[nd - 1] == ap, MGCR_ERR_INVALID, "csr_step_apply_xr: not the windowed form's case");
+        // (APC instantiations take the newest direction's A p from the update's operands: it must be the last of the dot-product streams —
+        // it is, in a lean cycle of up to FND directions; beyond that the kernel requests its streams like any other)
+        MGCR_CHECK(!A.sten_rare && tile_carry(A, rm) && (nd > XR_TILE_APC_NDT || d.v[nd - 1] == ap), MGCR_ERR_INVALID,
+                   "csr_step_apply_xr: not the windowed form's case");
         launch_xr_tile_nd<7, false>(nd, grid, win, m, r_in, ap, r_out, y, d, A.nrow, g, rm, parts, partsR, st, it, partsA, nblkA, strideA,
                                          den_slot, slot, lc);
     } else if (csr_stencil_active(A)) {

@@ -230,7 +230,7 @@ def test_poisson192_banded_row_map_bit_for_bit():
     assert_bitwise("p192_6steps", "multi-kernel (banded)", gcr, ref, None, x)
 
 
-@pytest.mark.parametrize("restart,steps,nz", [(5, 7, 16), (10, 12, 16), (3, 3, 16), (5, 7, 21)])
+@pytest.mark.parametrize("restart,steps,nz", [(5, 7, 16), (10, 12, 16), (3, 3, 16), (5, 7, 21), (12, 14, 16), (16, 18, 16)])
 def test_poisson_256x256_slab_carried_window_bit_for_bit(restart, steps, nz):
     """16 planes of a 256 x 256 grid (1 M rows): the far neighbours of a row are exactly one step of the banded row map away, so the
     windowed kernels carry them in registers from trip to trip and the residual update runs inside the apply kernel
@@ -380,6 +380,19 @@ def test_shifted_operator_on_a_slab_bit_for_bit(nz, ny, nx):
     gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(0, 5, 7, 1e-13, False), orc.gcr_param(restart=5, max_iter=7, tol=1e-13), b, dims=(nz, ny, nx))
     assert not small
     assert_bitwise("shifted_p%dx%dx%d_restart5_7steps" % (nz, ny, nx), "multi-kernel (carried window)", gcr, ref, None, x)
+
+
+@pytest.mark.parametrize("kw,okw", [(dict(trunc=6, max_it=10), dict(truncation=6, max_iter=10)), (dict(max_it=9), dict(max_iter=9))])
+def test_truncated_and_full_gcr_on_a_slab_bit_for_bit(kw, okw):
+    """The classic (not lean) kernels — truncated and full GCR — on the 256 x 256 x 16 slab: carried-window apply + dots, separate update."""
+    n, nz = 256, 16
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+    b = problems.rhs_grid(N, 0)
+    A = Sparse(N, ncol, rowptr, col, val)
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    gcr, x, ref, small = solve_both(A, Ao, N, GCR_Param(tau=1e-13, verb=False, **kw), orc.gcr_param(tol=1e-13, **okw), b, dims=(nz, n, n))
+    assert not small
+    assert_bitwise("p256x256x16_%s" % "_".join("%s%d" % kv for kv in sorted(okw.items())), "multi-kernel (banded, carried window)", gcr, ref, None, x)
 
 
 def test_carried_window_apply_same_bits():
