@@ -543,8 +543,11 @@ static int gcr_solve_impl(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, c
         for (int a = 0; a < LEAN_MAX; a++) { lt[a] = 0.0; lcx[a] = 0.0; for (int b2 = 0; b2 < LEAN_MAX; b2++) lT[a][b2] = 0.0; }
     }
     /* order 3: step 0's sums come out of the kernel that embeds the apply when the device fuses the start */
-    /* (only solves without preconditioner hooks start in that kernel: csrc/gcr.hip fuse_start / fuse_init) */
-    const int init_banded = g_dev_init_banded && !gp->right_precond && !gp->left_precond;
+    /* (csrc/gcr.hip: fuse_start — no x0, no preconditioner hooks — or fuse_init — a lean solve shorter than its restart cycle, whose first
+     * direction IS its start residual, x0 or not; every other start takes the plain-order kernels) */
+    const int dev_lean_like = g_dev_lean && gp->restart != 0 && storage_dev <= LEAN_MAX && !gp->left_precond && !gp->right_precond;
+    const int short_lean = dev_lean_like && gp->max_iter >= 1 && gp->max_iter < gp->restart;
+    const int init_banded = g_dev_init_banded && !gp->right_precond && !gp->left_precond && (!gp->use_x0 || short_lean);
     g_dev_banded_now = init_banded;
     double bnorm2 = orc_sqnorm(n, rhs);
     double bnorm = sqrt(bnorm2);

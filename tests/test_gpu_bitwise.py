@@ -468,6 +468,40 @@ def test_random_parameters_bit_for_bit(seed):
     assert np.array_equal(xg, ref[0]), "%s: x differs in %d entries (max %.3e)" % (what, int((xg != ref[0]).sum()), np.abs(xg - ref[0]).max())
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_parameters_on_slabs_bit_for_bit(seed):
+    """The same sweep of solver parameters (modes, restart / truncation lengths up to 17, shifts, x0, tolerances that end a solve in the
+    middle of a cycle) on slabs that take the plane-walk row maps, the carried window and the fused residual update."""
+    rng = np.random.default_rng(9000 + seed)
+    nz, ny, nx = [(16, 256, 256), (24, 200, 200), (24, 192, 192), (10, 320, 320), (20, 256, 128)][seed % 5]
+    N, ncol, rowptr, col, val = problems.poisson3d_box_csr(nz, ny, nx)
+    mode = rng.choice(["restart", "truncation", "full"], p=[0.6, 0.25, 0.15])
+    kw = dict(max_iter=int(rng.choice([1, 2, 3, 7, 12])), tol=float(rng.choice([1e-30, 3e-2, 1e-1])))
+    if mode == "restart":
+        kw["restart"] = int(rng.integers(1, 18))
+    elif mode == "truncation":
+        kw["truncation"] = int(rng.integers(1, 13))
+    shift = complex(rng.uniform(0.02, 0.08), rng.uniform(-0.03, 0.03)) if rng.random() < 0.35 else None
+    use_x0 = bool(rng.random() < 0.3)
+    b = problems.rhs_grid(N, int(rng.integers(0, 50)))
+    x0 = problems.rhs_grid(N, 77) * 0.1 if use_x0 else None
+    Ao = orc.csr(N, ncol, rowptr, col, val)
+    A = Sparse(N, ncol, rowptr, col, val)
+    if shift is not None:
+        Ao, A = orc.dirac(Ao, shift), DiracOp(A, shift)
+    po = orc.gcr_param(use_x0=use_x0, **kw)
+    gp = GCR_Param(kw.get("truncation", 0), kw.get("restart", 0), kw["max_iter"], kw["tol"], False, use_x0=use_x0, check_every=int(rng.choice([0, 1, 3, 50])))
+    gcr, x, ref, small = solve_both(A, Ao, N, gp, po, b, x0, dims=(nz, ny, nx))
+    what = "%dx%dx%d %s shift=%s x0=%s" % (nz, ny, nx, kw, shift, use_x0)
+    h, ho = gcr.last_history, ref[1]
+    m = min(h.size, ho.size)
+    assert not small
+    assert np.array_equal(h[:m], ho[:m]), "%s: first differing step %d" % (what, int(np.argmax(h[:m] != ho[:m])))
+    assert gcr.last_iterations == ref[2] and gcr.last_converged == ref[3], what
+    xg = x.to_numpy().ravel()
+    assert np.array_equal(xg, ref[0]), "%s: x differs in %d entries (max %.3e)" % (what, int((xg != ref[0]).sum()), np.abs(xg - ref[0]).max())
+
+
 def test_dot_and_norm_bit_for_bit(sample_gold):
     """Field::dot / squarednorm (src/Fields.h:216-235) through mgcr_dot / mgcr_norm2: device order == the GPU."""
     for n, seed in ((3072, 1), (1000, 2), (70000, 3), (1 << 21, 4)):
