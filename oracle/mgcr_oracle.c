@@ -654,7 +654,7 @@ static int gcr_solve_impl(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, c
                 memcpy(LP[k], dir, sizeof(cplx) * (size_t)n);
             }
         }
-        g_dev_banded_now = lean && g_dev_xr_banded && !flex && global_count < gp->max_iter;
+        g_dev_banded_now = lean && g_dev_xr_banded && !flex && gp->restart > 1 && global_count < gp->max_iter;   /* (csrc/gcr.hip xr_fuse: cycles of at least two steps) */
         rn2 = orc_sqnorm(n, r);
         g_dev_banded_now = 0;
         if (hist && global_count < hist_cap) hist[global_count] = sqrt(rn2) / bnorm;
