@@ -352,18 +352,20 @@ def test_no_operator_applies_in_place():
         assert np.array_equal(f.to_numpy(), before)     # rejected before anything ran
 
 
-def test_vcycle_bit_for_bit_on_a_256x256_slab(tmp_path):
+@pytest.mark.parametrize("levels,sm_restart,sm_sweeps", [(2, 10, 2), (1, 10, 2), (2, 2, 3)])
+def test_vcycle_bit_for_bit_on_a_256x256_slab(tmp_path, levels, sm_restart, sm_sweeps):
     """The V-cycle's large-plane kernels against the oracle, bit for bit: level 0 = 16 planes of a 256 x 256 grid (1 M rows: banded row map,
     carried window, residual update inside the windowed apply, the post-smoother's last A p' not written, its |b|^2 taken from the
     pre-smoother's pass, prolongator stream skipped — csrc/gcr_fused.hip, gcr_fused_xr_tile.h, gcr.hip, mg.hip), level 1 = 8 x 128 x 128
     (131 072 rows: 8 bands of 16 workgroups, update inside the un-windowed apply), level 2 = 4 x 64 x 64 (the one-launch coarsest
     solve).  Every level's operator tells the oracle its own layout AND row map (oracle Op.set_rowmap).  One cycle, and 6 steps of the
-    MG-preconditioned flexible GCR(5)."""
+    MG-preconditioned flexible GCR(5).  Also with two levels only (the coarsest solve then works on the 131 072-row level), and with
+    smoothers of 3 sweeps of GCR(2) — a smoother that closes a restart cycle, i.e. not the "shorter than a cycle" shape the other two have."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "cycle.npz")
-    dims, levels = (16, 256, 256), 2
+    dims = (16, 256, 256)
     code = r"""
 import sys
 import numpy as np
@@ -374,7 +376,7 @@ dims, levels = %r, %d
 mg.init()
 N, ncol, rowptr, col, val = problems.poisson3d_box_csr(*dims)
 A = Sparse(N, ncol, rowptr, col, val)
-prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, 10, 2, 1e-30, False)), levels, None, None,
+prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, %d, %d, 1e-30, False)), levels, None, None,
                null_vectors=np.ones((1, N), np.complex128))
 M = MG(A, prm)
 b = problems.rhs_grid(N, 0)
@@ -389,7 +391,7 @@ for l in range(levels + 1):
     lay.append([d["ell_width"], d["lanes"], d["tail_chunk_cap"], d["tail_rows"], M.level_info(l)["dim"], d["reach"], op.xr_fuse_kind()])
 np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), resident=mg.stat("resident_solves"),
          hist=outer.last_history, x=xs.to_numpy().ravel(), its=outer.last_iterations)
-""" % (root, dims, levels, out)
+""" % (root, dims, levels, sm_restart, sm_sweeps, out)
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MGCR_SMALL_SOLVE_ROWS="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     got = np.load(out)
@@ -398,7 +400,7 @@ np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), re
     b = problems.rhs_grid(N, 0)
     Ao = orc.csr(N, ncol, rowptr, col, val)
     Mo = orc.MG(Ao, rowptr, col, val, dims, (1, 1, 1), 2, np.ones((1, N), np.complex128), levels + 1,
-                orc.gcr_param(restart=10, max_iter=2, tol=1e-30), orc.gcr_param(restart=10, max_iter=50, tol=1e-2))
+                orc.gcr_param(restart=sm_restart, max_iter=sm_sweeps, tol=1e-30), orc.gcr_param(restart=10, max_iter=50, tol=1e-2))
     keep, maps = [], []
     for l in range(levels + 1):
         w, lanes, cap, _, dim, reach, kind = (int(v) for v in got["lay"][l])
@@ -408,7 +410,7 @@ np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), re
         plane = orc.row_map_plane(dim, reach)
         keep.append(op.set_layout(w, lanes, cap).set_rowmap(band, per, plane, init_banded=band > 0, xr_banded=band > 0 and kind in (1, 2)))
         maps.append((dim, reach, band, per, plane, kind))
-    assert maps[0][2] > 0 and maps[1][2] > 0 and maps[2][2] == 0, maps                  # two banded levels, the coarsest plain
+    assert maps[0][2] > 0 and maps[1][2] > 0 and (levels == 1 or maps[2][2] == 0), maps   # two banded levels, the coarsest of three plain
     with orc.device_order(lean=True, recurrence_residual=True):
         yo = Mo(b)
         xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=6, tol=1e-30, right=Mo, flexible=True), b)
