@@ -146,8 +146,17 @@ def main():
         xs = Field((r1 - r0,)).set_zero()
         gcr = GCR(A, GCR_Param(0, 5, 12, 1e-30, False, check_every=4))
         gcr.solve(b, xs)
+        # ... and other shapes of solve through the same kernels: a cycle of 12 directions, truncated GCR on the shifted operator from x0 != 0
+        from mgpreconditionedgcr_amd import DiracOp
+        more = {}
+        for tag, op, prm, x0 in (("restart12", A, GCR_Param(0, 12, 14, 1e-30, False, check_every=5), None),
+                                 ("trunc4_shift_x0", DiracOp(A, 0.05 + 0.02j), GCR_Param(4, 0, 9, 1e-30, False, use_x0=True), problems.rhs_grid(N, 77)[r0:r1] * 0.1)):
+            xv = Field((r1 - r0,), x0) if x0 is not None else Field((r1 - r0,)).set_zero()
+            gg = GCR(op, prm)
+            gg.solve(b, xv)
+            more[tag] = dict(hist=gg.last_history.copy(), x=xv.to_numpy())
         results["slab"] = dict(y=y, hist=gcr.last_history, x=xs.to_numpy(), its=gcr.last_iterations, format=A.storage_format()[0],
-                               layout=A.ell_layout(), allreduce=comm.allreduce_kind, halo=A.halo_kind)
+                               layout=A.ell_layout(), allreduce=comm.allreduce_kind, halo=A.halo_kind, more=more)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), results, allow_pickle=True)
         dist.barrier()
         dist.destroy_process_group()

@@ -45,6 +45,10 @@ def test_distributed_slab_carried_window(tmp_path, monkeypatch, n, nz):
         assert res[r]["slab"]["format"] == 3 and res[r]["slab"]["layout"]["reach"] == n * n
         assert np.array_equal(res[r]["slab"]["hist"], ref[r]["slab"]["hist"]) and np.array_equal(res[r]["slab"]["hist"], res[0]["slab"]["hist"])
         assert np.array_equal(res[r]["slab"]["x"], ref[r]["slab"]["x"]) and np.array_equal(res[r]["slab"]["y"], ref[r]["slab"]["y"])
+        for tag in ("restart12", "trunc4_shift_x0"):
+            assert np.array_equal(res[r]["slab"]["more"][tag]["hist"], ref[r]["slab"]["more"][tag]["hist"]), (tag, r)
+            assert np.array_equal(res[r]["slab"]["more"][tag]["x"], ref[r]["slab"]["more"][tag]["x"]), (tag, r)
+            assert np.isfinite(res[r]["slab"]["more"][tag]["hist"]).all() and res[r]["slab"]["more"][tag]["hist"][-1] < res[r]["slab"]["more"][tag]["hist"][0]
     N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
     A = Sparse(N, ncol, rowptr, col, val)
     b = Field((N,), problems.rhs_grid(N, 1))
