@@ -352,15 +352,17 @@ def test_no_operator_applies_in_place():
         assert np.array_equal(f.to_numpy(), before)     # rejected before anything ran
 
 
-@pytest.mark.parametrize("levels,sm_restart,sm_sweeps", [(2, 10, 2), (1, 10, 2), (2, 2, 3)])
-def test_vcycle_bit_for_bit_on_a_256x256_slab(tmp_path, levels, sm_restart, sm_sweeps):
-    """The V-cycle's large-plane kernels against the oracle, bit for bit: level 0 = 16 planes of a 256 x 256 grid (1 M rows: banded row map,
+@pytest.mark.parametrize("levels,sm_restart,sm_sweeps,ne", [(2, 10, 2, 1), (1, 10, 2, 1), (2, 2, 3, 1), (1, 10, 2, 2)])
+def test_vcycle_bit_for_bit_on_a_256x256_slab(tmp_path, levels, sm_restart, sm_sweeps, ne):
+    """(ne = 2: to rounding, see the end.)  The V-cycle's large-plane kernels against the oracle, bit for bit: level 0 = 16 planes of a 256 x 256 grid (1 M rows: banded row map,
     carried window, residual update inside the windowed apply, the post-smoother's last A p' not written, its |b|^2 taken from the
     pre-smoother's pass, prolongator stream skipped — csrc/gcr_fused.hip, gcr_fused_xr_tile.h, gcr.hip, mg.hip), level 1 = 8 x 128 x 128
     (131 072 rows: 8 bands of 16 workgroups, update inside the un-windowed apply), level 2 = 4 x 64 x 64 (the one-launch coarsest
     solve).  Every level's operator tells the oracle its own layout AND row map (oracle Op.set_rowmap).  One cycle, and 6 steps of the
     MG-preconditioned flexible GCR(5).  Also with two levels only (the coarsest solve then works on the 131 072-row level), and with
-    smoothers of 3 sweeps of GCR(2) — a smoother that closes a restart cycle, i.e. not the "shorter than a cycle" shape the other two have."""
+    smoothers of 3 sweeps of GCR(2) — a smoother that closes a restart cycle, i.e. not the "shorter than a cycle" shape the other two have —,
+    and with TWO near-null vectors per aggregate (a constant and a splitmix one: the prolongator is then a stream of numbers again, the
+    coarse operator has two unknowns per aggregate and is no stencil)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -376,8 +378,12 @@ dims, levels = %r, %d
 mg.init()
 N, ncol, rowptr, col, val = problems.poisson3d_box_csr(*dims)
 A = Sparse(N, ncol, rowptr, col, val)
-prm = MG_Param(Mesh(dims), 2, 1, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, %d, %d, 1e-30, False)), levels, None, None,
-               null_vectors=np.ones((1, N), np.complex128))
+ne = %d
+vecs = np.ones((ne, N), np.complex128)
+if ne > 1:
+    vecs[1] = problems.rhs_grid(N, 11)
+prm = MG_Param(Mesh(dims), 2, ne, None, GCR(GCR_Param(0, 10, 50, 1e-2, False)), GCR(GCR_Param(0, %d, %d, 1e-30, False)), levels, None, None,
+               null_vectors=vecs)
 M = MG(A, prm)
 b = problems.rhs_grid(N, 0)
 y = M(Field(dims, b)).to_numpy()
@@ -387,19 +393,25 @@ outer.solve(Field(dims, b), xs)
 lay = []
 for l in range(levels + 1):
     op = M.level_operator(l) if l else A
-    d = op.ell_layout()
-    lay.append([d["ell_width"], d["lanes"], d["tail_chunk_cap"], d["tail_rows"], M.level_info(l)["dim"], d["reach"], op.xr_fuse_kind()])
+    try:
+        d = op.ell_layout()
+        lay.append([d["ell_width"], d["lanes"], d["tail_chunk_cap"], d["tail_rows"], M.level_info(l)["dim"], d["reach"], op.xr_fuse_kind()])
+    except MgcrError:     # a coarse level with several unknowns per aggregate is a block operator: no row layout, plain sums
+        lay.append([-1, 1, 0, 0, M.level_info(l)["dim"], 0, 0])
 np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), resident=mg.stat("resident_solves"),
          hist=outer.last_history, x=xs.to_numpy().ravel(), its=outer.last_iterations)
-""" % (root, dims, levels, sm_restart, sm_sweeps, out)
+""" % (root, dims, levels, ne, sm_restart, sm_sweeps, out)
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MGCR_SMALL_SOLVE_ROWS="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     got = np.load(out)
-    assert got["small"] == 0 and got["resident"] > 0 and got["lay"][0][6] == 2        # level 0: update inside the windowed apply
+    assert got["small"] == 0 and (ne > 1 or got["resident"] > 0) and got["lay"][0][6] == 2   # level 0: update inside the windowed apply (a block coarsest operator has no one-launch solver)
     N, ncol, rowptr, col, val = problems.poisson3d_box_csr(*dims)
     b = problems.rhs_grid(N, 0)
     Ao = orc.csr(N, ncol, rowptr, col, val)
-    Mo = orc.MG(Ao, rowptr, col, val, dims, (1, 1, 1), 2, np.ones((1, N), np.complex128), levels + 1,
+    vecs = np.ones((ne, N), np.complex128)
+    if ne > 1:
+        vecs[1] = problems.rhs_grid(N, 11)
+    Mo = orc.MG(Ao, rowptr, col, val, dims, (1, 1, 1), 2, vecs, levels + 1,
                 orc.gcr_param(restart=sm_restart, max_iter=sm_sweeps, tol=1e-30), orc.gcr_param(restart=10, max_iter=50, tol=1e-2))
     keep, maps = [], []
     for l in range(levels + 1):
@@ -408,12 +420,20 @@ np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), re
         assert op.dim == dim
         band, per = orc.row_map(dim, reach)
         plane = orc.row_map_plane(dim, reach)
-        keep.append(op.set_layout(w, lanes, cap).set_rowmap(band, per, plane, init_banded=band > 0, xr_banded=band > 0 and kind in (1, 2)))
+        if w >= 0:
+            keep.append(op.set_layout(w, lanes, cap).set_rowmap(band, per, plane, init_banded=band > 0, xr_banded=band > 0 and kind in (1, 2)))
         maps.append((dim, reach, band, per, plane, kind))
-    assert maps[0][2] > 0 and maps[1][2] > 0 and (levels == 1 or maps[2][2] == 0), maps   # two banded levels, the coarsest of three plain
+    assert maps[0][2] > 0 and (ne > 1 or maps[1][2] > 0) and (levels == 1 or maps[2][2] == 0), maps   # two banded levels, the coarsest of three plain
     with orc.device_order(lean=True, recurrence_residual=True):
         yo = Mo(b)
         xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=6, tol=1e-30, right=Mo, flexible=True), b)
+    if ne > 1:
+        # two unknowns per aggregate: the Galerkin coarse operator is a block operator whose entries the device assembles in its own order
+        # (no model of that in the oracle): agreement to rounding, not to the bit
+        assert np.abs(got["y"] - yo).max() <= 1e-9 * np.abs(yo).max()
+        assert int(got["its"]) == ito and np.max(np.abs(got["hist"] - ho) / ho) <= 1e-9
+        assert np.abs(got["x"] - xo).max() <= 1e-9 * np.abs(xo).max()
+        return
     assert np.array_equal(got["y"], yo), "cycle: max rel dev %.3e" % (np.abs(got["y"] - yo).max() / np.abs(yo).max())
     assert int(got["its"]) == ito and np.array_equal(got["hist"], ho), (got["hist"], ho)
     assert np.array_equal(got["x"], xo), "x: max rel dev %.3e" % (np.abs(got["x"] - xo).max() / np.abs(xo).max())
