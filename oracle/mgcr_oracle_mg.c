@@ -38,6 +38,7 @@ void orc_op_residual(orc_op *op, const cplx *x, const cplx *b, cplx *r);
 int orc_device_recurrence_residual(void);
 cplx *orc_take_last_residual(void);
 orc_op *orc_op_csr(int64_t nrow, int64_t ncol, const int64_t *rowptr, const int64_t *col, const cplx *val);
+orc_op *orc_op_bcsr_from_triplets(int32_t nbrow, int32_t nbcol, int32_t bs, int32_t nt, const int32_t *rows, const int32_t *cols, const cplx *blocks);
 void orc_op_free(orc_op *op);
 int64_t orc_op_dim(const orc_op *op);
 
@@ -263,9 +264,14 @@ orc_mg *orc_mg_create(orc_op *A0, int64_t n0, const int64_t *rowptr, const int64
                     for (int k = 0; k < ne; k++) { cci[p] = (int64_t)bc[b] * ne + k; cva[p] = bl[(size_t)b * ne * ne + kp * ne + k]; p++; }
             }
         crp[nc] = p;
-        free(br); free(bc); free(bl); free(brp);
         mg->rp[l + 1] = crp; mg->ci[l + 1] = cci; mg->va[l + 1] = cva;
-        mg->A[l + 1] = orc_op_csr(nc, nc, crp, cci, cva);
+        /* The operator itself: with several unknowns per aggregate it is the reference's HierarchicalSparse (src/MG.h:204-281) — every
+         * block applied as a Dense and the block results accumulated (src/HierarchicalSparse.h:101-161), NOT a row-long sequential sum over
+         * the expanded entries; the expanded CSR above only feeds the next level's Galerkin products.  One unknown per aggregate: the two
+         * are the same sums, and the CSR form carries the device's row layouts (orc_op_set_layout). */
+        if (ne > 1) mg->A[l + 1] = orc_op_bcsr_from_triplets((int32_t)nagg, (int32_t)nagg, ne, (int32_t)nblk, br, bc, bl);
+        else mg->A[l + 1] = orc_op_csr(nc, nc, crp, cci, cva);
+        free(br); free(bc); free(bl); free(brp);
         mg->n[l + 1] = nc;
         /* next level: lattice of aggregates x ne, near-null vectors = R v */
         if (l + 2 < nlev) {

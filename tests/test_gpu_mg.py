@@ -354,7 +354,7 @@ def test_no_operator_applies_in_place():
 
 @pytest.mark.parametrize("levels,sm_restart,sm_sweeps,ne", [(2, 10, 2, 1), (1, 10, 2, 1), (2, 2, 3, 1), (1, 10, 2, 2)])
 def test_vcycle_bit_for_bit_on_a_256x256_slab(tmp_path, levels, sm_restart, sm_sweeps, ne):
-    """(ne = 2: to rounding, see the end.)  The V-cycle's large-plane kernels against the oracle, bit for bit: level 0 = 16 planes of a 256 x 256 grid (1 M rows: banded row map,
+    """The V-cycle's large-plane kernels against the oracle, bit for bit: level 0 = 16 planes of a 256 x 256 grid (1 M rows: banded row map,
     carried window, residual update inside the windowed apply, the post-smoother's last A p' not written, its |b|^2 taken from the
     pre-smoother's pass, prolongator stream skipped — csrc/gcr_fused.hip, gcr_fused_xr_tile.h, gcr.hip, mg.hip), level 1 = 8 x 128 x 128
     (131 072 rows: 8 bands of 16 workgroups, update inside the un-windowed apply), level 2 = 4 x 64 x 64 (the one-launch coarsest
@@ -362,7 +362,8 @@ def test_vcycle_bit_for_bit_on_a_256x256_slab(tmp_path, levels, sm_restart, sm_s
     MG-preconditioned flexible GCR(5).  Also with two levels only (the coarsest solve then works on the 131 072-row level), and with
     smoothers of 3 sweeps of GCR(2) — a smoother that closes a restart cycle, i.e. not the "shorter than a cycle" shape the other two have —,
     and with TWO near-null vectors per aggregate (a constant and a splitmix one: the prolongator is then a stream of numbers again, the
-    coarse operator has two unknowns per aggregate and is no stencil)."""
+    coarse operator has two unknowns per aggregate — a block operator, the reference's HierarchicalSparse: the oracle applies it block by
+    block as the reference does, oracle/mgcr_oracle_mg.c)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -427,14 +428,15 @@ np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), re
     with orc.device_order(lean=True, recurrence_residual=True):
         yo = Mo(b)
         xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=6, tol=1e-30, right=Mo, flexible=True), b)
-    if ne > 1:
-        # two unknowns per aggregate: the Galerkin coarse operator is a block operator whose entries the device assembles in its own order
-        # (no model of that in the oracle): agreement to rounding, not to the bit
-        assert np.abs(got["y"] - yo).max() <= 1e-9 * np.abs(yo).max()
-        assert int(got["its"]) == ito and np.max(np.abs(got["hist"] - ho) / ho) <= 1e-9
-        assert np.abs(got["x"] - xo).max() <= 1e-9 * np.abs(xo).max()
-        return
     assert np.array_equal(got["y"], yo), "cycle: max rel dev %.3e" % (np.abs(got["y"] - yo).max() / np.abs(yo).max())
+    if ne > 1:
+        # The cycle is bit for bit (above; on further right-hand sides too: tools/mg_ne_bisect.py), the coarse solver alone as well — but the
+        # preconditioned solve around it leaves the oracle's bits at its first step by ~1e-12 in x (alpha_0 = <r,A z>/<A z,A z> is a sum with
+        # cancellation: a last-bit difference of z inside the solve suffices).  With one vector per aggregate the same solve is bit for bit
+        # (the cases above), at 16^3 with two vectors as well: open — booked as agreement to rounding.
+        assert int(got["its"]) == ito and np.max(np.abs(got["hist"] - ho) / ho) <= 1e-10
+        assert np.abs(got["x"] - xo).max() <= 1e-10 * np.abs(xo).max()
+        return
     assert int(got["its"]) == ito and np.array_equal(got["hist"], ho), (got["hist"], ho)
     assert np.array_equal(got["x"], xo), "x: max rel dev %.3e" % (np.abs(got["x"] - xo).max() / np.abs(xo).max())
 
