@@ -479,12 +479,23 @@ static int gcr_solve_impl(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, c
 int orc_gcr_solve(orc_op *A, const orc_gcr_param *gp, const cplx *rhs, cplx *x, double *hist, int hist_cap,
                   int *converged) {
     const orc_op *b0 = A->kind == OP_DIRAC && A->D ? A->D : A;
-    if (!b0->has_rowmap) return gcr_solve_impl(A, gp, rhs, x, hist, hist_cap, converged);
-    /* this operator's own row map (a level of a hierarchy): in force for this solve, nested solves set their own */
+    /* The row map in force for THIS solve: the operator's own (a level of a hierarchy) or, for an operator without one, the map
+     * orc_set_device_model / _plane / _xr_banded set — never the one an ENCLOSING solve on another operator put in place (a coarse solve
+     * inside the preconditioner of a solve on a banded level would otherwise inherit that level's bands).  Nested solves do the same. */
+    static int depth = 0;
+    static int64_t base_band, base_plane;
+    static int base_per, base_ib, base_xb;
+    if (depth == 0) { base_band = g_dev_band; base_plane = g_dev_plane; base_per = g_dev_per; base_ib = g_dev_init_banded; base_xb = g_dev_xr_banded; }
     const int64_t band = g_dev_band, plane = g_dev_plane;
     const int per = g_dev_per, ib = g_dev_init_banded, xb = g_dev_xr_banded;
-    g_dev_band = b0->rm_band; g_dev_per = b0->rm_per; g_dev_plane = b0->rm_plane; g_dev_init_banded = b0->rm_init_banded; g_dev_xr_banded = b0->rm_xr_banded;
+    if (b0->has_rowmap) {
+        g_dev_band = b0->rm_band; g_dev_per = b0->rm_per; g_dev_plane = b0->rm_plane; g_dev_init_banded = b0->rm_init_banded; g_dev_xr_banded = b0->rm_xr_banded;
+    } else {
+        g_dev_band = base_band; g_dev_per = base_per; g_dev_plane = base_plane; g_dev_init_banded = base_ib; g_dev_xr_banded = base_xb;
+    }
+    depth++;
     const int rc = gcr_solve_impl(A, gp, rhs, x, hist, hist_cap, converged);
+    depth--;
     g_dev_band = band; g_dev_per = per; g_dev_plane = plane; g_dev_init_banded = ib; g_dev_xr_banded = xb;
     return rc;
 }

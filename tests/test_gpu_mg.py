@@ -429,14 +429,6 @@ np.savez(%r, y=y, lay=np.array(lay, np.int64), small=mg.stat("small_solves"), re
         yo = Mo(b)
         xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=6, tol=1e-30, right=Mo, flexible=True), b)
     assert np.array_equal(got["y"], yo), "cycle: max rel dev %.3e" % (np.abs(got["y"] - yo).max() / np.abs(yo).max())
-    if ne > 1:
-        # The cycle is bit for bit (above; on further right-hand sides too: tools/mg_ne_bisect.py), the coarse solver alone as well — but the
-        # preconditioned solve around it leaves the oracle's bits at its first step by ~1e-12 in x (alpha_0 = <r,A z>/<A z,A z> is a sum with
-        # cancellation: a last-bit difference of z inside the solve suffices).  With one vector per aggregate the same solve is bit for bit
-        # (the cases above), at 16^3 with two vectors as well: open — booked as agreement to rounding.
-        assert int(got["its"]) == ito and np.max(np.abs(got["hist"] - ho) / ho) <= 1e-10
-        assert np.abs(got["x"] - xo).max() <= 1e-10 * np.abs(xo).max()
-        return
     assert int(got["its"]) == ito and np.array_equal(got["hist"], ho), (got["hist"], ho)
     assert np.array_equal(got["x"], xo), "x: max rel dev %.3e" % (np.abs(got["x"] - xo).max() / np.abs(xo).max())
 
