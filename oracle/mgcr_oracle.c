@@ -162,7 +162,7 @@ static double dev_sum_ranks(int64_t n, const double *term, int banded) {
     double tot = 0.;
     for (int r = 0; r < g_dev_nranks; r++) {
         const int64_t a = g_dev_rank_off[r], b = g_dev_rank_off[r + 1];
-        tot += dev_sum(b - a, term + a, 0); /* (the banded row map is a matter of >= 2^23-row blocks: single-rank tests cover it) */
+        tot += dev_sum(b - a, term + a, banded); /* (every rank deals ITS rows by the map of its block: band / per as set for a rank's row count) */
     }
     (void)n;
     return tot;

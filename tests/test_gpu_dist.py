@@ -59,6 +59,17 @@ def test_distributed_slab_carried_window(tmp_path, monkeypatch, n, nz):
     g.solve(b, xs)
     h = res[0]["slab"]["hist"]
     assert h.size == g.last_history.size and np.max(np.abs(h - g.last_history) / g.last_history) < 1e-12
+    # ... and bit for bit against the oracle's rank model WITH each rank's banded row map (equal blocks: one map for all): the distributed
+    # solve keeps the update kernel (plain |r|^2), its first step and its dot products run in the apply kernels' order
+    nloc = N // world
+    band, per = orc.row_map(nloc, n * n)
+    with orc.device_order(rank_offsets=np.arange(world + 1, dtype=np.int64) * nloc, band=band, per=per, plane=orc.row_map_plane(nloc, n * n),
+                          init_banded=True, lean=True):
+        Ao = orc.csr(N, ncol, rowptr, col, val)
+        xo, ho, ito, _ = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=12, tol=1e-30), problems.rhs_grid(N, 1))
+    for r in range(world):
+        assert np.array_equal(res[r]["slab"]["hist"], ho), (r, int(np.argmax(res[r]["slab"]["hist"] != ho)))
+    assert np.array_equal(xd_all := np.concatenate([res[r]["slab"]["x"] for r in range(world)]), xo)
     xd = np.concatenate([res[r]["slab"]["x"] for r in range(world)])
     assert np.abs(xd - xs.to_numpy()).max() <= 1e-11 * np.abs(xs.to_numpy()).max()
 
