@@ -86,7 +86,19 @@ int64_t orc_mg_aggregates(int ndim, const int64_t *dims, const int32_t *blocked,
  * order with dot = sum conj(P_j) P_vec over the aggregate's members in ascending global index
  * (the reference sums over the full zero-padded field in index order, which visits the members
  * in that order), P_vec -= P_j * h, then field *= 1./norm. */
+/* The vectors handed to orc_mg_create ARE level 0's prolongator columns (already restricted to the aggregates and orthonormal — e.g. the
+ * prolongator a device set-up produced from its own near-null vectors): take them as they are instead of orthonormalising them once more
+ * (which moves their last bits).  Level 0 only; read once by the next orc_mg_create. */
+static int g_vectors_are_prolongator = 0;
+void orc_mg_set_vectors_are_prolongator(int on) { g_vectors_are_prolongator = on; }
 void orc_mg_prolongator(int64_t n, int ne, int64_t nagg, const int32_t *agg, const cplx *vecs, cplx *pv) {
+    if (g_vectors_are_prolongator) {
+        g_vectors_are_prolongator = 0;
+        for (int64_t i = 0; i < n; i++)
+            for (int k = 0; k < ne; k++) pv[i * ne + k] = vecs[(int64_t)k * n + i];
+        (void)nagg; (void)agg;
+        return;
+    }
     /* member lists in ascending index order */
     int64_t *ptr = (int64_t *)calloc((size_t)nagg + 1, sizeof(int64_t));
     int64_t *mem = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);

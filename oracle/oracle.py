@@ -76,6 +76,7 @@ def lib():
         L.orc_set_device_model.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_device_ranks.argtypes = [C.c_int, _i64p]
         L.orc_op_set_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_mg_set_vectors_are_prolongator.argtypes = [C.c_int]
         L.orc_op_set_rowmap.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int]
         L.orc_set_device_lean.argtypes = [C.c_int, C.c_int]
         L.orc_set_device_xr_banded.argtypes = [C.c_int]
@@ -460,7 +461,9 @@ def mg_galerkin(rowptr, col, val, agg, nagg, pv, shift=None):
 class MG(Op):
     """Corrected multigrid cycle as an operator (see oracle/mgcr_oracle_mg.c)."""
 
-    def __init__(self, A, rowptr, col, val, dims, blocked, sub, vecs, nlev, smoother, coarse, damping=1.0, shift=None):
+    def __init__(self, A, rowptr, col, val, dims, blocked, sub, vecs, nlev, smoother, coarse, damping=1.0, shift=None, vectors_are_prolongator=False):
+        """vectors_are_prolongator: `vecs` are level 0's prolongator columns as they stand (orthonormal per aggregate already): not
+        orthonormalised again."""
         rowptr = np.ascontiguousarray(rowptr, np.int64)
         col = np.ascontiguousarray(col, np.int64)
         val = _c(val)
@@ -469,6 +472,8 @@ class MG(Op):
         vecs = _c(vecs)
         ne, n = vecs.shape
         k = complex(shift) if shift is not None else 0j
+        if vectors_are_prolongator:
+            lib().orc_mg_set_vectors_are_prolongator(1)
         self.mg = lib().orc_mg_create(A.h, n, rowptr, col, val, int(shift is not None), k.real, k.imag, dims.size, dims,
                                       blocked, sub, ne, vecs, nlev, C.byref(smoother), C.byref(coarse), damping)
         if not self.mg:

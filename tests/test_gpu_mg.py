@@ -145,6 +145,14 @@ def test_mg_dirac_sample_two_level(sample_matrix_path, mg_gold):
     """Adaptive-aggregation MG on the reference's own sample operator 1 - kD near k_c
     (k_c = 0.20611 for the 4x4 lattice, src/main.cpp:699): near-null vectors by inverse iteration
     on the GPU, chirality doubling, block 2^4 — against the same hierarchy in the oracle."""
+    mg.lib().mgcr_set_small_solve_rows(0)      # (the 64-unknown coarsest solve on the multi-kernel path: the oracle's model below describes that one)
+    try:
+        _mg_dirac_sample_two_level(sample_matrix_path)
+    finally:
+        mg.lib().mgcr_set_small_solve_rows(1024)
+
+
+def _mg_dirac_sample_two_level(sample_matrix_path):
     D = read_data(os.path.basename(sample_matrix_path), directory=os.path.dirname(sample_matrix_path))
     k = 0.19
     dirac = DiracOp(D, k)
@@ -159,15 +167,27 @@ def test_mg_dirac_sample_two_level(sample_matrix_path, mg_gold):
     # span(pv) per aggregate == span(vecs) per aggregate: feed pv's columns (already orthonormal) as vectors
     vecs = np.ascontiguousarray(pv.T)
     Mo = orc.MG(Ao, rowptr, col, val, DIMS, (1, 1, 1, 1, 0, 0), 2, vecs, 2,
-                orc.gcr_param(restart=10, max_iter=2, tol=1e-30), orc.gcr_param(restart=10, max_iter=50, tol=1e-2), shift=k)
+                orc.gcr_param(restart=10, max_iter=2, tol=1e-30), orc.gcr_param(restart=10, max_iter=50, tol=1e-2), shift=k,
+                vectors_are_prolongator=True)      # (orthonormalising pv's columns once more would move their last bits)
+    pvo, aggo = Mo.prolongator(0)
+    assert np.array_equal(aggo, agg) and np.array_equal(pv.reshape(pvo.shape), pvo)
     b = problems.rhs_grid(3072, 4)
     y = M(Field(DIMS, b)).to_numpy()
     yo = Mo(b)
-    assert np.abs(y - yo).max() <= 1e-8 * np.abs(yo).max()
+    assert np.abs(y - yo).max() <= 1e-8 * np.abs(yo).max()           # the oracle in the reference's summation order
     outer = GCR(dirac, GCR_Param(0, 5, 200, 1e-10, False, None, M, flexible=True))
     x = Field(DIMS).set_zero()
     rhs = Field(DIMS, b)
     outer.solve(rhs, x)
+    # ... and in the DEVICE's order (rows of 39 entries: 8 lanes + tree; the coarse operator — 4 unknowns per aggregate — applied block by
+    # block like the reference's HierarchicalSparse; lean cycles; the recurrence residual): the cycle, the whole MG-preconditioned history,
+    # the iteration count and the solution, bit for bit — adaptive aggregation on the reference's own operator
+    lay = dirac.ell_layout()
+    with orc.device_order(ell_width=lay["ell_width"], ell_lanes=lay["lanes"], tail_cap=lay["tail_chunk_cap"], lean=True, recurrence_residual=True):
+        yd = Mo(b)
+        xo, ho, ito, co = orc.gcr_solve(Ao, orc.gcr_param(restart=5, max_iter=200, tol=1e-10, right=Mo, flexible=True), b)
+    assert np.array_equal(y.ravel(), yd)
+    assert outer.last_iterations == ito and np.array_equal(outer.last_history, ho) and np.array_equal(x.to_numpy().ravel(), xo)
     plain = GCR(dirac, GCR_Param(0, 5, 2000, 1e-10, False))
     x2 = Field(DIMS).set_zero()
     plain.solve(rhs, x2)
