@@ -395,6 +395,25 @@ def test_truncated_and_full_gcr_on_a_slab_bit_for_bit(kw, okw):
     assert_bitwise("p256x256x16_%s" % "_".join("%s%d" % kv for kv in sorted(okw.items())), "multi-kernel (banded, carried window)", gcr, ref, None, x)
 
 
+@pytest.mark.parametrize("hook", ["right", "left", "flexible"])
+def test_preconditioner_hooks_on_a_slab_bit_for_bit(hook):
+    """The literal hooks r = M(r) / Ar = Ml(Ar) (src/GCR.h:197-204,236-247) and the flexible right preconditioner on the 256 x 256 x 16 slab,
+    M = 1 + 0.04 D (an operator apply through the carried-window kernel with its shift epilogue): the solver then keeps the update kernel and
+    the plain-order start; 9 steps of GCR(4)."""
+    n, nz = 256, 16
+    N, ncol, rowptr, col, val = problems.poisson3d_csr(n, ni=nz)
+    b = problems.rhs_grid(N, 2)
+    D = Sparse(N, ncol, rowptr, col, val)
+    Do = orc.csr(N, ncol, rowptr, col, val)
+    M, Mo = DiracOp(D, -0.04), orc.dirac(Do, -0.04)
+    flex = hook == "flexible"
+    gp = GCR_Param(0, 4, 9, 1e-13, False, M if hook == "left" else None, None if hook == "left" else M, flexible=flex)
+    po = orc.gcr_param(restart=4, max_iter=9, tol=1e-13, left=Mo if hook == "left" else None, right=None if hook == "left" else Mo, flexible=flex)
+    gcr, x, ref, small = solve_both(D, Do, N, gp, po, b, dims=(nz, n, n))
+    assert not small
+    assert_bitwise("p256x256x16_hook_%s" % hook, "multi-kernel (banded, carried window)", gcr, ref, None, x)
+
+
 def test_carried_window_apply_same_bits():
     """The stand-alone apply (A x and the shifted x - k A x) of the 256 x 256 x 16 slab with and without the carried-window kernel
     (gcr_fused.hip sten_apply_carry_kernel; MGCR_APPLY_CARRY=0 takes spmv.hip's sten_spmv_tile): identical results."""
