@@ -28,13 +28,12 @@ def test_distributed_gcr_with_transport_collectives(tmp_path, monkeypatch):
     test_distributed_gcr_matches_single_process(tmp_path, 2)
 
 
-@pytest.mark.parametrize("n,nz", [(256, 16), (200, 28)])
-def test_distributed_slab_carried_window(tmp_path, monkeypatch, n, nz):
+@pytest.mark.parametrize("n,nz,world", [(256, 16, 2), (200, 28, 2), (256, 24, 3)])
+def test_distributed_slab_carried_window(tmp_path, monkeypatch, n, nz, world):
     """Two ranks, 8 planes of a 256 x 256 grid (14 of a 200 x 200 grid: the ragged plane walk) each: the row blocks' windowed kernels carry the far neighbours from trip to trip (the halo
     columns are rare slots of their own).  Same history, same x as with the far neighbours gathered (MGCR_TILE_CARRY=0), on every rank;
     and the single-GPU solve within re-association."""
-    mg.init()
-    world = 2
+    mg.init()          # (3 ranks: the middle one has a halo plane on either side — the leading slot AND the rare one behind the common slots)
     (tmp_path / "carry").mkdir()
     (tmp_path / "gather").mkdir()
     res = run_workers("slab:%d:%d" % (n, nz), world, tmp_path / "carry", timeout=240)
